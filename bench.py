@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): per GPU a batch of B=32 utterance graphs, graph_len L=4096, target length
+T=512, vocab V=8192, fp32, transition window TR (default 32, `--tr 4095` = README's --max-transition-length 99999).
+One STEP = one pass of the DAG training hot path over the batch with inputs resident in HBM:
+    dag_logsoftmax_gather_inplace (K1, softmax stored for backward)
+ -> dag_loss forward (K2 alpha || K3 beta) -> dag_loss backward (K4, K5) -> K1 backward
+ -> dag_best_alignment (K6 + K7, the GLAT alignment).
+`value` = utterances/s over all ranks (weak scaling: every rank owns its own 32 utterances, no data-path collective;
+SURVEY.md §8e); `ms_per_step` is the "dag_loss fwd+bwd ms/batch" of BASELINE.json's metric for this step definition.
+The logits buffer is recycled in place between steps (step s reads what step s-1's K1-backward left there: identical
+bytes, flops and control flow, no extra 8.6 GB restore copy inside the timed region).
+
+Extra objects on the JSON line: `roofline` (the DAG DP forward launch, HIP-event timed on the launch stream, against
+SURVEY.md §8d's algorithmic bytes), `cpu_baseline` (the reference's torch CPU path, twin in oracle/torch_port.py, on a
+bounded sample, rank 0 / N=1 only), `phases_ms` (per-op event timings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "utterances/sec end-to-end S2ST (fbank→waveform) + dag_loss fwd+bwd ms/batch"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tr", type=int, default=32, help="transition window (32 = tuner default, 4095 = README flag)")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--graph-len", type=int, default=4096)
+    ap.add_argument("--tgt-len", type=int, default=512)
+    ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="2,32", help="B,T of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference CPU path (torch_dag_logsoftmax_gather_inplace -> torch_dag_loss fwd+bwd -> torch_dag_best_alignment,
+    dense [B,L,L] links) on a bounded sample of the same workload; cost is linear in B and in T."""
+    import torch
+    from oracle import torch_port
+    cores = os.cpu_count() or 1
+    sb, stt = [int(v) for v in args.cpu_sample.split(",")]
+    L, V = args.graph_len, min(args.vocab, 8192)
+    # dense links make the reference CPU path's cost independent of TR; the sample uses TR=L-1 so the end is reachable
+    r = torch_port.time_cpu_dag_path(sb, stt, L, V, L - 1, threads=cores)
+    sample_s = r["fwd_s"] + r["bwd_s"] + r.get("align_s", 0.0)
+    # linear extrapolation to the full batch: B/sb samples, (T-1)/(stt-1) DP rows (fwd, bwd and alignment all scale so)
+    full_s = sample_s * (args.batch / sb) * ((args.tgt_len - 1) / (stt - 1))
+    return {
+        "value": args.batch / full_s, "unit": "utt/s", "cores": cores, "kind": "port",
+        "threads": torch.get_num_threads(),
+        "sample": f"B={sb},T={stt} of B={args.batch},T={args.tgt_len} at L={L},V={V} (dense links); "
+                  f"measured {sample_s:.2f}s (fwd {r['fwd_s']:.2f} bwd {r['bwd_s']:.2f} align {r.get('align_s', 0):.2f}), "
+                  f"extrapolated linearly in B and T to {full_s:.0f}s per batch",
+        "sample_seconds": sample_s, "extrapolated_batch_seconds": full_s,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    from daspeech_amd import custom_ops as ops
+    from daspeech_amd import _lib
+    _lib.load()
+    import sys as _sys
+    _mod = _sys.modules["daspeech_amd.custom_ops.dag_loss"]
+    lsg_fwd, lsg_bwd = _mod._lsg_forward, _mod._lsg_backward
+
+    B, L, T, V = args.batch, args.graph_len, args.tgt_len, args.vocab
+    TR = min(args.tr, L - 1)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    cg = torch.Generator().manual_seed(1234 + rank)
+    logits = torch.randn(B, L, V, device=dev, generator=gen)
+    out_len = (L - torch.randint(0, 5, (B,), generator=cg)).to(dev)
+    tgt_len = (T - torch.randint(0, 5, (B,), generator=cg)).to(dev)
+    tgt = torch.randint(4, V, (B, T), generator=cg).to(dev)
+    raw = torch.randn(B, L, TR, device=dev, generator=gen)
+    i = torch.arange(L, device=dev).view(1, L, 1)
+    d = torch.arange(TR, device=dev).view(1, 1, TR)
+    valid = (i + d + 1) < out_len.view(B, 1, 1)
+    dead = ~valid.any(-1, keepdim=True)
+    links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(dead, 0.0), -1)
+    links = links.masked_fill(~valid, float("-inf")).contiguous()
+    del raw, valid, dead
+    idx = tgt.unsqueeze(1).expand(-1, L, -1)
+
+    names = ["gather_fwd", "dag_fwd", "dag_bwd", "gather_bwd", "best_alignment"]
+    ev = {n: [] for n in names}
+
+    def step(record):
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()              # current stream == the stream the C ABI launches on
+            return e
+        k = links.detach().requires_grad_()
+        e0 = mark()
+        # K1 through the same launch wrappers the autograd Function uses (the logits buffer is a recycled leaf here,
+        # so the Function's mark_dirty contract cannot be exercised on it; tests cover the Function itself)
+        match_all = lsg_fwd(logits, idx, True).requires_grad_()               # [B,T,L] contiguous
+        e1 = mark()
+        loss = ops.dag_loss(match_all, k, out_len, tgt_len)
+        e2 = mark()
+        obj = -(loss / tgt_len).mean()
+        go = torch.autograd.grad(obj, [loss], retain_graph=True)[0]
+        e2b = mark()
+        gm, gk = torch.autograd.grad(loss, [match_all, k], grad_outputs=go)
+        e3 = mark()
+        gx = lsg_bwd(logits, idx, gm.transpose(1, 2))
+        e4 = mark()
+        with torch.no_grad():
+            path = ops.dag_best_alignment(match_all.detach(), links, out_len, tgt_len)
+        e5 = mark()
+        if record:
+            for n, (a, b) in zip(names, [(e0, e1), (e1, e2), (e2b, e3), (e3, e4), (e4, e5)]):
+                ev[n].append((a, b))
+        return loss, gx, gk, path
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out[0]).all(), "non-finite loss in the benchmark batch"
+
+    phases = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / max(1, len(ev[n])) for n in names}
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * args.steps / elapsed
+
+    # roofline of the DAG DP forward launch (alpha + beta): SURVEY.md §8(d)
+    #   2 * (B*T*L*4 [read match] + B*L*TR*4 [read links] + B*T*L*4 [write alpha/beta])
+    alg_bytes = 2.0 * (B * T * L * 4 + B * L * TR * 4 + B * T * L * 4)
+    dag_fwd_ms = phases["dag_fwd"]
+    achieved = alg_bytes / (dag_fwd_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_dag_fwd.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(f"tr{TR}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "dag_loss forward DP (alpha||beta, one launch)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes": alg_bytes, "avg_launch_ms": dag_fwd_ms}
+
+    result = {
+        "metric": METRIC, "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2 DAG training hot path: logsoftmax_gather + dag_loss fwd+bwd + dag_best_alignment, "
+                               f"B={B}/GPU, graph_len={L}, tgt_len={T}, vocab={V}, TR={TR}, fp32",
+                   "batch_per_gpu": B, "graph_len": L, "tgt_len": T, "vocab": V, "trans_len": TR,
+                   "parallelism": f"dp{world} (independent utterances per rank, no data-path collective)"},
+        "roofline": roofline, "phases_ms": phases,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI in include/daspeech_dag.h (libdaspeech_hip.so).
+
+The product path has NO CPU fallback: if the shared object is missing or a call fails this raises.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "lib", "libdaspeech_hip.so")
+
+ABI_VERSION = 1
+DTYPE_CODES = {"torch.float32": 0, "torch.float16": 1, "torch.bfloat16": 2}
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_p = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/daspeech_dag.h (tests check this).
+SIGNATURES = {
+    "dsp_abi_version": (_c_int, []),
+    "dsp_last_error": (ctypes.c_char_p, []),
+    "dsp_logsoftmax_gather": (_c_int, [_c_p, _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
+                                       _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_logsoftmax_gather_bwd": (_c_int, [_c_p, _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
+                                           _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "dsp_dag_loss_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                  _c_p, _c_sz, _c_p]),
+    "dsp_dag_loss_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                  _c_p, _c_sz, _c_p]),
+    "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+}
+
+_lib = None
+
+
+class DaspeechHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdaspeech_hip.so (once).  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise DaspeechHipError(
+            f"{SO_PATH} is missing: build it with `python -m daspeech_amd.build` (hipcc, gfx950). "
+            "daspeech_amd has no CPU fallback for its HIP ops.")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dsp_abi_version() != ABI_VERSION:
+        raise DaspeechHipError(f"ABI version mismatch: library {lib.dsp_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dsp_last_error().decode("utf-8", "replace")
+        raise DaspeechHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_handle():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

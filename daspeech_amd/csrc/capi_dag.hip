@@ -1,0 +1,59 @@
+// capi_dag.hip — extern "C" entry points of the DP ops (argument checks + kernel selection).
+#include "common.h"
+
+namespace dsp {
+int launch_dag_fwd_generic(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+int launch_pick_loss(const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, hipStream_t);
+int launch_best_alignment_generic(const float*, const float*, const int64_t*, const int64_t*, float*, int32_t*, int64_t*, int, int, int, int, hipStream_t);
+int launch_dag_bwd_generic(const float*, const float*, const float*, const float*, const float*, const int64_t*, const int64_t*,
+                           float*, float*, int, int, int, int, hipStream_t);
+
+static int check_dims(const char* fn, int B, int T, int L, int TR) {
+    if (B < 0 || T < 1 || L < 1 || TR < 1) { set_error("%s: bad sizes B=%d T=%d L=%d TR=%d", fn, B, T, L, TR); return DSP_EINVAL; }
+    return DSP_OK;
+}
+}  // namespace dsp
+
+using namespace dsp;
+
+extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR) { (void)B; (void)T; (void)L; (void)TR; return 0; }
+
+extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
+                                void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    (void)workspace; (void)workspace_bytes;
+    int rc = check_dims("dag_loss_fwd", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
+    if (rc) return rc;
+    if (loss) rc = launch_pick_loss(alpha, beta, out_len, tgt_len, loss, B, T, L, st);
+    return rc;
+}
+
+extern "C" int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* beta, const float* match,
+                                const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                float* grad_match, float* grad_links, int B, int T, int L, int TR,
+                                void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    (void)workspace; (void)workspace_bytes;
+    int rc = check_dims("dag_loss_bwd", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!grad_out || !alpha || !beta || !match || !links || !out_len || !tgt_len) { set_error("dag_loss_bwd: null pointer"); return DSP_EINVAL; }
+    return launch_dag_bwd_generic(grad_out, alpha, beta, match, links, out_len, tgt_len, grad_match, grad_links, B, T, L, TR, as_stream(stream));
+}
+
+extern "C" int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                      float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                                      dsp_stream_t stream)
+{
+    int rc = check_dims("dag_best_alignment", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
+    return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, as_stream(stream));
+}

@@ -1,0 +1,277 @@
+// logsoftmax_gather.hip — K1 and its backward for gfx950.
+//
+// What it replaces: DASpeech/custom_ops/logsoftmax_gather.cu:256-377 (forward, in-place softmax side effect)
+// and the Python backward in DASpeech/custom_ops/dag_loss.py:293-295.
+//
+// Design (HBM-bound op; SURVEY.md §8d: algorithmic bytes = B*L*V*s_in [+ the same again when the softmax is
+// stored] + B*S*L*4):
+//   * one 256-thread workgroup walks a tile of RT consecutive vertices (rows of V logits);
+//   * pass A reads the row ONCE from HBM with 16-byte loads keeping an online (max, sum) per lane, wave shuffles
+//     + one LDS hop combine them; the gather and the optional softmax store re-read the row while it is still
+//     L2-resident (a row is <= a few tens of KB), so HBM sees one read and at most one write per logit;
+//   * gathered values are staged in LDS as [S][RT] so that the [B,S,L] ("match_all") layout is written in
+//     RT-float contiguous runs instead of 4-byte scatters — the reference wrote [B,L,S] and paid a transpose copy
+//     (nat_dag_loss.py:128 + dag_loss.py:103).
+#include "common.h"
+
+namespace dsp {
+
+template <typename T> struct Vec;                 // 16-byte vector of T
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<__half> { static constexpr int N = 8; };
+template <> struct Vec<__hip_bfloat16> { static constexpr int N = 8; };
+
+template <typename T>
+__device__ __forceinline__ void load16(const T* p, float (&f)[Vec<T>::N]) {
+    uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < Vec<T>::N; ++i) f[i] = to_f(e[i]);
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const float (&f)[Vec<T>::N]) {
+    uint4 raw;
+    T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < Vec<T>::N; ++i) e[i] = from_f<T>(f[i]);
+    *reinterpret_cast<uint4*>(p) = raw;
+}
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    float nm = fmaxf(m, m2);
+    if (nm == NEG_INF) { s = 0.f; m = nm; return; }
+    s = s * __expf(m - nm) + s2 * __expf(m2 - nm);
+    m = nm;
+}
+
+// block-wide (max, sum-exp) of one row; result broadcast to every thread. red = 2*8 floats of LDS.
+template <typename T, bool VEC>
+__device__ __forceinline__ void row_max_sum(const T* row, int V, float* red, float& m_out, float& s_out) {
+    constexpr int N = Vec<T>::N;
+    float m = NEG_INF, s = 0.f;
+    if (VEC) {
+        for (int v = threadIdx.x * N; v < V; v += blockDim.x * N) {
+            float f[N];
+            load16(row + v, f);
+            float lm = f[0];
+#pragma unroll
+            for (int i = 1; i < N; ++i) lm = fmaxf(lm, f[i]);
+            float nm = fmaxf(m, lm);
+            if (nm != NEG_INF) {
+                float acc = s * __expf(m - nm);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += __expf(f[i] - nm);
+                s = acc;
+            }
+            m = nm;
+        }
+    } else {
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            float x = to_f(row[v]);
+            float nm = fmaxf(m, x);
+            if (nm != NEG_INF) s = s * __expf(m - nm) + __expf(x - nm);
+            m = nm;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                          // red[] free (previous row's readers are done)
+    if ((threadIdx.x & 63) == 0) { red[wave] = m; red[8 + wave] = s; }
+    __syncthreads();
+    m = red[0]; s = red[8];
+    for (int w = 1; w < nw; ++w) online_merge(m, s, red[w], red[8 + w]);
+    m_out = m; s_out = s;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void lsg_fwd_kernel(
+    T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
+    float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
+    int B, int L, int V, int S, int RT, int write_softmax)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                // 16 floats
+    float* stage = smem + 16;         // [S][RT]
+    constexpr int N = Vec<T>::N;
+    const int tiles_per_b = (L + RT - 1) / RT;
+    const long ntiles = (long)B * tiles_per_b;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_b);
+        const int j0 = (int)(tile % tiles_per_b) * RT;
+        const int nr = min(RT, L - j0);
+        for (int r = 0; r < nr; ++r) {
+            T* row = x + ((size_t)b * L + (j0 + r)) * V;
+            float m, s;
+            row_max_sum<T, VEC>(row, V, red, m, s);
+            const float ls = __logf(s);
+            for (int k = threadIdx.x; k < S; k += blockDim.x) {
+                int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+                stage[k * RT + r] = (to_f(row[t]) - m) - ls;        // logsoftmax_gather.cu:293
+            }
+            if (write_softmax) {
+                __syncthreads();                                      // gathers read the ORIGINAL logits
+                const float inv = 1.f / s;
+                if (VEC) {
+                    for (int v = threadIdx.x * N; v < V; v += blockDim.x * N) {
+                        float f[N];
+                        load16(row + v, f);
+#pragma unroll
+                        for (int i = 0; i < N; ++i) f[i] = __expf(f[i] - m) * inv;
+                        store16(row + v, f);
+                    }
+                } else {
+                    for (int v = threadIdx.x; v < V; v += blockDim.x)
+                        row[v] = from_f<T>(__expf(to_f(row[v]) - m) * inv);
+                }
+            }
+        }
+        __syncthreads();
+        const int tot = S * nr;
+        if (osj == 1 || oss != 1) {          // runs along the vertex axis: [B,S,L] layout
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                int k = e / nr, r = e - k * nr;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        } else {                             // runs along S: the reference's [B,L,S] layout
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                int r = e / S, k = e - r * S;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward: row <- softmax * (-(sum_s g)) + scatter_add(g)     (dag_loss.py:293-295)
+// The per-row scatter targets are accumulated in an LDS image of the row (ds_add_f32), so duplicates add up
+// exactly like scatter_add_ and the row is still written once.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void lsg_bwd_kernel(
+    T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
+    const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
+    int B, int L, int V, int S)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;            // 16 floats
+    float* delta = smem + 16;     // [V]
+    constexpr int N = Vec<T>::N;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) delta[v] = 0.f;
+    __syncthreads();
+    const long nrows = (long)B * L;
+    for (long rowi = blockIdx.x; rowi < nrows; rowi += gridDim.x) {
+        const int b = (int)(rowi / L), j = (int)(rowi % L);
+        T* row = x + (size_t)rowi * V;
+        float gs = 0.f;
+        for (int k = threadIdx.x; k < S; k += blockDim.x) {
+            float gv = g[b * gsb + (int64_t)j * gsj + k * gss];
+            int64_t t = idx[b * isb + (int64_t)j * isj + k * iss];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            gs += gv;
+            atomicAdd(&delta[t], gv);
+        }
+        gs = wave_sum(gs);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+        const float neg = -tot;
+        if (VEC) {
+            for (int v = threadIdx.x * N; v < V; v += blockDim.x * N) {
+                float f[N];
+                load16(row + v, f);
+#pragma unroll
+                for (int i = 0; i < N; ++i) f[i] = f[i] * neg + delta[v + i];
+                store16(row + v, f);
+            }
+        } else {
+            for (int v = threadIdx.x; v < V; v += blockDim.x)
+                row[v] = from_f<T>(to_f(row[v]) * neg + delta[v]);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < S; k += blockDim.x) {       // re-zero only what was touched
+            int64_t t = idx[b * isb + (int64_t)j * isj + k * iss];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            delta[t] = 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj, int64_t iss, float* match,
+                      int64_t osb, int64_t osj, int64_t oss, int B, int L, int V, int S, int ws, hipStream_t st)
+{
+    constexpr int N = Vec<T>::N;
+    const bool vec = (V % N == 0) && ((uintptr_t)logits % 16 == 0);
+    int RT = 16;
+    while (RT > 1 && (size_t)S * RT * 4 > 60 * 1024) RT >>= 1;
+    if ((size_t)S * RT * 4 > 150 * 1024) { set_error("logsoftmax_gather: S=%d too large for LDS staging", S); return DSP_EINVAL; }
+    if (RT > L) { RT = 1; while (RT * 2 <= L) RT *= 2; }
+    const size_t lds = (16 + (size_t)S * RT) * sizeof(float);
+    const long ntiles = (long)B * ((L + RT - 1) / RT);
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    auto k = vec ? lsg_fwd_kernel<T, true> : lsg_fwd_kernel<T, false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
+                       B, L, V, S, RT, ws);
+    return check_launch("logsoftmax_gather");
+}
+
+template <typename T>
+static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, int64_t iss, const float* g,
+                      int64_t gsb, int64_t gsj, int64_t gss, int B, int L, int V, int S, hipStream_t st)
+{
+    constexpr int N = Vec<T>::N;
+    const bool vec = (V % N == 0) && ((uintptr_t)sm % 16 == 0);
+    const size_t lds = (16 + (size_t)V) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("logsoftmax_gather_bwd: V=%d exceeds the LDS row image (max ~40k)", V); return DSP_EINVAL; }
+    const long nrows = (long)B * L;
+    const int grid = (int)(nrows < 2048 ? nrows : 2048);
+    auto k = vec ? lsg_bwd_kernel<T, true> : lsg_bwd_kernel<T, false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S);
+    return check_launch("logsoftmax_gather_bwd");
+}
+
+}  // namespace dsp
+
+extern "C" int dsp_logsoftmax_gather(void* logits, int dtype, const int64_t* idx, int64_t idx_sb, int64_t idx_sj,
+                                     int64_t idx_ss, float* match, int64_t out_sb, int64_t out_sj, int64_t out_ss,
+                                     int B, int L, int V, int S, int write_softmax, dsp_stream_t stream)
+{
+    using namespace dsp;
+    if (B < 0 || L < 0 || V <= 0 || S < 0) { set_error("logsoftmax_gather: bad sizes B=%d L=%d V=%d S=%d", B, L, V, S); return DSP_EINVAL; }
+    if (B == 0 || L == 0) return DSP_OK;
+    if (!logits || (S > 0 && (!idx || !match))) { set_error("logsoftmax_gather: null pointer"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case DSP_F32: return launch_fwd<float>(logits, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, write_softmax, st);
+        case DSP_F16: return launch_fwd<__half>(logits, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, write_softmax, st);
+        case DSP_BF16: return launch_fwd<__hip_bfloat16>(logits, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, write_softmax, st);
+    }
+    set_error("logsoftmax_gather: unsupported dtype code %d", dtype);
+    return DSP_EINVAL;
+}
+
+extern "C" int dsp_logsoftmax_gather_bwd(void* softmax_inout, int dtype, const int64_t* idx, int64_t idx_sb,
+                                         int64_t idx_sj, int64_t idx_ss, const float* g, int64_t g_sb, int64_t g_sj,
+                                         int64_t g_ss, int B, int L, int V, int S, dsp_stream_t stream)
+{
+    using namespace dsp;
+    if (B < 0 || L < 0 || V <= 0 || S < 0) { set_error("logsoftmax_gather_bwd: bad sizes"); return DSP_EINVAL; }
+    if (B == 0 || L == 0) return DSP_OK;
+    if (!softmax_inout || (S > 0 && (!idx || !g))) { set_error("logsoftmax_gather_bwd: null pointer"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case DSP_F32: return launch_bwd<float>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
+        case DSP_F16: return launch_bwd<__half>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
+        case DSP_BF16: return launch_bwd<__hip_bfloat16>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
+    }
+    set_error("logsoftmax_gather_bwd: unsupported dtype code %d", dtype);
+    return DSP_EINVAL;
+}

@@ -1,0 +1,333 @@
+"""Operator API of the DAG dynamic-programming ops — drop-in for DASpeech/custom_ops/dag_loss.py.
+
+Same eight public names, argument order, return types and side effects as the reference
+(DASpeech/custom_ops/__init__.py:1):
+
+    dag_loss(match_all, links, output_length, target_length) -> loss[B]                 (dag_loss.py:66-121,187)
+    dag_loss_with_alpha_beta(...) -> (loss[B], (alpha, beta))                            (dag_loss.py:123-188)
+    dag_best_alignment(...) -> path[B,L] int64                                           (dag_loss.py:190-236)
+    dag_logsoftmax_gather_inplace(word_ins_out, select_idx) -> (word_ins_out, match)     (dag_loss.py:238-299)
+    torch_dag_loss / torch_dag_best_alignment / torch_dag_logsoftmax_gather_inplace / logsumexp_keepdim
+        the pure-torch variants selected by the criteria's --torch-dag-* flags             (dag_loss.py:303-425)
+
+The first four run hand-written HIP kernels (gfx950) through the C ABI of include/daspeech_dag.h; they raise if
+the shared library is missing or the tensors are not on a GPU — there is NO silent fallback to the torch path.
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * kernels run on torch's CURRENT stream (the reference used legacy stream 0 + private streams);
+  * `match` returned by dag_logsoftmax_gather_inplace is a [B,L,S]-shaped *view* of a contiguous [B,S,L] buffer, so
+    the caller's `.transpose(1, 2)` (nat_dag_loss.py:128) is already contiguous and dag_loss's `.contiguous()` copies
+    nothing; values are identical;
+  * invalid samples (unreachable end, bad lengths) give -inf / zero gradients instead of device asserts
+    (dag_loss.cu:68-69) — the criteria already zero non-finite losses (nat_dag_loss.py:143-145);
+  * Viterbi ties follow the torch implementation's rule (smallest predecessor index), see SURVEY.md §7.
+"""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from .. import _lib
+
+__all__ = ["dag_loss", "dag_loss_with_alpha_beta", "dag_best_alignment", "dag_logsoftmax_gather_inplace",
+           "torch_dag_loss", "torch_dag_best_alignment", "torch_dag_logsoftmax_gather_inplace", "logsumexp_keepdim"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------------------
+
+def _require_gpu(name: str, *tensors: Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}: expected GPU tensors (the HIP ops have no CPU path; use torch_{name} on CPU)")
+        dev = dev or t.device
+        if t.device != dev:
+            raise RuntimeError(f"{name}: tensors are on different devices")
+    return dev
+
+
+def _check_dp_args(name, match_all, links, output_length, target_length):
+    if match_all.dim() != 3 or links.dim() != 3:
+        raise RuntimeError(f"{name}: match_all and links must be 3-D (got {match_all.dim()}-D and {links.dim()}-D)")
+    B, T, L = match_all.shape
+    if links.shape[0] != B or links.shape[1] != L:
+        raise RuntimeError(f"{name}: links must be [batch, prelen, translen] = [{B}, {L}, *], got {tuple(links.shape)}")
+    if output_length.shape != (B,) or target_length.shape != (B,):
+        raise RuntimeError(f"{name}: output_length / target_length must have shape [{B}]")
+    if links.shape[2] < 1 or T < 1 or L < 1:
+        raise RuntimeError(f"{name}: empty dimension")
+    if output_length.dtype != torch.long or target_length.dtype != torch.long:
+        raise RuntimeError(f"{name}: output_length / target_length must be int64")
+    return B, T, L, links.shape[2]
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):
+    dev = _require_gpu("dag_loss", match_all, links, output_length, target_length)
+    B, T, L, TR = _check_dp_args("dag_loss", match_all, links, output_length, target_length)
+    m = _f32c(match_all)
+    k = _f32c(links)
+    ol = output_length.contiguous()
+    tl = target_length.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+        beta = torch.empty((B, T, L), dtype=torch.float32, device=dev) if need_beta else None
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        wsz = lib.dsp_dag_workspace_bytes(B, T, L, TR)
+        ws = torch.empty((wsz,), dtype=torch.uint8, device=dev) if wsz else None
+        rc = lib.dsp_dag_loss_fwd(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta),
+                                  _lib.ptr(loss), B, T, L, TR, _lib.ptr(ws), wsz, _lib.current_stream_handle())
+        _lib.check(rc, "dsp_dag_loss_fwd")
+    return m, k, ol, tl, alpha, beta, loss
+
+
+def _dag_backward(grad_output, alpha, beta, m, k, ol, tl, need_match: bool, need_links: bool):
+    B, T, L = m.shape
+    TR = k.shape[2]
+    dev = m.device
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        go = grad_output.detach().to(torch.float32).contiguous()
+        gm = torch.empty_like(m) if need_match else None
+        gl = torch.empty_like(k) if need_links else None
+        wsz = lib.dsp_dag_workspace_bytes(B, T, L, TR)
+        ws = torch.empty((wsz,), dtype=torch.uint8, device=dev) if wsz else None
+        rc = lib.dsp_dag_loss_bwd(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(m), _lib.ptr(k), _lib.ptr(ol),
+                                  _lib.ptr(tl), _lib.ptr(gm), _lib.ptr(gl), B, T, L, TR, _lib.ptr(ws), wsz,
+                                  _lib.current_stream_handle())
+        _lib.check(rc, "dsp_dag_loss_bwd")
+    return gm, gl
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# HIP-backed autograd functions (class names and tunable class attributes kept from the reference)
+# ----------------------------------------------------------------------------------------------------------------
+
+class DagLossFunc(Function):
+    # launch-config knobs of the CUDA tuner (dag_loss.py:67-69); kept so `DagLossFunc.config = n` does not break
+    # callers — the HIP kernels pick their own geometry.
+    config = 1
+    config1 = 2
+    config2 = 2
+
+    @staticmethod
+    def forward(ctx, match_all, links, output_length, target_length):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
+        ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
+        ctx.in_dtypes = (match_all.dtype, links.dtype)
+        return loss.to(match_all.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None
+        alpha, beta, m, k, ol, tl = ctx.saved_tensors
+        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
+        gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
+        return gm, gl, None, None
+
+
+class DagLossWithAlphaBetaFunc(Function):
+    config = 1
+    config1 = 2
+    config2 = 2
+
+    @staticmethod
+    def forward(ctx, match_all, links, output_length, target_length):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
+        ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
+        ctx.in_dtypes = (match_all.dtype, links.dtype)
+        ctx.mark_non_differentiable(alpha)
+        if beta is not None:
+            ctx.mark_non_differentiable(beta)
+        return loss.to(match_all.dtype), (alpha, beta)
+
+    @staticmethod
+    def backward(ctx, grad_output, unused):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None
+        alpha, beta, m, k, ol, tl = ctx.saved_tensors
+        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
+        gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
+        return gm, gl, None, None
+
+
+dag_loss = DagLossFunc.apply
+dag_loss_with_alpha_beta = DagLossWithAlphaBetaFunc.apply
+
+
+class DagBestAlignmentFunc(Function):
+    config = 1
+
+    @staticmethod
+    def forward(ctx, match_all, links, output_length, target_length):
+        dev = _require_gpu("dag_best_alignment", match_all, links, output_length, target_length)
+        B, T, L, TR = _check_dp_args("dag_best_alignment", match_all, links, output_length, target_length)
+        m = _f32c(match_all)
+        k = _f32c(links)
+        ol = output_length.contiguous()
+        tl = target_length.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+            trace = torch.empty((B, T, L), dtype=torch.int32, device=dev)
+            path = torch.empty((B, L), dtype=torch.long, device=dev)
+            rc = lib.dsp_dag_best_alignment(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
+                                            _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.current_stream_handle())
+            _lib.check(rc, "dsp_dag_best_alignment")
+        ctx.mark_non_differentiable(path)
+        return path
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        assert False, "no backward function for best alignment"
+
+
+dag_best_alignment = DagBestAlignmentFunc.apply
+
+
+def _elem_strides(t: Tensor):
+    return [int(s) for s in t.stride()]
+
+
+def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) -> Tensor:
+    """K1 launch: returns the contiguous [B,S,L] match buffer; word_ins_out becomes softmax if write_softmax."""
+    dev = _require_gpu("dag_logsoftmax_gather_inplace", word_ins_out, select_idx)
+    if word_ins_out.dim() != 3 or select_idx.dim() != 3:
+        raise RuntimeError("dag_logsoftmax_gather_inplace: word_ins_out and select_idx must be 3-D")
+    if not word_ins_out.is_contiguous():
+        raise RuntimeError("dag_logsoftmax_gather_inplace: word_ins_out must be contiguous (it is modified in place)")
+    code = _lib.DTYPE_CODES.get(str(word_ins_out.dtype))
+    if code is None:
+        raise RuntimeError(f"dag_logsoftmax_gather_inplace: unsupported dtype {word_ins_out.dtype}")
+    if select_idx.dtype != torch.long:
+        raise RuntimeError("dag_logsoftmax_gather_inplace: select_idx must be int64")
+    B, L, V = word_ins_out.shape
+    if select_idx.shape[0] != B or select_idx.shape[1] != L:
+        raise RuntimeError("dag_logsoftmax_gather_inplace: select_idx must be [batch, prelen, slen]")
+    S = select_idx.shape[2]
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        buf = torch.empty((B, S, L), dtype=torch.float32, device=dev)      # "match_all" layout
+        isb, isj, iss = _elem_strides(select_idx)
+        rc = lib.dsp_logsoftmax_gather(_lib.ptr(word_ins_out), code, _lib.ptr(select_idx), isb, isj, iss,
+                                       _lib.ptr(buf), S * L, 1, L, B, L, V, S, 1 if write_softmax else 0,
+                                       _lib.current_stream_handle())
+        _lib.check(rc, "dsp_logsoftmax_gather")
+    return buf
+
+
+def _lsg_backward(softmax_inout: Tensor, select_idx: Tensor, grad_match_bls: Tensor) -> Tensor:
+    """K1 backward launch: softmax_inout [B,L,V] -> d/d logits in place; grad_match_bls is [B,L,S]-shaped (any strides)."""
+    B, L, V = softmax_inout.shape
+    S = select_idx.shape[2]
+    g = grad_match_bls.detach()
+    if g.dtype != torch.float32:
+        g = g.float()
+    code = _lib.DTYPE_CODES[str(softmax_inout.dtype)]
+    lib = _lib.load()
+    with torch.cuda.device(softmax_inout.device):
+        isb, isj, iss = _elem_strides(select_idx)
+        gsb, gsj, gss = _elem_strides(g)
+        rc = lib.dsp_logsoftmax_gather_bwd(_lib.ptr(softmax_inout), code, _lib.ptr(select_idx), isb, isj, iss,
+                                           _lib.ptr(g), gsb, gsj, gss, B, L, V, S, _lib.current_stream_handle())
+        _lib.check(rc, "dsp_logsoftmax_gather_bwd")
+    return softmax_inout
+
+
+class DagLogsoftmaxGatherFunc(Function):
+
+    @staticmethod
+    def forward(ctx, word_ins_out, select_idx):
+        need = ctx.needs_input_grad[0]
+        buf = _lsg_forward(word_ins_out, select_idx, need)
+        selected = buf.transpose(1, 2)                                         # [B, L, S] view
+        ctx.mark_dirty(word_ins_out)
+        ctx.set_materialize_grads(False)
+        if need:
+            ctx.save_for_backward(word_ins_out, select_idx)
+            ctx.has_backward = False
+        return word_ins_out, selected
+
+    @staticmethod
+    def backward(ctx, grad_word_ins_out, grad_output):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        assert grad_word_ins_out is None, "Cannot reuse word_ins_out after logsoftmax_gather"
+        if grad_output is None:
+            return None, None
+        assert not ctx.has_backward, "Cannot backward twice in logsoftmax_gather"
+        ctx.has_backward = True
+        grad_input, select_idx = ctx.saved_tensors        # holds softmax, becomes the gradient in place
+        return _lsg_backward(grad_input, select_idx, grad_output), None
+
+
+dag_logsoftmax_gather_inplace = DagLogsoftmaxGatherFunc.apply
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# torch variants (device-agnostic).  Behavioural twins of dag_loss.py:303-425: dense links[b,i,j] = i -> j.
+# ----------------------------------------------------------------------------------------------------------------
+
+def logsumexp_keepdim(x: Tensor, dim: int) -> Tensor:
+    """logsumexp that returns -inf (not nan) where every entry along `dim` is -inf (dag_loss.py:303-311)."""
+    top = x.max(dim=dim, keepdim=True)[0]
+    dead = top == float("-inf")
+    shift = top.detach().masked_fill(dead, 0.0)
+    total = (x - shift).exp().sum(dim=dim, keepdim=True)
+    return total.masked_fill(dead, 1.0).log() + shift.masked_fill(dead, float("-inf"))
+
+
+def _dp_dense(match_all: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor, use_max: bool) -> Tensor:
+    if links.dim() != 3 or links.shape[1] != links.shape[2]:
+        raise AssertionError("links should be batch_size * prelen * prelen")
+    B, T, L = match_all.shape
+    emit = match_all.transpose(1, 2)                       # [B, L, T]
+    col = torch.full((B, L, 1), float("-inf"), dtype=match_all.dtype, device=match_all.device)
+    col[:, 0, 0] = emit[:, 0, 0]
+    cols = [col]
+    for t in range(1, T):
+        scores = cols[-1] + links                          # [B, L(from), L(to)]
+        if use_max:
+            nxt = scores.max(dim=1)[0].unsqueeze(-1)
+        else:
+            nxt = logsumexp_keepdim(scores, 1).transpose(1, 2)
+        cols.append(nxt + emit[:, :, t:t + 1])
+    table = torch.cat(cols, -1)                            # [B, L, T]
+    return table[torch.arange(B, device=table.device), output_length - 1, target_length - 1]
+
+
+def torch_dag_loss(match_all: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor) -> Tensor:
+    """Marginal log-likelihood over all paths; dense links (dag_loss.py:325-366)."""
+    return _dp_dense(match_all, links, output_length, target_length, use_max=False)
+
+
+def _torch_max_loss(match_all, links, output_length, target_length):
+    return _dp_dense(match_all, links, output_length, target_length, use_max=True)
+
+
+def torch_dag_best_alignment(match_all: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor) -> Tensor:
+    """Viterbi path through autograd of the max-DP (dag_loss.py:388-419).  Like the reference this turns on
+    requires_grad on the caller's match_all."""
+    with torch.enable_grad():
+        match_all.requires_grad_()
+        best = _torch_max_loss(match_all, links, output_length, target_length)
+        (hits,) = torch.autograd.grad(best.sum(), [match_all])          # 1 on the chosen (t, j) cells
+    val, path = hits.max(dim=1)
+    return path.masked_fill(val < 0.5, -1)
+
+
+def torch_dag_logsoftmax_gather_inplace(word_ins_out: Tensor, select_idx: Tensor) -> Tuple[Tensor, Tensor]:
+    """log_softmax + gather without the in-place side effect (dag_loss.py:421-425)."""
+    logp = torch.log_softmax(word_ins_out, -1, dtype=torch.float32)
+    return word_ins_out, logp.gather(dim=-1, index=select_idx)

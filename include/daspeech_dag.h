@@ -1,0 +1,97 @@
+/* daspeech_dag.h — C ABI of the MI355X-native DASpeech hot path (libdaspeech_hip.so).
+ *
+ * Drop-in boundary.  These entry points replace, one for one, the four functions the reference binds
+ * through pybind11 in DASpeech/custom_ops/dag_loss.cpp:19-29 (module `dag_loss_fn`):
+ *     dag_loss / dag_loss_backward / dag_best_alignment / logsoftmax_gather
+ * plus the decode / TTS-glue steps the reference runs as Python loops (cited per function).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless the name says host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued on it,
+ *     nothing synchronises the host (the reference used legacy stream 0 + private streams, dag_loss.cu:334,355);
+ *   - inputs are borrowed and must be contiguous in the stated layout; outputs are caller-allocated
+ *     (the reference's callee allocated with at::zeros, dag_loss.cu:339-340 — here the kernels fill every
+ *     element themselves, so outputs need no pre-initialisation);
+ *   - return value: 0 = success, <0 = DSP_E* argument error (nothing launched), >0 = hipError_t of a failed
+ *     launch.  dsp_last_error() gives the message (thread-local).
+ *   - dtype codes for logits: 0 = fp32, 1 = fp16, 2 = bf16.
+ */
+#ifndef DASPEECH_DAG_H
+#define DASPEECH_DAG_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSP_ABI_VERSION 1
+
+#define DSP_OK 0
+#define DSP_EINVAL (-1)   /* bad size / null pointer / unsupported dtype */
+#define DSP_ENOSPC (-2)   /* workspace too small */
+
+#define DSP_F32 0
+#define DSP_F16 1
+#define DSP_BF16 2
+
+typedef void* dsp_stream_t;
+
+int dsp_abi_version(void);
+const char* dsp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  logsoftmax + gather            replaces `logsoftmax_gather` (dag_loss.cpp:28; logsoftmax_gather.cu:313-377)
+ *   logits  [B,L,V] contiguous, dtype per `dtype`; if write_softmax != 0 it is OVERWRITTEN with softmax(logits)
+ *           in its own dtype (the reference's in-place contract, logsoftmax_gather.cu:296-307).
+ *   idx     int64, addressed idx[b*idx_sb + j*idx_sj + s*idx_ss] (element strides) — the caller's
+ *           targets.unsqueeze(1).expand(-1,L,-1) (nat_dag_loss.py:127) is passed as (T, 0, 1) without a copy.
+ *   match   fp32, written at match[b*out_sb + j*out_sj + s*out_ss]; (S*L, 1, L) produces the [B,S,L]
+ *           ("match_all") layout directly, (L*S, S, 1) the reference's [B,L,S].
+ *   Indices outside [0,V) are an error the reference does not check either; here they are clamped. */
+int dsp_logsoftmax_gather(void* logits, int dtype,
+                          const int64_t* idx, int64_t idx_sb, int64_t idx_sj, int64_t idx_ss,
+                          float* match, int64_t out_sb, int64_t out_sj, int64_t out_ss,
+                          int B, int L, int V, int S, int write_softmax, dsp_stream_t stream);
+
+/* K1 backward                         replaces the Python in DASpeech/custom_ops/dag_loss.py:293-295
+ *   softmax_inout [B,L,V] holds softmax (left by K1) and is overwritten with d loss / d logits:
+ *       gx = softmax * (-(sum_s g[b,j,s]));  gx[b,j,idx[b,j,s]] += g[b,j,s]   (duplicates accumulate)
+ *   g fp32 addressed with element strides like `match` above. */
+int dsp_logsoftmax_gather_bwd(void* softmax_inout, int dtype,
+                              const int64_t* idx, int64_t idx_sb, int64_t idx_sj, int64_t idx_ss,
+                              const float* g, int64_t g_sb, int64_t g_sj, int64_t g_ss,
+                              int B, int L, int V, int S, dsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2/K3  forward / backward DP       replaces `dag_loss` (dag_loss.cpp:25; dag_loss.cu:313-375)
+ *   match [B,T,L] fp32, links [B,L,TR] fp32 (links[b,i,d] = log P(i -> i+d+1)), out_len/tgt_len int64 [B].
+ *   alpha [B,T,L] fp32 out; beta [B,T,L] fp32 out or NULL (= the reference's require_gradient=false).
+ *   loss  [B] fp32 out or NULL: beta[b,0,0] when beta != NULL else alpha[b,T_b-1,L_b-1] (dag_loss.py:107-110).
+ *   Cells the recurrence never reaches are -inf.  Unreachable ends give loss = -inf (no device assert).
+ *   workspace: dsp_dag_workspace_bytes(B,T,L,TR) bytes of device scratch (may be 0 -> pass NULL). */
+size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR);
+int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                     float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
+                     void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
+/* K4/K5  gradients                    replaces `dag_loss_backward` (dag_loss.cpp:26; dag_loss.cu:518-571)
+ *   grad_out [B]; grad_match [B,T,L]; grad_links [B,L,TR]; formulas SURVEY.md §9.1 K4/K5. Either output may be NULL. */
+int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* beta, const float* match,
+                     const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                     float* grad_match, float* grad_links, int B, int T, int L, int TR,
+                     void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
+/* K6/K7  Viterbi alignment            replaces `dag_best_alignment` (dag_loss.cpp:27; dag_best_alignment.cu:209-253)
+ *   alpha_max [B,T,L] fp32 out, trace [B,T,L] int32 out (scratch the caller owns), path [B,L] int64 out
+ *   (the reference returns int32 and casts in Python, dag_loss.py:228).  path[b,j] = t or -1.
+ *   Tie rule: smallest predecessor index among equal maxima (torch.max rule, dag_loss.py:320). */
+int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                           float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                           dsp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASPEECH_DAG_H */

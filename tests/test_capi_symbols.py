@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every symbol that
+include/daspeech_dag.h declares; the Python operator surface has the reference's eight names.  No compute calls."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    out = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not fn.endswith(".h"):
+            continue
+        text = open(os.path.join(ROOT, "include", fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out += re.findall(r"\b(dsp_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(out))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from daspeech_amd import build
+    return build.build()
+
+
+def test_header_symbols_are_exported(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    names = declared_symbols()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by {lib_path}"
+
+
+def test_binding_covers_header(lib_path):
+    from daspeech_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.dsp_abi_version() == _lib.ABI_VERSION
+    assert isinstance(lib.dsp_last_error(), bytes)
+    assert lib.dsp_dag_workspace_bytes(1, 2, 3, 4) >= 0
+
+
+def test_operator_surface_matches_reference_names():
+    # DASpeech/custom_ops/__init__.py:1
+    from daspeech_amd import custom_ops
+    names = ["dag_loss", "dag_loss_with_alpha_beta", "dag_best_alignment", "dag_logsoftmax_gather_inplace",
+             "torch_dag_loss", "torch_dag_best_alignment", "torch_dag_logsoftmax_gather_inplace", "logsumexp_keepdim"]
+    for n in names:
+        assert callable(getattr(custom_ops, n))
+    import sys
+    mod = sys.modules["daspeech_amd.custom_ops.dag_loss"]      # the package attribute is the function, as in the reference
+    for cls in ("DagLossFunc", "DagLossWithAlphaBetaFunc", "DagBestAlignmentFunc", "DagLogsoftmaxGatherFunc"):
+        assert inspect.isclass(getattr(mod, cls))
+    assert mod.DagLossFunc.config == 1 and mod.DagLossFunc.config1 == 2 and mod.DagLossFunc.config2 == 2
+
+
+def test_hip_ops_refuse_cpu_tensors():
+    import torch
+    from daspeech_amd import custom_ops
+    m = torch.zeros(1, 2, 3); k = torch.zeros(1, 3, 2)
+    ol = torch.tensor([3]); tl = torch.tensor([2])
+    with pytest.raises(RuntimeError):
+        custom_ops.dag_loss(m, k, ol, tl)
+    with pytest.raises(RuntimeError):
+        custom_ops.dag_best_alignment(m, k, ol, tl)
+    with pytest.raises(RuntimeError):
+        custom_ops.dag_logsoftmax_gather_inplace(torch.zeros(1, 3, 5), torch.zeros(1, 3, 2, dtype=torch.long))
