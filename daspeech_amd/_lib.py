@@ -30,6 +30,8 @@ SIGNATURES = {
     "dsp_dag_loss_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                   _c_p, _c_sz, _c_p]),
     "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "dsp_dag_last_launch_status": (_c_int, [_c_p, ctypes.POINTER(ctypes.c_uint)]),
 }
 
 _lib = None
@@ -44,6 +46,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one this process uses (loading /opt/rocm's libamdhip64 before
+    # torch leaves two runtimes in the process and launches then fail with "no ROCm-capable device")
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise DaspeechHipError(
             f"{SO_PATH} is missing: build it with `python -m daspeech_amd.build` (hipcc, gfx950). "
@@ -73,3 +78,14 @@ def ptr(t):
 def current_stream_handle():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_option(name: str, value: int):
+    check(load().dsp_dag_set_option(name.encode(), int(value)), "dsp_dag_set_option")
+
+
+def last_launch_status() -> int:
+    """Status word of the last fast-path DP launch on the current stream (synchronises it)."""
+    w = ctypes.c_uint(0)
+    check(load().dsp_dag_last_launch_status(current_stream_handle(), ctypes.byref(w)), "dsp_dag_last_launch_status")
+    return int(w.value)

@@ -1,5 +1,6 @@
 // capi_dag.hip — extern "C" entry points of the DP ops (argument checks + kernel selection).
 #include "common.h"
+#include <string.h>
 
 namespace dsp {
 int launch_dag_fwd_generic(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
@@ -7,6 +8,13 @@ int launch_pick_loss(const float*, const float*, const int64_t*, const int64_t*,
 int launch_best_alignment_generic(const float*, const float*, const int64_t*, const int64_t*, float*, int32_t*, int64_t*, int, int, int, int, hipStream_t);
 int launch_dag_bwd_generic(const float*, const float*, const float*, const float*, const float*, const int64_t*, const int64_t*,
                            float*, float*, int, int, int, int, hipStream_t);
+
+bool banded_supported(int L, int TR);
+int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
+int banded_last_error_word(hipStream_t st, unsigned int* word);
+int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
+
+static int g_force_generic = 0;       // test hook: dsp_dag_set_option("force_generic", 1)
 
 static int check_dims(const char* fn, int B, int T, int L, int TR) {
     if (B < 0 || T < 1 || L < 1 || TR < 1) { set_error("%s: bad sizes B=%d T=%d L=%d TR=%d", fn, B, T, L, TR); return DSP_EINVAL; }
@@ -28,7 +36,10 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
+    if (!g_force_generic && TR <= 32 && banded_supported(L, TR))
+        rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
+    else
+        rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     if (rc) return rc;
     if (loss) rc = launch_pick_loss(alpha, beta, out_len, tgt_len, loss, B, T, L, st);
     return rc;
@@ -55,5 +66,24 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
     if (rc) return rc;
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
-    return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, as_stream(stream));
+    hipStream_t st = as_stream(stream);
+    if (!g_force_generic && TR <= 32 && banded_supported(L, TR) && (size_t)L * 4 <= 160 * 1024) {
+        rc = launch_dag_banded(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
+        if (rc) return rc;
+        return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+    }
+    return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, st);
+}
+
+extern "C" int dsp_dag_set_option(const char* name, int value)
+{
+    if (name && !strcmp(name, "force_generic")) { g_force_generic = value; return DSP_OK; }
+    set_error("dsp_dag_set_option: unknown option");
+    return DSP_EINVAL;
+}
+
+extern "C" int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word)
+{
+    if (!host_word) { set_error("dsp_dag_last_launch_status: null pointer"); return DSP_EINVAL; }
+    return banded_last_error_word(as_stream(stream), host_word);
 }

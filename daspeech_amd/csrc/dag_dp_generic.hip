@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void dag_backtrace_kernel(
     for (int j = threadIdx.x; j < L; j += blockDim.x) path[(size_t)b * L + j] = lp[j];
 }
 
+int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st)
+{
+    const size_t lds2 = (size_t)L * sizeof(int32_t);
+    if (lds2 > 160 * 1024) { set_error("dag_best_alignment: graph size L=%d too large for the back-trace row image", L); return DSP_EINVAL; }
+    if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_backtrace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(dag_backtrace_kernel, dim3(B), dim3(256), lds2, st, trace, out_len, tgt_len, path, B, T, L);
+    return check_launch("dag_best_alignment(back-trace)");
+}
+
 int launch_dag_fwd_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                            float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
 {
@@ -217,10 +226,7 @@ int launch_best_alignment_generic(const float* match, const float* links, const 
                        alpha, trace, B, T, L, TR);
     int rc = check_launch("dag_best_alignment(max-alpha)");
     if (rc) return rc;
-    const size_t lds2 = (size_t)L * sizeof(int32_t);
-    if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_backtrace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(dag_backtrace_kernel, dim3(B), dim3(256), lds2, st, trace, out_len, tgt_len, path, B, T, L);
-    return check_launch("dag_best_alignment(back-trace)");
+    return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
 }
 
 }  // namespace dsp

@@ -269,7 +269,7 @@ class DagLogsoftmaxGatherFunc(Function):
         assert not ctx.has_backward, "Cannot backward twice in logsoftmax_gather"
         ctx.has_backward = True
         grad_input, select_idx = ctx.saved_tensors        # holds softmax, becomes the gradient in place
-        return _lsg_backward(grad_input, select_idx, grad_output), None
+        return _lsg_backward(grad_input, select_idx, grad_output).detach(), None
 
 
 dag_logsoftmax_gather_inplace = DagLogsoftmaxGatherFunc.apply

@@ -91,6 +91,15 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
                            float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                            dsp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics (no reference counterpart).
+ *   dsp_dag_set_option("force_generic", 1) routes the DP ops to the generic row-sequential kernels (cross-check of the
+ *   banded / dense fast paths in tests).  dsp_dag_last_launch_status copies the device-side status word of the last
+ *   fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
+ *   the stream and is meant for tests. */
+int dsp_dag_set_option(const char* name, int value);
+int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);
+
 #ifdef __cplusplus
 }
 #endif

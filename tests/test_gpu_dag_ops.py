@@ -102,7 +102,10 @@ SHAPES = [
     (2, 9, 70, 69),        # TR = L-1 (README --max-transition-length 99999)
     (5, 33, 257, 64),      # odd sizes, TR > wave
     (2, 2, 2, 1),          # minimum legal sizes
-    (1, 40, 1030, 16),     # L > one pass of 1024 threads
+    (1, 40, 1030, 16),     # L > one pass of 1024 threads, 3 column strips
+    (2, 30, 1500, 32),     # banded fast path, 3 strips, full window
+    (3, 25, 1031, 7),      # odd L (scalar store path), odd TR
+    (2, 70, 2048, 32),     # strip boundary exactly at L
 ]
 
 
@@ -253,3 +256,48 @@ def test_full_size_properties(TR):
     # compare with the max-DP score recomputed by torch on a banded formulation for a few samples
     ref = orc.dag_best_alignment(mc[:2], kc[:2], ol.cpu().numpy()[:2], tl.cpu().numpy()[:2], np.float32)
     np.testing.assert_array_equal(pc[:2], ref)
+
+
+# ---------------------------------------------------------------------------------------------- fast path vs generic
+
+@pytest.mark.parametrize("shape", [(2, 30, 1500, 32), (3, 25, 1031, 7), (2, 70, 2048, 32), (4, 16, 513, 32)])
+def test_banded_matches_generic_kernels(shape):
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(21 + L, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_()
+    try:
+        _lib.set_option("force_generic", 0)
+        loss_f, (a_f, b_f) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+        assert _lib.last_launch_status() == 0
+        p_f = ops().dag_best_alignment(m.detach(), k, o, t)
+        assert _lib.last_launch_status() == 0
+        _lib.set_option("force_generic", 1)
+        loss_g, (a_g, b_g) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+        p_g = ops().dag_best_alignment(m.detach(), k, o, t)
+    finally:
+        _lib.set_option("force_generic", 0)
+    assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)) and torch.equal(torch.isneginf(b_f), torch.isneginf(b_g))
+    fa = torch.isfinite(a_g); fb = torch.isfinite(b_g)
+    torch.testing.assert_close(a_f[fa], a_g[fa], rtol=2e-6, atol=2e-5 * T)
+    torch.testing.assert_close(b_f[fb], b_g[fb], rtol=2e-6, atol=2e-5 * T)
+    assert torch.equal(p_f, p_g)                       # Viterbi: bit-exact between the two kernel families
+
+
+def test_banded_repeated_launches_reuse_workspace():
+    """Tag epochs: many launches back to back on one stream must never see a stale granule."""
+    from daspeech_amd import _lib
+    B, T, L, TR = 2, 12, 1100, 16
+    match, links, ol, tl = make_dag_inputs(99, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    ref = None
+    for it in range(20):
+        with torch.no_grad():
+            loss = ops().dag_loss(m + 0.001 * it, k, o, t)
+        if it == 0:
+            ref = loss.clone()
+        assert _lib.last_launch_status() == 0
+    with torch.no_grad():
+        again = ops().dag_loss(m, k, o, t)
+    assert torch.equal(again, ref)
