@@ -187,10 +187,11 @@ def test_oracle_logsoftmax_gather(dtype, V):
     out_x, match = ops().dag_logsoftmax_gather_inplace(work, tg.unsqueeze(1).expand(-1, L, -1))
     np.testing.assert_allclose(match.detach().cpu().numpy(), ref, rtol=2e-6, atol=2e-6)
     eps = {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
-    np.testing.assert_allclose(out_x.detach().float().cpu().numpy(), sm, rtol=eps, atol=eps * 0.1)
+    sm_dev = out_x.detach().float().cpu().numpy()          # snapshot: backward overwrites this buffer with the gradient
+    np.testing.assert_allclose(sm_dev, sm, rtol=eps, atol=eps * 0.1)
     w = rng.standard_normal((B, L, T)).astype(np.float32)
     (gx,) = torch.autograd.grad((match * torch.from_numpy(w).to(dev())).sum(), [x])
-    gref = orc.logsoftmax_gather_bwd(out_x.detach().float().cpu().numpy(), idx, w, np.float64)
+    gref = orc.logsoftmax_gather_bwd(sm_dev, idx, w, np.float64)
     np.testing.assert_allclose(gx.float().cpu().numpy(), gref, rtol=4 * eps, atol=4 * eps)
     # materialised (non-expanded) index tensor gives the same result
     work2 = logits.to(dev()).clone()
