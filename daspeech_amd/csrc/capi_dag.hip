@@ -14,7 +14,11 @@ int launch_dag_banded(int mode, const float*, const float*, const int64_t*, cons
 int banded_last_error_word(hipStream_t st, unsigned int* word);
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
 
-static int g_force_generic = 0;       // test hook: dsp_dag_set_option("force_generic", 1)
+bool strip4_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
+int launch_dag_strip4(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
+
+// test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space, 3 = strip4
+static int g_path = 0;
 
 static int check_dims(const char* fn, int B, int T, int L, int TR) {
     if (B < 0 || T < 1 || L < 1 || TR < 1) { set_error("%s: bad sizes B=%d T=%d L=%d TR=%d", fn, B, T, L, TR); return DSP_EINVAL; }
@@ -36,7 +40,10 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    if (!g_force_generic && TR <= 32 && banded_supported(L, TR))
+    const bool s4 = strip4_supported(match, alpha, beta, nullptr, L, TR);
+    if ((g_path == 0 || g_path == 3) && s4)
+        rc = launch_dag_strip4(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
+    else if ((g_path == 0 || g_path == 2 || g_path == 3) && TR <= 32 && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else
         rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
@@ -67,17 +74,26 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    if (!g_force_generic && TR <= 32 && banded_supported(L, TR) && (size_t)L * 4 <= 160 * 1024) {
-        rc = launch_dag_banded(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
-        if (rc) return rc;
-        return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+    if ((size_t)L * 4 <= 160 * 1024) {
+        const bool s4 = strip4_supported(match, alpha_max, nullptr, trace, L, TR);
+        if ((g_path == 0 || g_path == 3) && s4) {
+            rc = launch_dag_strip4(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
+            if (rc) return rc;
+            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+        }
+        if ((g_path == 0 || g_path == 2 || g_path == 3) && TR <= 32 && banded_supported(L, TR)) {
+            rc = launch_dag_banded(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
+            if (rc) return rc;
+            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+        }
     }
     return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, st);
 }
 
 extern "C" int dsp_dag_set_option(const char* name, int value)
 {
-    if (name && !strcmp(name, "force_generic")) { g_force_generic = value; return DSP_OK; }
+    if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
+    if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");
     return DSP_EINVAL;
 }

@@ -279,15 +279,11 @@ static int get_ws(hipStream_t st, size_t need, BandedWS** out)
 
 bool banded_supported(int L, int TR) { (void)L; return TR <= 64; }
 
-// mode 0: alpha and/or beta (logsum); mode 1: max-alpha + trace
-int launch_dag_banded(int mode, const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                      float* alpha, float* beta, int32_t* trace, int B, int T, int L, int TR, hipStream_t st)
+// Shared by dag_dp_banded.hip and dag_dp_strip4.hip: per-(device, stream) workspace with monotonically increasing tag
+// epochs, so the halo granules never need re-zeroing between launches.  Caller holds no lock; this function locks.
+int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base)
 {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    const int TRP = TR <= 32 ? 32 : 64;
-    const int NS = (L + ST_W - 1) / ST_W;
-    const int ndir = (mode == 0 && alpha && beta) ? 2 : 1;
-    const size_t halo_bytes = (size_t)ndir * B * NS * T * TRP * sizeof(u64);
     const size_t need = 256 + halo_bytes;
     BandedWS* ws = nullptr;
     int rc = get_ws(st, need, &ws);
@@ -299,14 +295,27 @@ int launch_dag_banded(int mode, const float* match, const float* links, const in
     }
     hipError_t e = hipMemsetAsync(ws->base, 0, 8, st);               // ticket + error word
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    *counters = reinterpret_cast<u32*>(ws->base);
+    *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws->base) + 256);
+    *tag_base = ws->tag_base;
+    ws->tag_base += (u32)T + 1u;
+    return DSP_OK;
+}
+
+// mode 0: alpha and/or beta (logsum); mode 1: max-alpha + trace
+int launch_dag_banded(int mode, const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                      float* alpha, float* beta, int32_t* trace, int B, int T, int L, int TR, hipStream_t st)
+{
+    const int TRP = TR <= 32 ? 32 : 64;
+    const int NS = (L + ST_W - 1) / ST_W;
+    const int ndir = (mode == 0 && alpha && beta) ? 2 : 1;
+    const size_t halo_bytes = (size_t)ndir * B * NS * T * TRP * sizeof(u64);
     StripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = trace;
-    p.counters = reinterpret_cast<u32*>(ws->base);
-    p.halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws->base) + 256);
-    p.tag_base = ws->tag_base;
+    int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
+    if (rc) return rc;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
-    ws->tag_base += (u32)T + 1u;
     const dim3 grid((unsigned)(ndir * B * NS)), block(ST_THREADS);
     if (mode == 0) {
         if (TRP == 32) hipLaunchKernelGGL((dag_strip_kernel<32, 0>), grid, block, 0, st, p);

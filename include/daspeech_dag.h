@@ -93,8 +93,8 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
 
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart).
- *   dsp_dag_set_option("force_generic", 1) routes the DP ops to the generic row-sequential kernels (cross-check of the
- *   banded / dense fast paths in tests).  dsp_dag_last_launch_status copies the device-side status word of the last
+ *   dsp_dag_set_option("dp_path", n) pins the DP kernel family: 0 = auto, 1 = generic row-sequential, 2 = banded
+ *   2-column log-space strips, 3 = strip4 (exp-space, wave-specialised); used by tests to cross-check the families.  dsp_dag_last_launch_status copies the device-side status word of the last
  *   fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_set_option(const char* name, int value);

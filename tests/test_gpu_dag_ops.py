@@ -261,29 +261,63 @@ def test_full_size_properties(TR):
 
 # ---------------------------------------------------------------------------------------------- fast path vs generic
 
-@pytest.mark.parametrize("shape", [(2, 30, 1500, 32), (3, 25, 1031, 7), (2, 70, 2048, 32), (4, 16, 513, 32)])
-def test_banded_matches_generic_kernels(shape):
+@pytest.mark.parametrize("shape", [(2, 30, 1500, 32), (3, 25, 1031, 7), (2, 70, 2048, 32), (4, 16, 513, 32),
+                                   (3, 40, 1028, 32), (2, 33, 2304, 20), (40, 9, 1024, 32), (2, 12, 64, 5)])
+def test_fast_paths_match_generic_kernels(shape):
+    """The three DP kernel families (generic row-sequential, banded 2-column log-space strips, strip4 exp-space) agree:
+    alpha/beta within fp32 DP tolerance, Viterbi traces bit-exact."""
     from daspeech_amd import _lib
     B, T, L, TR = shape
     match, links, ol, tl = make_dag_inputs(21 + L, B, T, L, TR)
     m, k, o, t = to_dev(match, links, ol, tl)
     m.requires_grad_()
+    res = {}
     try:
-        _lib.set_option("force_generic", 0)
-        loss_f, (a_f, b_f) = ops().dag_loss_with_alpha_beta(m, k, o, t)
-        assert _lib.last_launch_status() == 0
-        p_f = ops().dag_best_alignment(m.detach(), k, o, t)
-        assert _lib.last_launch_status() == 0
-        _lib.set_option("force_generic", 1)
-        loss_g, (a_g, b_g) = ops().dag_loss_with_alpha_beta(m, k, o, t)
-        p_g = ops().dag_best_alignment(m.detach(), k, o, t)
+        for path in (1, 2, 3):
+            _lib.set_option("dp_path", path)
+            loss, (a, b) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+            assert _lib.last_launch_status() == 0
+            p = ops().dag_best_alignment(m.detach(), k, o, t)
+            assert _lib.last_launch_status() == 0
+            res[path] = (loss.detach(), a, b, p)
     finally:
-        _lib.set_option("force_generic", 0)
-    assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)) and torch.equal(torch.isneginf(b_f), torch.isneginf(b_g))
+        _lib.set_option("dp_path", 0)
+    _, a_g, b_g, p_g = res[1]
     fa = torch.isfinite(a_g); fb = torch.isfinite(b_g)
-    torch.testing.assert_close(a_f[fa], a_g[fa], rtol=2e-6, atol=2e-5 * T)
-    torch.testing.assert_close(b_f[fb], b_g[fb], rtol=2e-6, atol=2e-5 * T)
-    assert torch.equal(p_f, p_g)                       # Viterbi: bit-exact between the two kernel families
+    for path in (2, 3):
+        _, a_f, b_f, p_f = res[path]
+        assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)), path
+        assert torch.equal(torch.isneginf(b_f), torch.isneginf(b_g)), path
+        torch.testing.assert_close(a_f[fa], a_g[fa], rtol=3e-6, atol=3e-5 * T)
+        torch.testing.assert_close(b_f[fb], b_g[fb], rtol=3e-6, atol=3e-5 * T)
+        assert torch.equal(p_f, p_g), path            # Viterbi: bit-exact between kernel families
+
+
+def test_strip4_exactness_guard():
+    """Inputs that force the exp-space kernel's log-space fallback: adjacent vertices whose scores differ by hundreds of
+    nats (far beyond the 2^-90 window), plus -inf emissions (force-emit mask) — results must still match the fp64 oracle."""
+    from daspeech_amd import _lib
+    B, T, L, TR = 2, 24, 1024, 32
+    match, links, ol, tl = make_dag_inputs(77, B, T, L, TR, ragged=False)
+    rng = np.random.default_rng(5)
+    match = match + (rng.integers(0, 2, match.shape) * -300.0).astype(np.float32)     # cliffs of 300 nats between neighbours
+    match[0, 5, :] = -np.inf; match[0, 5, 40] = 0.0                                   # force-emit row
+    links = np.where(np.isfinite(links), links + (rng.integers(0, 2, links.shape) * -120.0), links).astype(np.float32)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_()
+    try:
+        _lib.set_option("dp_path", 3)
+        loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+        assert _lib.last_launch_status() == 0
+    finally:
+        _lib.set_option("dp_path", 0)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    a = alpha.cpu().numpy(); b = beta.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
+    fa = np.isfinite(a64); fb = np.isfinite(b64)
+    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
+    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
 
 
 def test_banded_repeated_launches_reuse_workspace():
