@@ -84,6 +84,23 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
     const int own_li0 = BETA ? 0 : 32, own_g0 = BETA ? 0 : 8;
     const int pub_li0 = BETA ? 0 : W;          // boundary columns handed to the consumer: alpha last 32, beta first 32
 
+    // ---- prologue: the strip's transition rows -> LDS tile (coalesced, once), then -> registers ----
+    // tile[r][d] = links[rlo + r][d] (pitch 33), -inf outside the graph / beyond TR.  The tile overlays the main-loop
+    // buffers, which are not live yet.
+    {
+        float* tile = reinterpret_cast<float*>(smem_raw);
+        constexpr int NTHR = NT + 192, RPP = NTHR / 32;       // rows per pass
+        const int rlo = BETA ? j0 : (j0 - 32);
+        const int dd = tid & 31, r0 = tid >> 5;
+        for (int r = r0; r < W + 32; r += RPP) {
+            const int i = rlo + r;
+            float v = NEG_INF;
+            if (dd < TR && i >= 0 && i < L) v = K[(size_t)i * TR + dd];
+            tile[r * 33 + dd] = v;
+        }
+    }
+    __syncthreads();
+
     if (wave < NCW) {
         // =========================================================== compute waves
         const int l = tid;                       // lane's group
@@ -91,15 +108,16 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
         const bool col_ok = j < L;
         float E[4][32];
         float lmax[4];
+        const float* tile = reinterpret_cast<const float*>(smem_raw);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float raw[32];
             float mx = NEG_INF;
 #pragma unroll
             for (int d = 1; d <= 32; ++d) {
-                float v = NEG_INF;
-                if (!BETA) { const int i = j + c - d; if (d <= TR && i >= 0 && col_ok) v = K[(size_t)i * TR + (d - 1)]; }
-                else { if (d <= TR && col_ok && j + c + d < Lb) v = K[(size_t)(j + c) * TR + (d - 1)]; }
+                float v;
+                if (!BETA) v = tile[(4 * l + c - d + 32) * 33 + (d - 1)];
+                else { v = tile[(4 * l + c) * 33 + (d - 1)]; if (j + c + d >= Lb) v = NEG_INF; }
                 raw[d - 1] = (MODE == 0) ? v * S4_LOG2E : v;
                 mx = fmaxf(mx, raw[d - 1]);
             }
@@ -114,6 +132,7 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                 for (int d = 0; d < 32; ++d) E[c][d] = raw[d];
             }
         }
+        __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         s4_barrier();                            // prologue barrier: match row 0 is in the ring
 
         for (int it = 0; it < nrows; ++it) {
@@ -136,19 +155,23 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                 int ref = cg[0];
 #pragma unroll
                 for (int k = 1; k < 9; ++k) ref = max(ref, cg[k]);
-                float w[36];
+                // window walked group by group (4 live values instead of 36): element q of the window feeds the cells
+                // (c, d) with qidx(c, d) == q
+                float S[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const float4 v = *reinterpret_cast<const float4*>(Pbuf + prv * RL + 4 * l + 4 * k);
                     const int e = max(cg[k] - ref, -250);
-                    w[4 * k + 0] = ldexpf(v.x, e); w[4 * k + 1] = ldexpf(v.y, e);
-                    w[4 * k + 2] = ldexpf(v.z, e); w[4 * k + 3] = ldexpf(v.w, e);
-                }
-                float S[4] = {0.f, 0.f, 0.f, 0.f};
+                    const float wv[4] = {ldexpf(v.x, e), ldexpf(v.y, e), ldexpf(v.z, e), ldexpf(v.w, e)};
 #pragma unroll
-                for (int d = 1; d <= 32; ++d) {
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = 4 * k + i;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) S[c] = fmaf(w[qidx<BETA>(c, d)], E[c][d - 1], S[c]);
+                        for (int c = 0; c < 4; ++c) {
+                            const int d = BETA ? (q - c) : (32 + c - q);
+                            if (d >= 1 && d <= 32) S[c] = fmaf(wv[i], E[c][d - 1], S[c]);
+                        }
+                    }
                 }
                 const float reff = (float)ref;
                 bool need_fb = false;
@@ -161,49 +184,61 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                     }
                 }
                 if (__builtin_expect(need_fb, 0)) {
-                    // exact log-space recomputation of the flagged cells from the a2 row (rare)
-                    float aw[36];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const float4 v = *reinterpret_cast<const float4*>(Abuf + prv * RL + 4 * l + 4 * k);
-                        aw[4 * k] = v.x; aw[4 * k + 1] = v.y; aw[4 * k + 2] = v.z; aw[4 * k + 3] = v.w;
-                    }
-#pragma unroll
+                    // exact log-space recomputation of the flagged cells (rare): a2 row from LDS, raw links from HBM
+                    // (E may have flushed links that are far below the column's largest one)
+#pragma unroll 1
                     for (int c = 0; c < 4; ++c) {
                         const bool act = (j + c >= t) && (j + c < Lb);
-                        if (act && ref != NEGSENT && S[c] < 0x1p-90f) {
-                            float mx = NEG_INF;
-#pragma unroll
-                            for (int d = 1; d <= 32; ++d)
-                                mx = fmaxf(mx, aw[qidx<BETA>(c, d)] + __builtin_amdgcn_logf(E[c][d - 1]));
-                            if (mx != NEG_INF) {
-                                float sum = 0.f;
-#pragma unroll
-                                for (int d = 1; d <= 32; ++d)
-                                    sum += __builtin_amdgcn_exp2f(aw[qidx<BETA>(c, d)] + __builtin_amdgcn_logf(E[c][d - 1]) - mx);
-                                a2[c] = __builtin_amdgcn_logf(sum) + mx + lmax[c] + m2[c] * S4_LOG2E;
-                            }
+                        if (!(act && ref != NEGSENT && S[c] < 0x1p-90f)) continue;
+                        float mx = NEG_INF;
+                        for (int d = 1; d <= 32; ++d) {
+                            const float av = Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))];
+                            float lk = NEG_INF;
+                            if (!BETA) { const int i = j + c - d; if (d <= TR && i >= 0) lk = K[(size_t)i * TR + (d - 1)] * S4_LOG2E; }
+                            else { if (d <= TR && j + c + d < Lb) lk = K[(size_t)(j + c) * TR + (d - 1)] * S4_LOG2E; }
+                            mx = fmaxf(mx, av + lk);
                         }
+                        float r = NEG_INF;
+                        if (mx != NEG_INF) {
+                            float sum = 0.f;
+                            for (int d = 1; d <= 32; ++d) {
+                                const float av = Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))];
+                                float lk = NEG_INF;
+                                if (!BETA) { const int i = j + c - d; if (d <= TR && i >= 0) lk = K[(size_t)i * TR + (d - 1)] * S4_LOG2E; }
+                                else { if (d <= TR && j + c + d < Lb) lk = K[(size_t)(j + c) * TR + (d - 1)] * S4_LOG2E; }
+                                sum += __builtin_amdgcn_exp2f(av + lk - mx);
+                            }
+                            const float mm = (c == 0) ? m2[0] : (c == 1) ? m2[1] : (c == 2) ? m2[2] : m2[3];
+                            r = __builtin_amdgcn_logf(sum) + mx + mm * S4_LOG2E;
+                        }
+                        if (c == 0) a2[0] = r; else if (c == 1) a2[1] = r; else if (c == 2) a2[2] = r; else a2[3] = r;
                     }
                 }
             } else {
                 // MODE 1: max-DP in the natural domain; ascending predecessor index, strict '>' (smallest index wins ties)
-                float aw[36];
+                float mxv[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+                int av[4] = {-1, -1, -1, -1};
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const float4 v = *reinterpret_cast<const float4*>(Abuf + prv * RL + 4 * l + 4 * k);
-                    aw[4 * k] = v.x; aw[4 * k + 1] = v.y; aw[4 * k + 2] = v.z; aw[4 * k + 3] = v.w;
+                    const float wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = 4 * k + i;               // ascending q == ascending predecessor index
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int d = 32 + c - q;
+                            if (d >= 1 && d <= 32) {
+                                const float x = wv[i] + E[c][d - 1];
+                                if (x > mxv[c]) { mxv[c] = x; av[c] = j + c - d; }
+                            }
+                        }
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float mx = NEG_INF; int a = -1;
-#pragma unroll
-                    for (int d = 32; d >= 1; --d) {
-                        const float x = aw[qidx<false>(c, d)] + E[c][d - 1];
-                        if (x > mx) { mx = x; a = j + c - d; }
-                    }
                     const bool act = (j + c >= t) && (j + c < Lb);
-                    if (act) { a2[c] = mx + m2[c]; arg[c] = a; }
+                    if (act) { a2[c] = mxv[c] + m2[c]; arg[c] = av[c]; }
                 }
             }
             // ---- write the row: LDS state for the next row, HBM output ----
@@ -246,6 +281,7 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                                                  (__attribute__((address_space(3))) void*)(slot + i * 256), 16, 0, 0);
             }
         };
+        __syncthreads();                         // link tile consumed
         for (int r = 0; r < S4_RING - 1 && r < nrows; ++r) issue_row(r);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s4_barrier();                            // prologue barrier
@@ -276,6 +312,7 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
             }
         };
         if (has_producer) load_chunk(0);
+        __syncthreads();                         // link tile consumed
         s4_barrier();                            // prologue barrier
         for (int itb = 0; itb < nrows; itb += S4_CH) {
 #pragma unroll
@@ -314,6 +351,7 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
     } else {
         // =========================================================== publish wave: boundary columns -> granules
         const bool pl = has_consumer && lane < S4_TRP;
+        __syncthreads();                         // link tile consumed
         s4_barrier();                            // prologue barrier
         for (int it = 0; it < nrows; ++it) {
             if (it > 0 && pl) {                  // row it-1 is complete (barrier it-1 passed); compute now writes the other buffer
@@ -338,7 +376,8 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4_kernel(StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int W = 4 * NT, RL = W + 32, GL = NT + 8;
-    u32* s_ticket = reinterpret_cast<u32*>(smem_raw + (size_t)(4 * RL + 2 * GL + S4_RING * W) * 4);
+    u32* s_ticket = reinterpret_cast<u32*>(smem_raw);          // 16-byte header; everything else starts at +16
+    (void)RL; (void)GL;
     const int tid = threadIdx.x;
     if (tid == 0) *s_ticket = atomicAdd(&p.counters[0], 1u);
     __syncthreads();
@@ -367,8 +406,8 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4_kernel(StripParams p)
         }
         return;
     }
-    if (MODE == 0 && is_beta) strip4_body<NT, MODE, true>(p, smem_raw, b, s, dirslot, so);
-    else strip4_body<NT, MODE, false>(p, smem_raw, b, s, dirslot, so);
+    if (MODE == 0 && is_beta) strip4_body<NT, MODE, true>(p, smem_raw + 16, b, s, dirslot, so);
+    else strip4_body<NT, MODE, false>(p, smem_raw + 16, b, s, dirslot, so);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -386,7 +425,9 @@ template <int NT, int MODE>
 static int launch_one(const StripParams& p, int nwg, hipStream_t st)
 {
     constexpr int W = 4 * NT, RL = W + 32, GL = NT + 8;
-    const size_t lds = (size_t)(4 * RL + 2 * GL + S4_RING * W) * 4 + 16;
+    const size_t lds_main = (size_t)(4 * RL + 2 * GL + S4_RING * W) * 4 + 16;
+    const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
+    const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     auto k = dag_strip4_kernel<NT, MODE>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(NT + 192), lds, st, p);
