@@ -32,6 +32,8 @@ SIGNATURES = {
     "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "dsp_dag_last_launch_status": (_c_int, [_c_p, ctypes.POINTER(ctypes.c_uint)]),
+    "dsp_dag_last_fallback_count": (ctypes.c_uint, []),
+    "dsp_dag_debug_words": (ctypes.POINTER(ctypes.c_uint), []),
 }
 
 _lib = None
@@ -89,3 +91,19 @@ def last_launch_status() -> int:
     w = ctypes.c_uint(0)
     check(load().dsp_dag_last_launch_status(current_stream_handle(), ctypes.byref(w)), "dsp_dag_last_launch_status")
     return int(w.value)
+
+
+def last_fallback_count() -> int:
+    """Exact-fallback cell count of the launch inspected by the latest last_launch_status() call."""
+    return int(load().dsp_dag_last_fallback_count())
+
+
+def debug_fallback_cells():
+    """(sample, row, column, S) of the first fallback cells of the launch inspected by last_launch_status()."""
+    import struct
+    w = load().dsp_dag_debug_words()
+    out = []
+    for i in range(min(14, int(w[1]))):
+        b, t, j, sb = w[7 + 4 * i], w[8 + 4 * i], w[9 + 4 * i], w[10 + 4 * i]
+        out.append((int(b), int(t), int(j), struct.unpack("f", struct.pack("I", sb))[0]))
+    return out

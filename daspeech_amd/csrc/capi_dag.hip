@@ -19,6 +19,8 @@ int launch_dag_strip4(int mode, const float*, const float*, const int64_t*, cons
 
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space, 3 = strip4
 static int g_path = 0;
+static unsigned int g_last_fallbacks = 0;
+static unsigned int g_dbg[64] = {0};
 
 static int check_dims(const char* fn, int B, int T, int L, int TR) {
     if (B < 0 || T < 1 || L < 1 || TR < 1) { set_error("%s: bad sizes B=%d T=%d L=%d TR=%d", fn, B, T, L, TR); return DSP_EINVAL; }
@@ -101,5 +103,12 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
 extern "C" int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word)
 {
     if (!host_word) { set_error("dsp_dag_last_launch_status: null pointer"); return DSP_EINVAL; }
-    return banded_last_error_word(as_stream(stream), host_word);
+    int rc = banded_last_error_word(as_stream(stream), g_dbg);
+    host_word[0] = g_dbg[0];
+    g_last_fallbacks = g_dbg[1];
+    return rc;
 }
+
+extern "C" const unsigned int* dsp_dag_debug_words(void) { return g_dbg; }
+
+extern "C" unsigned int dsp_dag_last_fallback_count(void) { return g_last_fallbacks; }

@@ -41,6 +41,7 @@ struct StripParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
+    int dbg;
 };
 
 __device__ __forceinline__ u64 gran_load(const u64* p) {
@@ -293,7 +294,7 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
         if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
         ws->tag_base = 0;
     }
-    hipError_t e = hipMemsetAsync(ws->base, 0, 8, st);               // ticket + error word
+    hipError_t e = hipMemsetAsync(ws->base, 0, 256, st);             // ticket, error word, fallback counter, debug slots
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     *counters = reinterpret_cast<u32*>(ws->base);
     *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws->base) + 256);
@@ -315,7 +316,7 @@ int launch_dag_banded(int mode, const float* match, const float* links, const in
     p.alpha = alpha; p.beta = beta; p.trace = trace;
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.dbg = 0;
     const dim3 grid((unsigned)(ndir * B * NS)), block(ST_THREADS);
     if (mode == 0) {
         if (TRP == 32) hipLaunchKernelGGL((dag_strip_kernel<32, 0>), grid, block, 0, st, p);
@@ -335,7 +336,7 @@ int banded_last_error_word(hipStream_t st, u32* word)
     const u64 key = ((u64)devid << 48) ^ (u64)(uintptr_t)st;
     auto it = g_ws.find(key);
     if (it == g_ws.end() || !it->second.base) { *word = 0; return DSP_OK; }
-    hipError_t e = hipMemcpyAsync(word, reinterpret_cast<char*>(it->second.base) + 4, 4, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(word, reinterpret_cast<char*>(it->second.base) + 4, 252, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("banded_last_error_word: %s", hipGetErrorString(e)); return (int)e; }
     return DSP_OK;

@@ -4,14 +4,18 @@
 // calculate_maxalpha_kernel (dag_best_alignment.cu:39-130).  Same strip / tagged-granule / ticket structure as
 // dag_dp_banded.hip (read its header first); what is new here:
 //
-//   * 4 COLUMNS PER LANE, EXP-SPACE RECURRENCE.  A lane owns 4 adjacent vertices and keeps E = 2^(link) of their
-//     4 x 32 incoming (alpha) / outgoing (beta) edges in registers.  The previous row is kept in LDS as
-//         P[k] = 2^(a2[k] - c[g])   with one integer scale c[g] per GROUP OF 4 COLUMNS (= per lane, no reduction),
-//     so a cell costs 32 FMAs + (36 v_ldexp + 9 integer ops)/4 instead of 32 x (add, max, sub, exp, add):
-//     2 transcendentals per cell instead of 32.  (a2 = alpha * log2 e.)
-//   * EXACTNESS GUARD.  P, E <= 1 by construction.  If a cell's scaled sum S falls below 2^-90 some term that matters
-//     to fp32 may have been flushed, so the cell is recomputed in log space from the a2 row that is also kept in LDS;
-//     otherwise every flushed term is < 2^-36 of S.  Rare (needs > 62 nats between a cell and its 36-column window).
+//   * 4 COLUMNS PER LANE, EXP-SPACE RECURRENCE.  A lane owns 4 adjacent vertices and keeps E = 2^(link - lmax) of their
+//     4 x 32 incoming (alpha) / outgoing (beta) edges in registers.  Per row it reads its 36-value window of the
+//     previous row a2 (= alpha * log2 e, kept in LDS), rescales it ONCE against a per-lane reference,
+//         w[q] = 2^(a2[q] - ref),   ref = min over the lane's 4 columns of (max a2 over that column's predecessors),
+//     and every cell is then 32 FMAs: 36 + 4 transcendentals per lane-row instead of 4 x 32 x 2.
+//     The reference point is the SMALLEST of the four per-column maxima, so every column's dominant predecessor maps to
+//     >= 1.0 — next to the diagonal adjacent columns of a row differ by 30+ binades and a shared maximum would flush
+//     the left columns.
+//   * EXACTNESS GUARD.  E <= 1 by construction.  A cell whose scaled sum S is below 2^-97 (or whose window spans more
+//     than 2^120) may have lost terms that matter to fp32 and is recomputed exactly in log space from the a2 row and
+//     the raw links; otherwise everything flushed is < 2^-24 of S.  Rare: needs ~65 nats between a column's largest
+//     predecessor term and the rest (emission cliffs), never on smooth data.
 //   * WAVE SPECIALISATION, NO vmcnt STALLS ON THE CRITICAL PATH.  Compute waves touch global memory only with stores.
 //       - loader wave : streams match rows into an 8-slot LDS ring with global_load_lds (LDS-DMA, no VGPRs), 7 rows
 //                       ahead, retired with a COUNTED s_waitcnt vmcnt(N) — never 0 in steady state;
@@ -24,6 +28,7 @@ namespace dsp {
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct StripParams {
     const float* match; const float* links; const int64_t* out_len; const int64_t* tgt_len;
@@ -31,6 +36,7 @@ struct StripParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
+    int dbg;
 };
 
 constexpr int S4_TRP = 32;
@@ -60,10 +66,11 @@ template <int NT, int MODE, bool BETA>
 __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw, int b, int s, int dirslot, int so)
 {
     constexpr int W = 4 * NT, RL = W + 32, GL = NT + 8, NCW = NT / 64, DPR = W / 256;
-    float* Pbuf = reinterpret_cast<float*>(smem_raw);          // [2][RL]  scaled linear values (MODE 0)
-    float* Abuf = Pbuf + 2 * RL;                               // [2][RL]  a2 (MODE 0, log2 domain) / alpha_max (MODE 1)
-    int* Cbuf = reinterpret_cast<int*>(Abuf + 2 * RL);         // [2][GL]  group scales
-    float* Mring = reinterpret_cast<float*>(Cbuf + 2 * GL);    // [RING][W] match rows
+    float* Abuf = reinterpret_cast<float*>(smem_raw);          // [2][RL]  a2 (MODE 0, log2 domain) / alpha_max (MODE 1)
+    float* Pbuf = Abuf + 2 * RL;                               // [2][RL]  mantissa 2^(a2 - ceil a2) in (0.5, 1]   (MODE 0)
+    int* Cbuf = reinterpret_cast<int*>(Pbuf + 2 * RL);         // [2][RL]  integer exponent ceil(a2)               (MODE 0)
+    float* Mring = reinterpret_cast<float*>(Cbuf + 2 * RL);    // [RING][W] match rows
+    (void)GL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, L = p.L, TR = p.TR;
@@ -80,8 +87,8 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
     const u64* hin = p.halo + ((size_t)(dirslot * p.B + b) * p.NS + (has_producer ? prod_strip : 0)) * (size_t)T * S4_TRP;
     u64* hout = p.halo + ((size_t)(dirslot * p.B + b) * p.NS + s) * (size_t)T * S4_TRP;
     // LDS geometry: alpha li = col - j0 + 32 (halo [0,32)); beta li = col - j0 (halo [W, W+32))
-    const int halo_li0 = BETA ? W : 0, halo_g0 = BETA ? NT : 0;
-    const int own_li0 = BETA ? 0 : 32, own_g0 = BETA ? 0 : 8;
+    const int halo_li0 = BETA ? W : 0;
+    const int own_li0 = BETA ? 0 : 32;
     const int pub_li0 = BETA ? 0 : W;          // boundary columns handed to the consumer: alpha last 32, beta first 32
 
     // ---- prologue: the strip's transition rows -> LDS tile (coalesced, once), then -> registers ----
@@ -92,11 +99,17 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
         constexpr int NTHR = NT + 192, RPP = NTHR / 32;       // rows per pass
         const int rlo = BETA ? j0 : (j0 - 32);
         const int dd = tid & 31, r0 = tid >> 5;
-        for (int r = r0; r < W + 32; r += RPP) {
-            const int i = rlo + r;
-            float v = NEG_INF;
-            if (dd < TR && i >= 0 && i < L) v = K[(size_t)i * TR + dd];
-            tile[r * 33 + dd] = v;
+        for (int rb = r0; rb < W + 32; rb += 8 * RPP) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                       // 8 independent (clamped, unconditional) loads in flight
+                const int i = rlo + rb + u * RPP;
+                const bool ok = dd < TR && i >= 0 && i < L;
+                const float raw = K[(size_t)(ok ? i : 0) * TR + (ok ? dd : 0)];
+                v[u] = ok ? raw : NEG_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int r = rb + u * RPP; if (r < W + 32) tile[r * 33 + dd] = v[u]; }
         }
     }
     __syncthreads();
@@ -106,6 +119,13 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
         const int l = tid;                       // lane's group
         const int j = j0 + 4 * l;
         const bool col_ok = j < L;
+        // structural reachability (cells outside are -inf in the reference too: their LSE runs over -inf terms only):
+        // alpha: t <= col <= min(L_b-1, t*TR);  beta: col >= t, col < L_b, L_b-1-col <= (T_b-1-t)*TR
+        auto cell_active = [&](int col, int t) -> bool {
+            if (col < t || col >= Lb) return false;
+            if (!BETA) return (long)col <= (long)t * TR;
+            return (long)(Lb - 1 - col) <= (long)(Tb - 1 - t) * TR;
+        };
         float E[4][32];
         float lmax[4];
         const float* tile = reinterpret_cast<const float*>(smem_raw);
@@ -132,6 +152,25 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                 for (int d = 0; d < 32; ++d) E[c][d] = raw[d];
             }
         }
+        // MODE 0: pair layout for v_pk_fma_f32 — E2[c][i] = (weight of window element 2i, weight of 2i+1) for column c,
+        // zero where the element is not a predecessor of that column; the window is consumed as 18 (w[2i], w[2i+1]) pairs.
+        v2f E2[4][18];
+        if (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    const int q0 = 2 * i, q1 = 2 * i + 1;
+                    const int d0 = BETA ? (q0 - c) : (32 + c - q0), d1 = BETA ? (q1 - c) : (32 + c - q1);
+                    E2[c][i].x = (d0 >= 1 && d0 <= 32) ? E[c][(d0 >= 1 && d0 <= 32) ? d0 - 1 : 0] : 0.f;
+                    E2[c][i].y = (d1 >= 1 && d1 <= 32) ? E[c][(d1 >= 1 && d1 <= 32) ? d1 - 1 : 0] : 0.f;
+                }
+            }
+        }
+        auto Eval = [&](int c, int d) -> float {        // E(c, d) recovered from the pair layout (static indices only)
+            const int q = BETA ? (c + d) : (32 + c - d);
+            return (q & 1) ? E2[c][q >> 1].y : E2[c][q >> 1].x;
+        };
         __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         s4_barrier();                            // prologue barrier: match row 0 is in the ring
 
@@ -149,67 +188,130 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                     if (seed) a2[c] = (MODE == 0) ? m2[c] * S4_LOG2E : m2[c];
                 }
             } else if (MODE == 0) {
-                int cg[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) cg[k] = Cbuf[prv * GL + l + k];
-                int ref = cg[0];
-#pragma unroll
-                for (int k = 1; k < 9; ++k) ref = max(ref, cg[k]);
-                // window walked group by group (4 live values instead of 36): element q of the window feeds the cells
-                // (c, d) with qidx(c, d) == q
-                float S[4] = {0.f, 0.f, 0.f, 0.f};
+                int cw[36];
+                float pw[36];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(Pbuf + prv * RL + 4 * l + 4 * k);
-                    const int e = max(cg[k] - ref, -250);
-                    const float wv[4] = {ldexpf(v.x, e), ldexpf(v.y, e), ldexpf(v.z, e), ldexpf(v.w, e)};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int q = 4 * k + i;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int d = BETA ? (q - c) : (32 + c - q);
-                            if (d >= 1 && d <= 32) S[c] = fmaf(wv[i], E[c][d - 1], S[c]);
-                        }
-                    }
+                    const int4 ci = *reinterpret_cast<const int4*>(Cbuf + prv * RL + 4 * l + 4 * k);
+                    const float4 pv = *reinterpret_cast<const float4*>(Pbuf + prv * RL + 4 * l + 4 * k);
+                    cw[4 * k] = ci.x; cw[4 * k + 1] = ci.y; cw[4 * k + 2] = ci.z; cw[4 * k + 3] = ci.w;
+                    pw[4 * k] = pv.x; pw[4 * k + 1] = pv.y; pw[4 * k + 2] = pv.z; pw[4 * k + 3] = pv.w;
                 }
-                const float reff = (float)ref;
+                // per-column maximum exponent over that column's predecessors: alpha q in [c, c+31], beta q in [c+1, c+32]
+                int common = cw[4];
+#pragma unroll
+                for (int q = 5; q <= 31; ++q) common = max(common, cw[q]);
+                int cm[4];
+                if (!BETA) {
+                    cm[0] = max(max(common, cw[0]), max(max(cw[1], cw[2]), cw[3]));
+                    cm[1] = max(max(common, cw[32]), max(max(cw[1], cw[2]), cw[3]));
+                    cm[2] = max(max(common, cw[32]), max(max(cw[33], cw[2]), cw[3]));
+                    cm[3] = max(max(common, cw[32]), max(max(cw[33], cw[34]), cw[3]));
+                } else {
+                    const int c32 = max(common, cw[32]);
+                    cm[0] = max(c32, max(max(cw[1], cw[2]), cw[3]));
+                    cm[1] = max(max(c32, cw[33]), max(cw[2], cw[3]));
+                    cm[2] = max(max(c32, cw[33]), max(cw[34], cw[3]));
+                    cm[3] = max(max(c32, cw[33]), max(cw[34], cw[35]));
+                }
+                const int hi = max(max(cm[0], cm[1]), max(cm[2], cm[3]));
+                int refi = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (cm[c] != NEGSENT) refi = min(refi, cm[c]);
+                const bool any_live = hi != NEGSENT;
+                if (!any_live) refi = 0;
+                const bool wide = (hi - refi) > 120;               // the four column maxima are > 2^120 apart
+                // one full-rate v_ldexp per window element (no transcendental): w = P * 2^(C - ref)
+                v2f S2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { S2[c].x = 0.f; S2[c].y = 0.f; }
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    v2f w2;
+                    w2.x = ldexpf(pw[2 * i], cw[2 * i] - refi);
+                    w2.y = ldexpf(pw[2 * i + 1], cw[2 * i + 1] - refi);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) S2[c] = __builtin_elementwise_fma(w2, E2[c][i], S2[c]);
+                }
+                float S[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) S[c] = S2[c].x + S2[c].y;
+                const float ref = (float)refi;
+                // all four cells unconditionally (independent FMA chains stay interleaved); masks applied by selects
                 bool need_fb = false;
+                const bool R_live = any_live;
+                bool flag[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const bool act = (j + c >= t) && (j + c < Lb);
-                    if (act && ref != NEGSENT) {
-                        if (S[c] < 0x1p-90f) need_fb = true;
-                        else a2[c] = __builtin_amdgcn_logf(S[c]) + reff + lmax[c] + m2[c] * S4_LOG2E;
-                    }
+                    const float cand = __builtin_amdgcn_logf(S[c]) + ref + lmax[c] + m2[c] * S4_LOG2E;
+                    const bool okc = cell_active(j + c, t) & (cm[c] != NEGSENT);
+                    flag[c] = okc & (wide | !(S[c] >= 0x1p-97f));
+                    a2[c] = (okc & !flag[c]) ? cand : NEG_INF;
+                    need_fb |= flag[c];
                 }
                 if (__builtin_expect(need_fb, 0)) {
-                    // exact log-space recomputation of the flagged cells (rare): a2 row from LDS, raw links from HBM
-                    // (E may have flushed links that are far below the column's largest one)
+                    // (a) MEDIUM path, registers only: redo the flagged column against ITS OWN maximum (covers windows whose
+                    //     four column maxima are > 2^120 apart — the diagonal at large t).  Falls through to the exact
+                    //     path only if the column's own sum is still below the exactness threshold.
+                    float aw[36];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float4 v = *reinterpret_cast<const float4*>(Abuf + prv * RL + 4 * l + 4 * k);
+                        aw[4 * k] = v.x; aw[4 * k + 1] = v.y; aw[4 * k + 2] = v.z; aw[4 * k + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (flag[c]) {
+                            float cmx = NEG_INF;
+#pragma unroll
+                            for (int d = 1; d <= 32; ++d) cmx = fmaxf(cmx, aw[qidx<BETA>(c, d)]);
+                            float sc = 0.f;
+#pragma unroll
+                            for (int d = 1; d <= 32; ++d)
+                                sc = fmaf(__builtin_amdgcn_exp2f(aw[qidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
+                            S[c] = sc;
+                            if (sc >= 0x1p-97f) a2[c] = __builtin_amdgcn_logf(sc) + cmx + lmax[c] + m2[c] * S4_LOG2E;
+                        } else {
+                            S[c] = 1.f;                      // settled by the fast path (or inactive)
+                        }
+                    }
+                    // (b) EXACT path for what is left
 #pragma unroll 1
                     for (int c = 0; c < 4; ++c) {
-                        const bool act = (j + c >= t) && (j + c < Lb);
-                        if (!(act && ref != NEGSENT && S[c] < 0x1p-90f)) continue;
-                        float mx = NEG_INF;
-                        for (int d = 1; d <= 32; ++d) {
-                            const float av = Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))];
-                            float lk = NEG_INF;
-                            if (!BETA) { const int i = j + c - d; if (d <= TR && i >= 0) lk = K[(size_t)i * TR + (d - 1)] * S4_LOG2E; }
-                            else { if (d <= TR && j + c + d < Lb) lk = K[(size_t)(j + c) * TR + (d - 1)] * S4_LOG2E; }
-                            mx = fmaxf(mx, av + lk);
-                        }
+                        { const int cmc = (c == 0) ? cm[0] : (c == 1) ? cm[1] : (c == 2) ? cm[2] : cm[3];
+                          const float Sc = (c == 0) ? S[0] : (c == 1) ? S[1] : (c == 2) ? S[2] : S[3];
+                          if (!(cell_active(j + c, t) && R_live && cmc != NEGSENT && !(Sc >= 0x1p-97f))) continue; }
+                        // (1) cheap structural test: is any predecessor alive (a2 row in LDS)?  if not the cell is -inf
+                        float amax = NEG_INF;
+                        for (int d = 1; d <= 32; ++d) amax = fmaxf(amax, Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))]);
                         float r = NEG_INF;
-                        if (mx != NEG_INF) {
-                            float sum = 0.f;
-                            for (int d = 1; d <= 32; ++d) {
-                                const float av = Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))];
-                                float lk = NEG_INF;
-                                if (!BETA) { const int i = j + c - d; if (d <= TR && i >= 0) lk = K[(size_t)i * TR + (d - 1)] * S4_LOG2E; }
-                                else { if (d <= TR && j + c + d < Lb) lk = K[(size_t)(j + c) * TR + (d - 1)] * S4_LOG2E; }
-                                sum += __builtin_amdgcn_exp2f(av + lk - mx);
+                        if (amax != NEG_INF) {
+                            // (2) exact log-space value; raw links re-read from HBM 8 at a time (independent loads)
+                            { const u32 slot = atomicAdd(&p.counters[2], 1u); if (slot < 14) { p.counters[8 + 4 * slot] = (u32)b; p.counters[9 + 4 * slot] = (u32)t; p.counters[10 + 4 * slot] = (u32)(j + c); p.counters[11 + 4 * slot] = (u32)refi; } }
+                            float mx = NEG_INF, sum = 0.f;
+                            for (int d0 = 1; d0 <= 32; d0 += 8) {
+                                float lk[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int d = d0 + u;
+                                    const int row = BETA ? (j + c) : (j + c - d);
+                                    const bool ok = d <= TR && row >= 0 && row < L && (!BETA || j + c + d < Lb);
+                                    const float raw = K[(size_t)(ok ? row : 0) * TR + (ok ? d - 1 : 0)];
+                                    lk[u] = ok ? raw * S4_LOG2E : NEG_INF;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int d = d0 + u;
+                                    const float v = Abuf[prv * RL + 4 * l + (BETA ? (c + d) : (32 + c - d))] + lk[u];
+                                    const float nm = fmaxf(mx, v);
+                                    if (nm != NEG_INF) sum = sum * __builtin_amdgcn_exp2f(mx - nm) + __builtin_amdgcn_exp2f(v - nm);
+                                    mx = nm;
+                                }
                             }
-                            const float mm = (c == 0) ? m2[0] : (c == 1) ? m2[1] : (c == 2) ? m2[2] : m2[3];
-                            r = __builtin_amdgcn_logf(sum) + mx + mm * S4_LOG2E;
+                            if (mx != NEG_INF) {
+                                const float mm = (c == 0) ? m2[0] : (c == 1) ? m2[1] : (c == 2) ? m2[2] : m2[3];
+                                r = __builtin_amdgcn_logf(sum) + mx + mm * S4_LOG2E;
+                            }
                         }
                         if (c == 0) a2[0] = r; else if (c == 1) a2[1] = r; else if (c == 2) a2[2] = r; else a2[3] = r;
                     }
@@ -237,20 +339,22 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const bool act = (j + c >= t) && (j + c < Lb);
+                    const bool act = (j + c >= t) && (j + c < Lb);     // (no reach mask here: bit-exact trace incl. -1s)
                     if (act) { a2[c] = mxv[c] + m2[c]; arg[c] = av[c]; }
                 }
             }
             // ---- write the row: LDS state for the next row, HBM output ----
             if (MODE == 0) {
-                const float mx = fmaxf(fmaxf(a2[0], a2[1]), fmaxf(a2[2], a2[3]));
-                int cn = NEGSENT; float cf = 0.f;
-                if (mx != NEG_INF) { cf = ceilf(mx); cn = (int)cf; }
-                float4 pv;
-                pv.x = __builtin_amdgcn_exp2f(a2[0] - cf); pv.y = __builtin_amdgcn_exp2f(a2[1] - cf);
-                pv.z = __builtin_amdgcn_exp2f(a2[2] - cf); pv.w = __builtin_amdgcn_exp2f(a2[3] - cf);
-                *reinterpret_cast<float4*>(Pbuf + cur * RL + own_li0 + 4 * l) = pv;
-                Cbuf[cur * GL + own_g0 + l] = cn;
+                float pn[4]; int cn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool dead = a2[c] == NEG_INF;
+                    const float cf = dead ? 0.f : ceilf(a2[c]);
+                    pn[c] = __builtin_amdgcn_exp2f(a2[c] - cf);
+                    cn[c] = dead ? NEGSENT : (int)cf;
+                }
+                *reinterpret_cast<float4*>(Pbuf + cur * RL + own_li0 + 4 * l) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                *reinterpret_cast<int4*>(Cbuf + cur * RL + own_li0 + 4 * l) = make_int4(cn[0], cn[1], cn[2], cn[3]);
             }
             *reinterpret_cast<float4*>(Abuf + cur * RL + own_li0 + 4 * l) = make_float4(a2[0], a2[1], a2[2], a2[3]);
             if (col_ok) {
@@ -336,12 +440,10 @@ __device__ __forceinline__ void strip4_body(const StripParams& p, char* smem_raw
                 if (hl) {
                     Abuf[cur * RL + halo_li0 + lane] = hv;
                     if (MODE == 0) {
-                        float mx = fmaxf(hv, __shfl_xor(hv, 1, 64));
-                        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-                        int cn = NEGSENT; float cf = 0.f;
-                        if (mx != NEG_INF) { cf = ceilf(mx); cn = (int)cf; }
+                        const bool dead = hv == NEG_INF;
+                        const float cf = dead ? 0.f : ceilf(hv);
                         Pbuf[cur * RL + halo_li0 + lane] = __builtin_amdgcn_exp2f(hv - cf);
-                        if ((lane & 3) == 0) Cbuf[cur * GL + halo_g0 + (lane >> 2)] = cn;
+                        Cbuf[cur * RL + halo_li0 + lane] = dead ? NEGSENT : (int)cf;
                     }
                 }
                 if (k == S4_CH - 1 && has_producer) load_chunk(itb + S4_CH);   // next chunk: one round trip per 8 rows
@@ -425,7 +527,7 @@ template <int NT, int MODE>
 static int launch_one(const StripParams& p, int nwg, hipStream_t st)
 {
     constexpr int W = 4 * NT, RL = W + 32, GL = NT + 8;
-    const size_t lds_main = (size_t)(4 * RL + 2 * GL + S4_RING * W) * 4 + 16;
+    const size_t lds_main = (size_t)(6 * RL + S4_RING * W) * 4 + 16; (void)GL;
     const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     auto k = dag_strip4_kernel<NT, MODE>;
@@ -445,7 +547,7 @@ int launch_dag_strip4(int mode, const float* match, const float* links, const in
     StripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = trace;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.dbg = 0;
     const size_t halo_bytes = (size_t)ndir * B * NS * T * S4_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;

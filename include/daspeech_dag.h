@@ -99,6 +99,11 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
  *   the stream and is meant for tests. */
 int dsp_dag_set_option(const char* name, int value);
 int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);
+/* cells that took the exp-space kernel's exact log-space fallback in the launch last queried by the call above */
+unsigned int dsp_dag_last_fallback_count(void);
+/* raw status words (63) captured by the last dsp_dag_last_launch_status call: [0] error, [1] fallback count,
+ * [7+4i..] = {sample, row, column, bits of S} of the first 14 fallback cells */
+const unsigned int* dsp_dag_debug_words(void);
 
 #ifdef __cplusplus
 }

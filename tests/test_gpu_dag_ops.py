@@ -309,6 +309,7 @@ def test_strip4_exactness_guard():
         _lib.set_option("dp_path", 3)
         loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
         assert _lib.last_launch_status() == 0
+        assert _lib.last_fallback_count() > 0          # the guard really fired
     finally:
         _lib.set_option("dp_path", 0)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
