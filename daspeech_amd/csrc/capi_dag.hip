@@ -78,7 +78,7 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
     hipStream_t st = as_stream(stream);
     if ((size_t)L * 4 <= 160 * 1024) {
         const bool s4 = strip4_supported(match, alpha_max, nullptr, trace, L, TR);
-        if ((g_path == 0 || g_path == 3) && s4) {
+        if (g_path == 3 && s4) {     // auto mode prefers the 2-column strips for the max-DP (measured faster, r01)
             rc = launch_dag_strip4(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
