@@ -61,6 +61,73 @@ __global__ __launch_bounds__(256) void dag_grad_links_generic_kernel(
     *out = acc * g_out[b];
 }
 
+// K5 tiled (TR-agnostic, used for every TR): one workgroup = 64 source vertices x 32 transition slots of one sample.
+// The reference walks alpha[t][i] / beta[t+1][i+d+1] down the t axis with stride-L loads per thread
+// (dag_loss.cu:471-475); here row tiles of alpha (64 wide) and beta (96 wide) are staged through LDS with coalesced
+// loads (pre-scaled to the log2 domain), so HBM/L2 see each alpha row once and each beta row 1.5x per 64-vertex block,
+// and the inner loop is LDS reads + v_exp_f32 only.
+constexpr int K5_TC = 32;
+__global__ __launch_bounds__(256) void dag_grad_links_tiled_kernel(
+    const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ links, const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
+    float* __restrict__ g_links, int B, int T, int L, int TR)
+{
+    __shared__ float At[K5_TC][64];
+    __shared__ float Bt[K5_TC][96];
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.x * 64, dc0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, i = tid & 63, dg = tid >> 6;
+    const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
+    const size_t TL = (size_t)T * L;
+    const float* A = alpha + (size_t)b * TL;
+    const float* Bp = beta + (size_t)b * TL;
+    const float b00 = Bp[0];
+    const bool dead = isinf(b00) || Tb > T || Lb > L || Tb < 1 || Lb < 1;
+    const int vi = i0 + i;
+    float extra[8], acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int d = dc0 + dg * 8 + u;
+        const bool ok = !dead && d < TR && vi < Lb && vi + d + 1 < Lb;                 // dag_loss.cu:461-466
+        extra[u] = ok ? (links[((size_t)b * L + vi) * TR + d] - b00) * LOG2E : NEG_INF;   // :469
+        acc[u] = 0.f;
+    }
+    const int nt = dead ? 0 : (Tb - 1);                    // t = 0 .. T_b-2   (:471-475)
+    const int bcol0 = i0 + dc0 + 1;                        // first beta column of the tile
+    for (int t0 = 0; t0 < nt; t0 += K5_TC) {
+        const int rows = min(K5_TC, nt - t0);
+        for (int e = tid; e < K5_TC * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            float v = NEG_INF;
+            if (r < rows && i0 + c < L) v = A[(size_t)(t0 + r) * L + i0 + c] * LOG2E;
+            At[r][c] = v;
+        }
+        for (int e = tid; e < K5_TC * 96; e += 256) {
+            const int r = e / 96, c = e - r * 96;
+            float v = NEG_INF;
+            if (r < rows && bcol0 + c < L) v = Bp[(size_t)(t0 + r + 1) * L + bcol0 + c] * LOG2E;
+            Bt[r][c] = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const float a = At[r][i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc[u] += __builtin_amdgcn_exp2f(a + Bt[r][i + dg * 8 + u] + extra[u]);
+        }
+        __syncthreads();
+    }
+    if (vi < L) {
+        const float go = g_out[b];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int d = dc0 + dg * 8 + u;
+            if (d < TR) g_links[((size_t)b * L + vi) * TR + d] = (extra[u] == NEG_INF) ? 0.f : acc[u] * go;
+        }
+    }
+}
+
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,
                            const int64_t* out_len, const int64_t* tgt_len, float* g_match, float* g_links,
                            int B, int T, int L, int TR, hipStream_t st)
@@ -73,7 +140,7 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         if (rc) return rc;
     }
     if (g_links) {
-        hipLaunchKernelGGL(dag_grad_links_generic_kernel, dim3((TR + 31) / 32, (L + 7) / 8, B), dim3(256), 0, st,
+        hipLaunchKernelGGL(dag_grad_links_tiled_kernel, dim3((L + 63) / 64, (TR + 31) / 32, B), dim3(256), 0, st,
                            g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
         int rc = check_launch("dag_loss_bwd(grad_links)");
         if (rc) return rc;

@@ -147,6 +147,107 @@ __global__ __launch_bounds__(256) void lsg_fwd_kernel(
     }
 }
 
+// Register-resident forward: the whole row (<= NV x 256 x 16 bytes) is read ONCE into registers with 16-byte loads, the
+// next row of the tile is prefetched while the current one is reduced, and the softmax is stored straight from the
+// registers — no second pass over the logits (the generic kernel above re-reads the row from L2 for the store).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
+    T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
+    float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
+    int B, int L, int V, int S, int RT, int write_softmax)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                // 16 floats
+    float* stage = smem + 16;         // [S][RT]
+    constexpr int N = Vec<T>::N;
+    const int tid = threadIdx.x;
+    const int tiles_per_b = (L + RT - 1) / RT;
+    const long ntiles = (long)B * tiles_per_b;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_b);
+        const int j0 = (int)(tile % tiles_per_b) * RT;
+        const int nr = min(RT, L - j0);
+        uint4 cur[NV], nxt[NV];
+        auto load_row = [&](int r, uint4 (&dst)[NV]) {
+            const T* row = x + ((size_t)b * L + (j0 + r)) * V;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                if (v < V) dst[k] = *reinterpret_cast<const uint4*>(row + v);
+            }
+        };
+        load_row(0, cur);
+        for (int r = 0; r < nr; ++r) {
+            T* row = x + ((size_t)b * L + (j0 + r)) * V;
+            if (r + 1 < nr) load_row(r + 1, nxt);
+            float f[NV][N];
+            float m = NEG_INF;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                const T* e = reinterpret_cast<const T*>(&cur[k]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { f[k][i] = (v < V) ? to_f(e[i]) : NEG_INF; m = fmaxf(m, f[k][i]); }
+            }
+            float s = 0.f;
+            if (m != NEG_INF) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s += __expf(f[k][i] - m);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+                online_merge(m, s, m2, s2);
+            }
+            __syncthreads();                              // red[] free; previous row's softmax stores are behind us
+            if ((tid & 63) == 0) { red[tid >> 6] = m; red[8 + (tid >> 6)] = s; }
+            __syncthreads();
+            m = red[0]; s = red[8];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) online_merge(m, s, red[w], red[8 + w]);
+            const float ls = __logf(s);
+            for (int k = tid; k < S; k += 256) {
+                int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+                stage[k * RT + r] = (to_f(row[t]) - m) - ls;            // L2-hot re-read of single elements
+            }
+            if (write_softmax) {
+                __syncthreads();                                          // gathers read the ORIGINAL logits
+                const float inv = 1.f / s;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int v = (k * 256 + tid) * N;
+                    if (v < V) {
+                        uint4 o;
+                        T* e = reinterpret_cast<T*>(&o);
+#pragma unroll
+                        for (int i = 0; i < N; ++i) e[i] = from_f<T>(__expf(f[k][i] - m) * inv);
+                        *reinterpret_cast<uint4*>(row + v) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) cur[k] = nxt[k];
+        }
+        __syncthreads();
+        const int tot = S * nr;
+        if (osj == 1 || oss != 1) {
+            for (int e = tid; e < tot; e += 256) {
+                int k = e / nr, r = e - k * nr;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        } else {
+            for (int e = tid; e < tot; e += 256) {
+                int r = e / S, k = e - r * S;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // backward: row <- softmax * (-(sum_s g)) + scatter_add(g)     (dag_loss.py:293-295)
 // The per-row scatter targets are accumulated in an LDS image of the row (ds_add_f32), so duplicates add up
 // exactly like scatter_add_ and the row is still written once.
@@ -215,6 +316,15 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
     const size_t lds = (16 + (size_t)S * RT) * sizeof(float);
     const long ntiles = (long)B * ((L + RT - 1) / RT);
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    // register-resident variant when the row fits NV x 256 sixteen-byte vectors
+    const int nvec = (V + 256 * N - 1) / (256 * N);
+    if (vec && nvec <= 8) {
+        auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : lsg_fwd_reg_kernel<T, 8>);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kr, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
+                           B, L, V, S, RT, ws);
+        return check_launch("logsoftmax_gather(reg)");
+    }
     auto k = vec ? lsg_fwd_kernel<T, true> : lsg_fwd_kernel<T, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
