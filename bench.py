@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--tgt-len", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1,24", help="B,T of the bounded CPU sample")
+    ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     return ap.parse_args()
 
 
