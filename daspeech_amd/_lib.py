@@ -30,6 +30,16 @@ SIGNATURES = {
     "dsp_dag_loss_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                   _c_p, _c_sz, _c_p]),
     "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    # include/daspeech_decode.h
+    "dsp_argmax_logp": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_lookahead_next": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_follow_path": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_gather_rows": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_durations": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
+    "dsp_bucketize_embed_add": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p]),
+    "dsp_length_regulator_lens": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    "dsp_length_regulator_expand": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "dsp_dag_last_launch_status": (_c_int, [_c_p, ctypes.POINTER(ctypes.c_uint)]),
     "dsp_dag_last_fallback_count": (ctypes.c_uint, []),

@@ -1,0 +1,65 @@
+/* daspeech_decode.h — C ABI of the inference-side steps of the DASpeech hot path (libdaspeech_hip.so).
+ *
+ * These entry points replace Python / torch code of the reference that runs on the host or as chains of small torch ops:
+ *   graph decode (lookahead / greedy)   DASpeech/models/s2s_conformer_dag_fastspeech2.py:201-243   (F2, F3 in SURVEY.md §2.3)
+ *   posterior of the "expect" strategy   DASpeech/criterions/s2s_dag_fastspeech2_loss.py:259-261     (F1)
+ *   variance-adaptor glue               fairseq/fairseq/models/text_to_speech/fastspeech2.py:169-210 (F6)
+ *   length regulator                    fairseq/fairseq/models/text_to_speech/fastspeech2.py:98-114  (F7)
+ * Conventions as in daspeech_dag.h (device pointers, caller-allocated outputs, hipStream_t as void*, int return codes). */
+#ifndef DASPEECH_DECODE_H
+#define DASPEECH_DECODE_H
+
+#include "daspeech_dag.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* F2a  per-vertex argmax token and its log-probability            (s2s_conformer_dag_fastspeech2.py:207-208)
+ *   logits [B,L,V] (dtype code as in daspeech_dag.h, read only); tok [B,L] int32 = argmax_v (first maximum);
+ *   score [B,L] fp32 = max_v log_softmax(logits) = -log sum_v exp(x_v - max). */
+int dsp_argmax_logp(const void* logits, int dtype, int32_t* tok, float* score, int B, int L, int V, dsp_stream_t stream);
+
+/* F2b  best successor of every vertex on the COMPACT links layout  (:209-217; replaces restore_valid_links + dense argmax)
+ *   links [B,L,TR] fp32; score [B,L] fp32 (ignored when greedy != 0); next[b,i] = argmax_j (links[b,i,j-i-1] + score[b,j]*beta)
+ *   with the dense row's tie rule: first maximum = smallest j; a row without any finite entry gives 0. */
+int dsp_lookahead_next(const float* links, const float* score, float beta, int greedy, int32_t* next,
+                       int B, int L, int TR, dsp_stream_t stream);
+
+/* F3a  follow the path 0 -> ... -> L_b-1, collapse repeats, drop pads        (:219-233)
+ *   out_tokens [B,cap] int64 (pad-filled; [b,0] = token of vertex 0), keep_idx [B,cap] int32 = vertex of each kept non-bos
+ *   token (-1 padded), n_feat [B] int32 = number of kept non-bos tokens. cap >= L is always enough. */
+int dsp_follow_path(const int32_t* next, const int32_t* tok, const int64_t* out_len, int pad,
+                    int64_t* out_tokens, int32_t* keep_idx, int32_t* n_feat, int B, int L, int cap, dsp_stream_t stream);
+
+/* F3b  gather the decoder states of the kept vertices, zero padded            (:232,234,241; _collate_frames)
+ *   features [B,L,D] (dtype code), keep_idx [B,cap]; out [B,Fmax,D] same dtype: out[b,k] = features[b,keep_idx[b,k]] for
+ *   k < n_feat[b], 0 after.  Pure copy: bit-exact. */
+int dsp_gather_rows(const void* features, int dtype, const int32_t* keep_idx, const int32_t* n_feat, void* out,
+                    int B, int L, int D, int cap, int Fmax, dsp_stream_t stream);
+
+/* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
+ *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */
+int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream);
+
+/* F6a  predicted durations                                                     (fastspeech2.py:202-205)
+ *   dur = clamp(round((exp(log_dur) - 1) * factor), 0) as int64, 0 where pad_mask != 0 (uint8/bool). */
+int dsp_durations(const float* log_dur, const uint8_t* pad_mask, float factor, int64_t* dur, int64_t n, dsp_stream_t stream);
+
+/* F6b  x += Embedding[bucketize(v, bins)]                                      (fastspeech2.py:169-177,207-210)
+ *   x [n,C] fp32 in/out, v [n] fp32, bins [nb] fp32 ascending (torch.bucketize right=False), emb [nb+1,C] fp32. */
+int dsp_bucketize_embed_add(float* x, const float* v, const float* bins, int nb, const float* emb, int64_t n, int C,
+                            dsp_stream_t stream);
+
+/* F7   length regulator                                                        (fastspeech2.py:98-114)
+ *   step 1: dsp_length_regulator_lens  : out_lens[b] = sum_t dur[b,t]; cum [B,N] int64 scratch = inclusive prefix sums.
+ *   step 2: dsp_length_regulator_expand: out [B,maxlen,C] (dtype code) = rows of x [B,N,C] repeated dur times, zero padded.
+ *   The caller reads max(out_lens) between the two (the output shape depends on it; the reference syncs B*N times). */
+int dsp_length_regulator_lens(const int64_t* dur, int64_t* cum, int64_t* out_lens, int B, int N, dsp_stream_t stream);
+int dsp_length_regulator_expand(const void* x, int dtype, const int64_t* cum, void* out, int B, int N, int C, int maxlen,
+                                dsp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASPEECH_DECODE_H */

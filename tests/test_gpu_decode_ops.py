@@ -1,0 +1,153 @@
+"""GPU parity of the inference-side ops (graph decode, posterior, variance-adaptor glue, length regulator) against the CPU
+oracle (oracle/dag_oracle.c, functions citing the reference lines) — integer / copy outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dag_oracle as orc
+from tests.util_inputs import make_dag_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def D():
+    from daspeech_amd import decode_ops
+    return decode_ops
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 512), (torch.float16, 97), (torch.bfloat16, 1000)])
+def test_argmax_logp(dtype, V):
+    rng = np.random.default_rng(V)
+    x = torch.from_numpy((rng.standard_normal((3, 41, V)) * 3).astype(np.float32)).to(dtype)
+    x[0, 0, 5] = x[0, 0, 9] = x[0, 0].max() + 1          # exact tie -> first index wins
+    tok_ref, sc_ref = orc.argmax_logp(x.float().numpy())
+    tok, sc = D().argmax_logp(x.to(dev()))
+    np.testing.assert_array_equal(tok.cpu().numpy(), tok_ref)
+    np.testing.assert_allclose(sc.cpu().numpy(), sc_ref, rtol=2e-6, atol=2e-6)
+    assert tok[0, 0].item() == 5
+
+
+@pytest.mark.parametrize("shape", [(3, 60, 8), (2, 33, 32), (2, 20, 19)])
+@pytest.mark.parametrize("greedy", [False, True])
+def test_lookahead_next_bit_exact(shape, greedy):
+    B, L, TR = shape
+    _, links, ol, _ = make_dag_inputs(5 + L, B, 4, L, TR)
+    rng = np.random.default_rng(L)
+    sc = (-rng.random((B, L)) * 3).astype(np.float32)
+    # quantise to provoke ties
+    links = np.where(np.isfinite(links), np.round(links * 4) / 4, links).astype(np.float32)
+    sc = np.round(sc * 4) / 4
+    ref = orc.lookahead_next(links, sc, beta=0.75, greedy=greedy)
+    out = D().lookahead_next(torch.from_numpy(links).to(dev()), torch.from_numpy(sc).to(dev()), 0.75, greedy)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # the dense formulation of the reference gives the same indices (s2s_conformer_dag_fastspeech2.py:214/217)
+    dense = torch.from_numpy(orc.restore_valid_links(links))
+    if greedy:
+        idx = dense.max(dim=-1)[1]
+    else:
+        idx = (dense + torch.from_numpy(sc).unsqueeze(1) * 0.75).max(dim=-1)[1]
+    np.testing.assert_array_equal(out.cpu().numpy(), idx.numpy())
+
+
+def test_graph_decode_matches_reference_loop():
+    B, L, TR, V, Dm, pad = 4, 48, 6, 30, 16, 1
+    rng = np.random.default_rng(3)
+    _, links, ol, _ = make_dag_inputs(3, B, 4, L, TR)
+    logits = (rng.standard_normal((B, L, V)) * 2).astype(np.float32)
+    logits[:, ::5, pad] += 20.0                                   # some vertices emit <pad>: must be dropped
+    logits[:, 1::7, 7] += 20.0; logits[:, 2::7, 7] += 20.0        # repeated tokens: collapsed
+    feats = rng.standard_normal((B, L, Dm)).astype(np.float32)
+    out_tok, out_feat, mask, lens = D().graph_decode(torch.from_numpy(logits).to(dev()), torch.from_numpy(links).to(dev()),
+                                                     torch.from_numpy(feats).to(dev()), torch.from_numpy(ol).to(dev()), pad, 1.0)
+    # restatement of the reference's host loop (s2s_conformer_dag_fastspeech2.py:219-243) on oracle tok/next
+    tok, sc = orc.argmax_logp(logits)
+    nxt = orc.lookahead_next(links, sc, 1.0)
+    toks_ref, keep_ref, nf_ref = orc.follow_path(nxt, tok, ol, pad)
+    for b in range(B):
+        last = tok[b, 0]; j = 0; res = [last]; kept = []
+        while j != ol[b] - 1:
+            j = nxt[b, j]; now = tok[b, j]
+            if now != pad and now != last:
+                res.append(now); kept.append(j)
+            last = now
+        assert nf_ref[b] == len(kept) and lens[b].item() == len(kept)
+        got = out_tok[b].cpu().numpy()
+        np.testing.assert_array_equal(got[: len(res)], np.array(res))
+        assert np.all(got[len(res):] == pad)
+        np.testing.assert_array_equal(out_feat[b, : len(kept)].cpu().numpy(), feats[b, kept])       # bit-exact gather
+        assert np.all(out_feat[b, len(kept):].cpu().numpy() == 0)
+        assert mask[b].cpu().numpy().tolist() == [False] * len(kept) + [True] * (out_feat.shape[1] - len(kept))
+
+
+def test_posterior_and_expect():
+    B, T, L, TR, Dm = 3, 9, 70, 8, 32
+    match, links, ol, tl = make_dag_inputs(17, B, T, L, TR)
+    a = orc.dag_alpha(match, links, ol, tl, np.float32)
+    b = orc.dag_beta(match, links, ol, tl, np.float32)
+    feats = np.random.default_rng(0).standard_normal((B, L, Dm)).astype(np.float32)
+    score_ref, ex_ref = orc.posterior_expect(a, b, feats)
+    score = D().posterior(torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev()))
+    np.testing.assert_allclose(score.cpu().numpy(), score_ref, rtol=1e-4, atol=1e-6)
+    rows = score.sum(-1).cpu().numpy()
+    for bb in range(B):
+        np.testing.assert_allclose(rows[bb, : tl[bb]], 1.0, rtol=1e-4)
+        assert np.all(rows[bb, tl[bb]:] == 0)                      # all -inf rows: NaN -> 0
+    ex = D().expect_features(torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev()), torch.from_numpy(feats).to(dev()))
+    np.testing.assert_allclose(ex.cpu().numpy(), ex_ref[:, 1:], rtol=1e-3, atol=1e-4)
+
+
+def test_durations_and_bucketize():
+    rng = np.random.default_rng(1)
+    ld = (rng.standard_normal((4, 37)) * 1.2 + 1.0).astype(np.float32)
+    ld[0, :4] = np.log(np.array([1.5, 2.5, 3.5, 0.2], np.float32))       # (exp-1) = .5, 1.5, 2.5: half-to-even cases
+    pm = rng.random((4, 37)) < 0.2
+    ref = orc.durations(ld, pm, 1.0)
+    out = D().predicted_durations(torch.from_numpy(ld).to(dev()), torch.from_numpy(pm).to(dev()), 1.0)
+    # expf on device vs libm can differ in the last ulp exactly on a rounding boundary: allow |diff| <= 1 on < 0.5 % of entries
+    diff = np.abs(out.cpu().numpy() - ref)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.005
+    assert np.all(out.cpu().numpy()[pm] == 0)
+    t = torch.clamp(torch.round((torch.exp(torch.from_numpy(ld)) - 1) * 1.0).long(), min=0).masked_fill(torch.from_numpy(pm), 0)
+    assert (np.abs(t.numpy() - out.cpu().numpy()) > 0).mean() < 0.005
+    # bucketize + embedding add (pitch / energy path)
+    C, nb = 24, 255
+    bins = np.linspace(-3.0, 3.0, nb).astype(np.float32)
+    v = (rng.standard_normal(4 * 37) * 2).astype(np.float32)
+    v[:3] = bins[[0, 100, 254]]                                     # exactly on an edge: right=False -> that index
+    emb = rng.standard_normal((nb + 1, C)).astype(np.float32)
+    x = rng.standard_normal((4 * 37, C)).astype(np.float32)
+    idx_ref = orc.bucketize(v, bins)
+    np.testing.assert_array_equal(idx_ref, torch.bucketize(torch.from_numpy(v), torch.from_numpy(bins)).numpy())
+    out = D().bucketize_embed_add(torch.from_numpy(x).to(dev()), torch.from_numpy(v).to(dev()), torch.from_numpy(bins).to(dev()),
+                                  torch.from_numpy(emb).to(dev()))
+    np.testing.assert_array_equal(out.cpu().numpy(), x + emb[idx_ref])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 3, 2), (5, 61, 256), (3, 300, 80), (1, 1, 7)])
+def test_length_regulator_bit_exact(shape, dtype):
+    B, N, C = shape
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((B, N, C)).astype(np.float32)
+    dur = rng.poisson(3.0, (B, N)).astype(np.int64)
+    dur[:, ::4] = 0
+    if shape == (2, 3, 2):
+        x = np.arange(12, dtype=np.float32).reshape(2, 3, 2) + 1
+        dur = np.array([[2, 0, 1], [1, 1, 0]])                       # SURVEY.md §9.3 example
+    xt = torch.from_numpy(x).to(dtype)
+    ref, lens_ref = orc.length_regulate(xt.float().numpy(), dur)
+    out, lens = D().length_regulate(xt.to(dev()), torch.from_numpy(dur).to(dev()))
+    np.testing.assert_array_equal(lens.cpu().numpy(), lens_ref)
+    np.testing.assert_array_equal(out.float().cpu().numpy(), ref)
+    if shape == (2, 3, 2):
+        assert lens.tolist() == [3, 2]
+
+
+def test_length_regulator_all_zero_durations():
+    x = torch.randn(2, 5, 8, device=dev())
+    out, lens = D().length_regulate(x, torch.zeros(2, 5, dtype=torch.long, device=dev()))
+    assert out.shape == (2, 0, 8) and lens.tolist() == [0, 0]
