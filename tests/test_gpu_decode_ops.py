@@ -84,7 +84,7 @@ def test_graph_decode_matches_reference_loop():
 
 
 def test_posterior_and_expect():
-    B, T, L, TR, Dm = 3, 9, 70, 8, 32
+    B, T, L, TR, Dm = 3, 9, 70, 16, 32
     match, links, ol, tl = make_dag_inputs(17, B, T, L, TR)
     a = orc.dag_alpha(match, links, ol, tl, np.float32)
     b = orc.dag_beta(match, links, ol, tl, np.float32)
