@@ -1,0 +1,183 @@
+"""FastSpeech2 without token embedding (the DASpeech TTS half) on top of the HIP variance-adaptor glue.
+
+Mirrors, with fairseq-compatible parameter names so a reference checkpoint's `tts.*` keys load:
+  FFNAdapter                 DASpeech/models/s2s_conformer_dag_fastspeech2.py:24-39
+  PositionwiseFeedForward / FFTLayer / VariancePredictor / VarianceAdaptor
+                             fairseq/fairseq/models/text_to_speech/fastspeech2.py:42-216
+  FastSpeech2EncoderNoEmb    DASpeech/models/fastspeech2_noemb.py:69-174
+The integer / copy steps (durations, bucketize + embedding add, length regulator) run as HIP kernels
+(daspeech_amd/decode_ops.py); dense layers are PyTorch-ROCm (hipBLASLt / MIOpen), as the north star prescribes.
+"""
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import decode_ops
+
+# README.md:295-300 model sizes of the released DASpeech configuration
+DEFAULT_TTS_ARGS = dict(
+    adaptor_in=512, adaptor_hidden=1024, embed_dim=256, heads=4, fft_hidden_dim=1024, fft_kernel_size=9, enc_layers=4,
+    dec_layers=4, var_pred_hidden_dim=256, var_pred_kernel_size=3, var_pred_n_bins=256, pitch_min=-4.6600, pitch_max=5.7333,
+    energy_min=-4.9544, energy_max=3.2244, out_dim=80, max_positions=1200,
+)
+
+
+class FFNAdapter(nn.Module):
+    def __init__(self, input_size: int, hidden_size: int, output_size: int):
+        super().__init__()
+        self.fc1 = nn.Linear(input_size, hidden_size)
+        self.fc2 = nn.Linear(hidden_size, output_size)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.fc2(F.relu(self.fc1(x)))
+
+
+class _SelfAttention(nn.Module):
+    """fairseq MultiheadAttention parameter names (q_proj / k_proj / v_proj / out_proj), self-attention only."""
+
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.heads = heads
+        self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(dim, dim) for _ in range(4))
+
+    def forward(self, x: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+        B, N, C = x.shape
+        h = self.heads
+        q = self.q_proj(x).view(B, N, h, C // h).transpose(1, 2)
+        k = self.k_proj(x).view(B, N, h, C // h).transpose(1, 2)
+        v = self.v_proj(x).view(B, N, h, C // h).transpose(1, 2)
+        mask = None
+        if padding_mask is not None:
+            mask = torch.zeros(B, 1, 1, N, dtype=x.dtype, device=x.device).masked_fill(padding_mask.view(B, 1, 1, N), float("-inf"))
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class _ConvFFN(nn.Module):
+    def __init__(self, dim: int, hidden: int, kernel: int):
+        super().__init__()
+        pad = (kernel - 1) // 2
+        self.ffn = nn.Sequential(nn.Conv1d(dim, hidden, kernel, padding=pad), nn.ReLU(), nn.Conv1d(hidden, dim, kernel, padding=pad))
+        self.layer_norm = nn.LayerNorm(dim)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.layer_norm(self.ffn(x.transpose(1, 2)).transpose(1, 2) + x)
+
+
+class FFTLayer(nn.Module):
+    def __init__(self, dim: int, heads: int, hidden: int, kernel: int):
+        super().__init__()
+        self.self_attn = _SelfAttention(dim, heads)
+        self.layer_norm = nn.LayerNorm(dim)
+        self.ffn = _ConvFFN(dim, hidden, kernel)
+
+    def forward(self, x: Tensor, padding_mask: Optional[Tensor] = None) -> Tensor:
+        x = self.layer_norm(self.self_attn(x, padding_mask) + x)
+        return self.ffn(x)
+
+
+class VariancePredictor(nn.Module):
+    """Conv1d-ReLU-LN-Conv1d-ReLU-LN-Linear (fastspeech2.py:117-151); dropout is identity at inference."""
+
+    def __init__(self, dim: int, hidden: int, kernel: int):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv1d(dim, hidden, kernel, padding=(kernel - 1) // 2), nn.ReLU())
+        self.ln1 = nn.LayerNorm(hidden)
+        self.conv2 = nn.Sequential(nn.Conv1d(hidden, hidden, kernel, padding=1), nn.ReLU())
+        self.ln2 = nn.LayerNorm(hidden)
+        self.proj = nn.Linear(hidden, 1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.ln1(self.conv1(x.transpose(1, 2)).transpose(1, 2))
+        x = self.ln2(self.conv2(x.transpose(1, 2)).transpose(1, 2))
+        return self.proj(x).squeeze(2)
+
+
+class VarianceAdaptor(nn.Module):
+    """fastspeech2.py:154-216.  Inference path (predicted durations / pitch / energy) uses the HIP ops; with teacher values
+    (training) the same kernels consume the provided tensors."""
+
+    def __init__(self, dim: int, hidden: int, kernel: int, n_bins: int, pitch_min: float, pitch_max: float,
+                 energy_min: float, energy_max: float):
+        super().__init__()
+        self.duration_predictor = VariancePredictor(dim, hidden, kernel)
+        self.pitch_predictor = VariancePredictor(dim, hidden, kernel)
+        self.energy_predictor = VariancePredictor(dim, hidden, kernel)
+        self.register_buffer("pitch_bins", torch.linspace(pitch_min, pitch_max, n_bins - 1), persistent=False)
+        self.register_buffer("energy_bins", torch.linspace(energy_min, energy_max, n_bins - 1), persistent=False)
+        self.embed_pitch = nn.Embedding(n_bins, dim)
+        self.embed_energy = nn.Embedding(n_bins, dim)
+
+    def forward(self, x: Tensor, padding_mask: Tensor, durations: Optional[Tensor] = None, pitches: Optional[Tensor] = None,
+                energies: Optional[Tensor] = None, d_factor: float = 1.0, p_factor: float = 1.0, e_factor: float = 1.0):
+        B, N, C = x.shape
+        log_dur_out = self.duration_predictor(x)
+        dur_out = decode_ops.predicted_durations(log_dur_out, padding_mask, d_factor)                     # :202-205
+        pitch_out = self.pitch_predictor(x)
+        pv = pitch_out * p_factor if pitches is None else pitches
+        x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), pv.reshape(-1), self.pitch_bins, self.embed_pitch.weight).view(B, N, C)
+        energy_out = self.energy_predictor(x)                                                             # on x + pitch_emb  :209
+        ev = energy_out * e_factor if energies is None else energies
+        x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), ev.reshape(-1), self.energy_bins, self.embed_energy.weight).view(B, N, C)
+        x, out_lens = decode_ops.length_regulate(x, dur_out if durations is None else durations)          # :212-214
+        if pitches is None:
+            pitch_out = pitch_out * p_factor
+        if energies is None:
+            energy_out = energy_out * e_factor
+        return x, out_lens, log_dur_out, pitch_out, energy_out
+
+
+def sinusoidal_table(n: int, dim: int, padding_idx: int = 1) -> Tensor:
+    """modules/sinusoidal_positional_embedding.py:36-58: [sin | cos] halves, row `padding_idx` zeroed."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n, 1)], dim=1)
+    tab[padding_idx] = 0
+    return tab
+
+
+def positions_from_padding_mask(padding_mask: Tensor, padding_idx: int = 1) -> Tensor:
+    """The reference feeds the padding MASK to the positional embedding as if it were tokens with pad=1
+    (fastspeech2_noemb.py:150,166 + fairseq/utils.py:256-266): non-pad frames get 2,3,..., pads get 1 (the zero row)."""
+    keep = (~padding_mask).int()
+    return (torch.cumsum(keep, dim=1) * keep).long() + padding_idx
+
+
+class FastSpeech2NoEmb(nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+        a = SimpleNamespace(**{**DEFAULT_TTS_ARGS, **kw})
+        self.args = a
+        self.pos_emb_alpha = nn.Parameter(torch.ones(1))
+        self.dec_pos_emb_alpha = nn.Parameter(torch.ones(1))
+        self.register_buffer("pos_table", sinusoidal_table(a.max_positions + 2, a.embed_dim), persistent=False)
+        self.encoder_fft_layers = nn.ModuleList(FFTLayer(a.embed_dim, a.heads, a.fft_hidden_dim, a.fft_kernel_size) for _ in range(a.enc_layers))
+        self.var_adaptor = VarianceAdaptor(a.embed_dim, a.var_pred_hidden_dim, a.var_pred_kernel_size, a.var_pred_n_bins,
+                                           a.pitch_min, a.pitch_max, a.energy_min, a.energy_max)
+        self.decoder_fft_layers = nn.ModuleList(FFTLayer(a.embed_dim, a.heads, a.fft_hidden_dim, a.fft_kernel_size) for _ in range(a.dec_layers))
+        self.out_proj = nn.Linear(a.embed_dim, a.out_dim)
+
+    def _pos(self, padding_mask: Tensor) -> Tensor:
+        idx = positions_from_padding_mask(padding_mask).clamp(max=self.pos_table.shape[0] - 1)
+        return self.pos_table[idx]
+
+    def forward(self, x: Tensor, padding_mask: Tensor, durations=None, pitches=None, energies=None):
+        """x [B,N,256] adaptor output, padding_mask [B,N] bool -> (mel [B,F,80], out_lens, log_dur, pitch, energy)
+        (fastspeech2_noemb.py:140-174)."""
+        x = x + self.pos_emb_alpha * self._pos(padding_mask)
+        for layer in self.encoder_fft_layers:
+            x = layer(x, padding_mask)
+        x, out_lens, log_dur, pitch, energy = self.var_adaptor(x, padding_mask, durations, pitches, energies)
+        F_ = x.shape[1]
+        dec_mask = torch.arange(F_, device=x.device).unsqueeze(0) >= out_lens.unsqueeze(1)
+        x = x + self.dec_pos_emb_alpha * self._pos(dec_mask)
+        for layer in self.decoder_fft_layers:
+            x = layer(x, dec_mask)
+        return self.out_proj(x), out_lens, log_dur, pitch, energy
