@@ -17,7 +17,11 @@ int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t
 bool strip4_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip4(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 
-// test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space, 3 = strip4
+bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
+int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
+
+// test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
+// 3 = strip4 (4 columns/lane, 3 helper waves), 4 = strip2 (2 columns/lane, loader wave)
 static int g_path = 0;
 static unsigned int g_last_fallbacks = 0;
 static unsigned int g_dbg[64] = {0};
@@ -43,7 +47,9 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     const bool s4 = strip4_supported(match, alpha, beta, nullptr, L, TR);
-    if ((g_path == 0 || g_path == 3) && s4)
+    if ((g_path == 0 || g_path == 4) && strip2_supported(match, alpha, beta, nullptr, L, TR))
+        rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
+    else if ((g_path == 0 || g_path == 3) && s4)
         rc = launch_dag_strip4(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 2 || g_path == 3) && TR <= 32 && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
@@ -78,7 +84,12 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
     hipStream_t st = as_stream(stream);
     if ((size_t)L * 4 <= 160 * 1024) {
         const bool s4 = strip4_supported(match, alpha_max, nullptr, trace, L, TR);
-        if (g_path == 3 && s4) {     // auto mode prefers the 2-column strips for the max-DP (measured faster, r01)
+        if ((g_path == 0 || g_path == 4) && strip2_supported(match, alpha_max, nullptr, trace, L, TR)) {
+            rc = launch_dag_strip2(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
+            if (rc) return rc;
+            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+        }
+        if (g_path == 3 && s4) {
             rc = launch_dag_strip4(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);

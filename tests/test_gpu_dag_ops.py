@@ -273,7 +273,7 @@ def test_fast_paths_match_generic_kernels(shape):
     m.requires_grad_()
     res = {}
     try:
-        for path in (1, 2, 3):
+        for path in (1, 2, 3, 4):
             _lib.set_option("dp_path", path)
             loss, (a, b) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
@@ -284,7 +284,7 @@ def test_fast_paths_match_generic_kernels(shape):
         _lib.set_option("dp_path", 0)
     _, a_g, b_g, p_g = res[1]
     fa = torch.isfinite(a_g); fb = torch.isfinite(b_g)
-    for path in (2, 3):
+    for path in (2, 3, 4):
         _, a_f, b_f, p_f = res[path]
         assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)), path
         assert torch.equal(torch.isneginf(b_f), torch.isneginf(b_g)), path
@@ -306,19 +306,22 @@ def test_strip4_exactness_guard():
     m, k, o, t = to_dev(match, links, ol, tl)
     m.requires_grad_()
     try:
-        _lib.set_option("dp_path", 3)
-        loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
-        assert _lib.last_launch_status() == 0
-        assert _lib.last_fallback_count() > 0          # the guard really fired
+        res = {}
+        for path in (3, 4):
+            _lib.set_option("dp_path", path)
+            loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+            assert _lib.last_launch_status() == 0
+            assert _lib.last_fallback_count() > 0          # the guard really fired
+            res[path] = (alpha.cpu().numpy(), beta.cpu().numpy())
     finally:
         _lib.set_option("dp_path", 0)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
     b64 = orc.dag_beta(match, links, ol, tl, np.float64)
-    a = alpha.cpu().numpy(); b = beta.cpu().numpy()
-    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
-    fa = np.isfinite(a64); fb = np.isfinite(b64)
-    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
-    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
+    for path, (a, b) in res.items():
+        assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), path
+        fa = np.isfinite(a64); fb = np.isfinite(b64)
+        np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
+        np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
 
 
 def test_banded_repeated_launches_reuse_workspace():
