@@ -12,6 +12,10 @@
 //     ONE counted s_waitcnt per row.  Compute waves only store (alpha / trace / boundary granules) and never wait on vmcnt;
 //     the lanes next to the halo convert the landed granules (tag check; a stale tag falls back to a direct poll).
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 namespace dsp {
 
@@ -62,8 +66,7 @@ template <bool BETA> __device__ __forceinline__ constexpr int q2(int c, int d) {
 template <int NT, int MODE, bool BETA>
 __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw, int b, int s, int dirslot, int so)
 {
-    constexpr int W = 2 * NT, RL = W + 32, NCW = NT / 64, DPR = W / 256;
-    static_assert(W % 256 == 0, "strip width must be a multiple of 256 columns (1 KiB LDS-DMA pieces)");
+    constexpr int W = 2 * NT, RL = W + 32, NCW = NT / 64, DPR = (W + 255) / 256;     // 1 KiB LDS-DMA pieces per match row
     float* Abuf = reinterpret_cast<float*>(smem_raw);          // [2][RL] a2 (MODE 0) / alpha_max (MODE 1)
     float* Pbuf = Abuf + 2 * RL;                               // [2][RL] mantissa 2^(a2 - ceil a2)
     int* Cbuf = reinterpret_cast<int*>(Pbuf + 2 * RL);         // [2][RL] exponent ceil(a2)
@@ -87,13 +90,15 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
     const int halo_li0 = BETA ? W : 0;
     const int own_li0 = BETA ? 0 : 32;
 
-    // ---- prologue: the strip's transition rows -> LDS tile (coalesced, once) ----
-    {
+    // ---- prologue: the strip's transition rows -> LDS tile -> registers, in TWO passes (half the lanes each) so the tile
+    //      (NT+34 rows x 33 floats = 38 KB) stays below the main-loop LDS footprint and two workgroups fit a CU ----
+    constexpr int TROWS = NT + 34;
+    auto stage_pass = [&](int pass) {
         float* tile = reinterpret_cast<float*>(smem_raw);
         constexpr int NTHR = NT + 64, RPP = NTHR / 32;
-        const int rlo = BETA ? j0 : (j0 - 32);
+        const int rlo = (BETA ? j0 : (j0 - 32)) + pass * NT;
         const int dd = tid & 31, r0 = tid >> 5;
-        for (int rb = r0; rb < W + 32; rb += 8 * RPP) {
+        for (int rb = r0; rb < TROWS; rb += 8 * RPP) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -103,10 +108,9 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
                 v[u] = ok ? raw : NEG_INF;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int r = rb + u * RPP; if (r < W + 32) tile[r * 33 + dd] = v[u]; }
+            for (int u = 0; u < 8; ++u) { const int r = rb + u * RPP; if (r < TROWS) tile[r * 33 + dd] = v[u]; }
         }
-    }
-    __syncthreads();
+    };
 
     if (wave < NCW) {
         // =========================================================== compute waves
@@ -122,41 +126,50 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
         const float* tile = reinterpret_cast<const float*>(smem_raw);
         float lmax[2];
         v2f E2[2][17];                 // MODE 0: pair layout of 2^(link2 - lmax);  MODE 1: raw links in the same layout
+        const int my_pass = (l >= NT / 2) ? 1 : 0;
+        const int lt = l - my_pass * (NT / 2);          // lane index inside its pass's tile
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            stage_pass(pass);
+            __syncthreads();
+            if (pass == my_pass) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float raw[32];
-            float mx = NEG_INF;
+                for (int c = 0; c < 2; ++c) {
+                    float raw[32];
+                    float mx = NEG_INF;
 #pragma unroll
-            for (int d = 1; d <= 32; ++d) {
-                float v;
-                if (!BETA) v = tile[(2 * l + c - d + 32) * 33 + (d - 1)];
-                else { v = tile[(2 * l + c) * 33 + (d - 1)]; if (j + c + d >= Lb) v = NEG_INF; }
-                raw[d - 1] = (MODE == 0) ? v * S2_LOG2E : v;
-                mx = fmaxf(mx, raw[d - 1]);
+                    for (int d = 1; d <= 32; ++d) {
+                        float v;
+                        if (!BETA) v = tile[(2 * lt + c - d + 32) * 33 + (d - 1)];
+                        else { v = tile[(2 * lt + c) * 33 + (d - 1)]; if (j + c + d >= Lb) v = NEG_INF; }
+                        raw[d - 1] = (MODE == 0) ? v * S2_LOG2E : v;
+                        mx = fmaxf(mx, raw[d - 1]);
+                    }
+                    if (MODE == 0) {
+                        if (mx == NEG_INF) mx = 0.f;
+                        lmax[c] = mx;
+#pragma unroll
+                        for (int d = 0; d < 32; ++d) raw[d] = __builtin_amdgcn_exp2f(raw[d] - mx);
+                    } else {
+                        lmax[c] = 0.f;
+                    }
+                    const float fill = (MODE == 0) ? 0.f : NEG_INF;
+#pragma unroll
+                    for (int i = 0; i < 17; ++i) {
+                        const int qa = 2 * i, qb = 2 * i + 1;
+                        const int da = BETA ? (qa - c) : (32 + c - qa), db = BETA ? (qb - c) : (32 + c - qb);
+                        E2[c][i].x = (da >= 1 && da <= 32) ? raw[(da >= 1 && da <= 32) ? da - 1 : 0] : fill;
+                        E2[c][i].y = (db >= 1 && db <= 32) ? raw[(db >= 1 && db <= 32) ? db - 1 : 0] : fill;
+                    }
+                }
             }
-            if (MODE == 0) {
-                if (mx == NEG_INF) mx = 0.f;
-                lmax[c] = mx;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) raw[d] = __builtin_amdgcn_exp2f(raw[d] - mx);
-            } else {
-                lmax[c] = 0.f;
-            }
-            const float fill = (MODE == 0) ? 0.f : NEG_INF;
-#pragma unroll
-            for (int i = 0; i < 17; ++i) {
-                const int qa = 2 * i, qb = 2 * i + 1;
-                const int da = BETA ? (qa - c) : (32 + c - qa), db = BETA ? (qb - c) : (32 + c - qb);
-                E2[c][i].x = (da >= 1 && da <= 32) ? raw[(da >= 1 && da <= 32) ? da - 1 : 0] : fill;
-                E2[c][i].y = (db >= 1 && db <= 32) ? raw[(db >= 1 && db <= 32) ? db - 1 : 0] : fill;
-            }
+            __syncthreads();
         }
         auto Eval = [&](int c, int d) -> float { const int q = q2<BETA>(c, d); return (q & 1) ? E2[c][q >> 1].y : E2[c][q >> 1].x; };
         // lanes that convert the landed halo granules (2 columns each) and lanes that publish this strip's boundary
         const bool halo_lane = tid < 16;
         const int pub_c = BETA ? (2 * l) : (2 * l - (W - 32));
         const bool pub_lane = has_consumer && pub_c >= 0 && pub_c < 32;
-        __syncthreads();                         // tile consumed
         s2_barrier();                            // prologue barrier: rows 0 .. PD-1 of match / halo are in the rings
 
         for (int it = 0; it < nrows; ++it) {
@@ -370,8 +383,9 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
             for (int i = 0; i < DPR; ++i) {
                 const int col = j0 + i * 256 + lane * 4;
                 const float* g = rowp + (col < L ? col : 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(mslot + i * 256), 16, 0, 0);
+                if (i * 256 + lane * 4 < W)                      // the last piece of a 384-column strip is half a wave
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(mslot + i * 256), 16, 0, 0);
             }
             if (has_producer) {
                 // 32 granules = 256 B: lanes 0..15 carry them, the others re-read lane 0's piece into a scratch slot tail
@@ -382,7 +396,7 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
                                                      (__attribute__((address_space(3))) void*)hs, 16, 0, 16 /* sc1 */);
             }
         };
-        __syncthreads();                         // link tile consumed
+        for (int pass = 0; pass < 2; ++pass) { stage_pass(pass); __syncthreads(); __syncthreads(); }
         for (int r = 0; r < S2_PD && r < nrows; ++r) issue_row(r);
         s2_wait_vmcnt<0>();
         s2_barrier();                            // prologue barrier
@@ -422,6 +436,16 @@ __global__ __launch_bounds__(NT + 64, 3) void dag_strip2_kernel(StripParams p)
     const int T = p.T, L = p.L;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    u64* census = nullptr;
+    if (p.dbg && tid == 0) {                          // residency census (DSP_DEBUG=census): hw id + start clock per workgroup
+        census = p.halo + (size_t)p.ndir * p.B * p.NS * T * 32 + (size_t)ticket * 4;
+        u32 hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        census[0] = ((u64)xcc << 32) | hwid;
+        census[1] = __builtin_readcyclecounter();
+        census[2] = wall_clock64();
+    }
     if (!valid || j0 >= Lb) {
         if (tid < NT) {
             const int j = j0 + 2 * tid;
@@ -438,6 +462,7 @@ __global__ __launch_bounds__(NT + 64, 3) void dag_strip2_kernel(StripParams p)
     __syncthreads();                               // everyone has read the ticket before the tile overlays the header area
     if (MODE == 0 && is_beta) strip2_body<NT, MODE, true>(p, smem_raw + 16, b, s, dirslot, so);
     else strip2_body<NT, MODE, false>(p, smem_raw + 16, b, s, dirslot, so);
+    if (census) census[3] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -455,10 +480,16 @@ static int launch_strip2(const StripParams& p, int nwg, hipStream_t st)
 {
     constexpr int W = 2 * NT, RL = W + 32;
     const size_t lds_main = (size_t)(6 * RL + S2_RING * W) * 4 + (size_t)S2_RING * 32 * 8;
-    const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
-    const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
+    const size_t lds_tile = (size_t)(NT + 34) * 33 * 4;
+    size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
+    if (getenv("DSP_S2_LDS")) lds = (size_t)atoi(getenv("DSP_S2_LDS"));
     auto k = dag_strip2_kernel<NT, MODE>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (getenv("DSP_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k, NT + 64, lds);
+        fprintf(stderr, "[dsp] strip2<%d,%d>: lds=%zu bytes, occupancy API = %d blocks/CU, grid=%d\n", NT, MODE, lds, nb, nwg);
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(NT + 64), lds, st, p);
     return check_launch(MODE == 0 ? "dag_loss_fwd(strip2)" : "dag_best_alignment(strip2)");
 }
@@ -467,17 +498,31 @@ int launch_dag_strip2(int mode, const float* match, const float* links, const in
                       float* alpha, float* beta, int32_t* trace, int B, int T, int L, int TR, hipStream_t st)
 {
     const int ndir = (mode == 0 && alpha && beta) ? 2 : 1;
-    constexpr int NT = 256, W = 2 * NT;
+    // 192 compute lanes + 64 loader lanes = 4 waves per workgroup = ONE WAVE PER SIMD per workgroup: with 5-wave
+    // workgroups the hardware admitted a single workgroup per CU although the occupancy API reported 2 (census in
+    // tools/census.py); 4-wave workgroups stack 3 deep at 168 VGPRs.
+    constexpr int NT = 192, W = 2 * NT;
     const int NS = (L + W - 1) / W;
     StripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = trace;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.dbg = 0;
     const size_t halo_bytes = (size_t)ndir * B * NS * T * 32 * sizeof(u64);
-    int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
-    if (rc) return rc;
     const int nwg = ndir * B * NS;
-    return mode == 0 ? launch_strip2<NT, 0>(p, nwg, st) : launch_strip2<NT, 1>(p, nwg, st);
+    const char* dbg = getenv("DSP_DEBUG");
+    const bool census = dbg && !strcmp(dbg, "census");
+    p.dbg = census ? 1 : 0;
+    int rc = banded_acquire_ws(st, halo_bytes + (census ? (size_t)nwg * 32 : 0), T, &p.counters, &p.halo, &p.tag_base);
+    if (rc) return rc;
+    rc = mode == 0 ? launch_strip2<NT, 0>(p, nwg, st) : launch_strip2<NT, 1>(p, nwg, st);
+    if (census && rc == 0) {
+        std::vector<u64> h((size_t)nwg * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), p.halo + (size_t)ndir * B * NS * T * 32, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen("/tmp/census.txt", "w");
+        if (f) { for (int i = 0; i < nwg; ++i) fprintf(f, "%d %llx %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]); fclose(f); }
+    }
+    return rc;
 }
 
 }  // namespace dsp
