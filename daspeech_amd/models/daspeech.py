@@ -1,0 +1,299 @@
+"""DASpeech model glue in PyTorch-ROCm: Conformer encoder -> DA-Transformer (NAT) decoder with the links head -> FFN adapter
+-> FastSpeech2-NoEmb -> (vocoder), behind the reference's plugin names.
+
+Mirrors (structure, tensor contracts, argument names; dense layers are plain torch = hipBLASLt/MIOpen MFMA GEMMs):
+  S2TConformerDAGModel           DASpeech/models/s2t_conformer_dag.py:60-443     (links head :140-212, graph size :281-283)
+  S2SConformerDAGFastSpeech2     DASpeech/models/s2s_conformer_dag_fastspeech2.py:42-354 (forward :143-173, forward_decoder :194-243)
+  S2TConformerEncoder            fairseq/fairseq/models/speech_to_text/s2t_conformer.py:32-162
+  ConformerEncoderLayer          fairseq/fairseq/modules/conformer_layer.py:21-286, espnet_multihead_attention.py:111-198
+  NATransformerDecoder           fairseq/fairseq/models/nat/nonautoregressive_transformer.py:207-366
+The DAG ops and the graph decode are the HIP kernels of this repo (daspeech_amd.custom_ops / daspeech_amd.decode_ops).
+Random weights of the released architecture (README.md:288-300) are what the synthetic benchmarks use.
+"""
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import decode_ops
+from .fastspeech2 import FFNAdapter, FastSpeech2NoEmb
+
+PAD, BOS, EOS, UNK = 1, 0, 2, 3          # fairseq Dictionary defaults
+
+DEFAULT_ARGS = dict(
+    input_feat=80, conv_channels=1024, conv_kernels=(5, 5),
+    encoder_layers=12, encoder_embed_dim=256, encoder_ffn_embed_dim=2048, encoder_attention_heads=4, depthwise_kernel=31,
+    decoder_layers=4, decoder_embed_dim=512, decoder_ffn_embed_dim=2048, decoder_attention_heads=8,
+    vocab_size=512, max_target_positions=1024, src_upsample_scale=0.5, max_transition_length=99999,
+    decode_strategy="lookahead", decode_beta=1.0, adaptor_ffn_dim=1024,
+)
+
+
+# ------------------------------------------------------------------------------------------------ Conformer encoder
+class Conv1dSubsampler(nn.Module):
+    """Two stride-2 Conv1d + GLU (speech_to_text/modules/convolution.py:13-59): T -> ~T/4."""
+
+    def __init__(self, in_ch, mid_ch, out_ch, kernels=(5, 5)):
+        super().__init__()
+        n = len(kernels)
+        self.conv_layers = nn.ModuleList(
+            nn.Conv1d(in_ch if i == 0 else mid_ch // 2, mid_ch if i < n - 1 else out_ch * 2, k, stride=2, padding=k // 2)
+            for i, k in enumerate(kernels))
+
+    def out_lengths(self, lens: Tensor) -> Tensor:
+        for _ in self.conv_layers:
+            lens = ((lens.float() - 1) / 2 + 1).floor().long()
+        return lens
+
+    def forward(self, x: Tensor, lens: Tensor):
+        x = x.transpose(1, 2)                        # B x C x T
+        for conv in self.conv_layers:
+            x = F.glu(conv(x), dim=1)
+        return x.transpose(1, 2), self.out_lengths(lens)
+
+
+def rel_positional_encoding(T: int, dim: int, device, dtype) -> Tensor:
+    """[1, 2T-1, dim] sinusoid over relative positions T-1 .. -(T-1) (modules/positional_encoding.py RelPositionalEncoding)."""
+    pos = torch.arange(T - 1, -T, -1.0, device=device).unsqueeze(1)
+    div = torch.exp(torch.arange(0, dim, 2, device=device).float() * -(math.log(10000.0) / dim))
+    pe = torch.zeros(2 * T - 1, dim, device=device)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0).to(dtype)
+
+
+class RelPosSelfAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.h, self.dk = heads, dim // heads
+        self.linear_q, self.linear_k, self.linear_v, self.linear_out = (nn.Linear(dim, dim) for _ in range(4))
+        self.linear_pos = nn.Linear(dim, dim, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.zeros(heads, self.dk))
+        self.pos_bias_v = nn.Parameter(torch.zeros(heads, self.dk))
+        nn.init.xavier_uniform_(self.pos_bias_u); nn.init.xavier_uniform_(self.pos_bias_v)
+
+    @staticmethod
+    def rel_shift(x: Tensor) -> Tensor:              # [B,h,T,2T-1] -> [B,h,T,T]
+        B, h, T, P = x.shape
+        x = F.pad(x, (1, 0)).view(B, h, P + 1, T)[:, :, 1:].reshape(B, h, T, P)
+        return x[..., : P // 2 + 1]
+
+    def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
+        B, T, C = x.shape
+        q = self.linear_q(x).view(B, T, self.h, self.dk)
+        k = self.linear_k(x).view(B, T, self.h, self.dk).transpose(1, 2)
+        v = self.linear_v(x).view(B, T, self.h, self.dk).transpose(1, 2)
+        p = self.linear_pos(pos).view(1, -1, self.h, self.dk).transpose(1, 2)
+        ac = torch.matmul((q + self.pos_bias_u).transpose(1, 2), k.transpose(-2, -1))
+        bd = self.rel_shift(torch.matmul((q + self.pos_bias_v).transpose(1, 2), p.transpose(-2, -1)))
+        scores = (ac + bd) / math.sqrt(self.dk)
+        if pad_mask is not None:
+            scores = scores.masked_fill(pad_mask.view(B, 1, 1, T), float("-inf"))
+        att = torch.softmax(scores, dim=-1)
+        return self.linear_out(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C))
+
+
+class ConformerLayer(nn.Module):
+    def __init__(self, dim, ffn, heads, dw_kernel):
+        super().__init__()
+        def ffn_block():
+            return nn.ModuleDict(dict(layer_norm=nn.LayerNorm(dim), w_1=nn.Linear(dim, ffn), w_2=nn.Linear(ffn, dim)))
+        self.ffn1, self.ffn2 = ffn_block(), ffn_block()
+        self.self_attn_layer_norm = nn.LayerNorm(dim)
+        self.self_attn = RelPosSelfAttention(dim, heads)
+        self.conv_module = nn.ModuleDict(dict(
+            layer_norm=nn.LayerNorm(dim), pointwise_conv1=nn.Conv1d(dim, 2 * dim, 1, bias=False),
+            depthwise_conv=nn.Conv1d(dim, dim, dw_kernel, padding=(dw_kernel - 1) // 2, groups=dim, bias=False),
+            batch_norm=nn.BatchNorm1d(dim), pointwise_conv2=nn.Conv1d(dim, dim, 1, bias=False)))
+        self.final_layer_norm = nn.LayerNorm(dim)
+
+    @staticmethod
+    def _ffn(m, x):
+        return m["w_2"](F.silu(m["w_1"](m["layer_norm"](x))))
+
+    def forward(self, x, pos, pad_mask):
+        x = x + 0.5 * self._ffn(self.ffn1, x)
+        x = x + self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask)
+        c = self.conv_module
+        y = c["layer_norm"](x).transpose(1, 2)
+        y = F.glu(c["pointwise_conv1"](y), dim=1)
+        y = c["pointwise_conv2"](F.silu(c["batch_norm"](c["depthwise_conv"](y)))).transpose(1, 2)
+        x = x + y
+        x = x + 0.5 * self._ffn(self.ffn2, x)
+        return self.final_layer_norm(x)
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, a):
+        super().__init__()
+        self.subsample = Conv1dSubsampler(a.input_feat, a.conv_channels, a.encoder_embed_dim, a.conv_kernels)
+        self.embed_scale = math.sqrt(a.encoder_embed_dim)
+        self.linear = nn.Linear(a.encoder_embed_dim, a.encoder_embed_dim)
+        self.conformer_layers = nn.ModuleList(
+            ConformerLayer(a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.encoder_attention_heads, a.depthwise_kernel)
+            for _ in range(a.encoder_layers))
+
+    def forward(self, src_tokens: Tensor, src_lengths: Tensor) -> Dict[str, Tensor]:
+        x, lens = self.subsample(src_tokens, src_lengths)
+        T = x.shape[1]
+        pad_mask = torch.arange(T, device=x.device).unsqueeze(0) >= lens.unsqueeze(1)
+        x = self.linear(self.embed_scale * x)
+        pos = rel_positional_encoding(T, x.shape[-1], x.device, x.dtype)
+        for layer in self.conformer_layers:
+            x = layer(x, pos, pad_mask)
+        return {"encoder_out": x, "encoder_padding_mask": pad_mask, "encoder_lengths": lens}
+
+
+# ------------------------------------------------------------------------------------------------ NAT decoder + links head
+class _MHA(nn.Module):
+    def __init__(self, dim, heads, kdim=None):
+        super().__init__()
+        kdim = kdim or dim
+        self.h = heads
+        self.q_proj, self.out_proj = nn.Linear(dim, dim), nn.Linear(dim, dim)
+        self.k_proj, self.v_proj = nn.Linear(kdim, dim), nn.Linear(kdim, dim)
+
+    def forward(self, x, mem, mem_pad):
+        B, N, C = x.shape
+        M = mem.shape[1]
+        q = self.q_proj(x).view(B, N, self.h, -1).transpose(1, 2)
+        k = self.k_proj(mem).view(B, M, self.h, -1).transpose(1, 2)
+        v = self.v_proj(mem).view(B, M, self.h, -1).transpose(1, 2)
+        mask = None
+        if mem_pad is not None:
+            mask = torch.zeros(B, 1, 1, M, dtype=x.dtype, device=x.device).masked_fill(mem_pad.view(B, 1, 1, M), float("-inf"))
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class NATDecoderLayer(nn.Module):
+    """Post-norm Transformer decoder layer without causal mask (modules/transformer_layer.py, NAT usage)."""
+
+    def __init__(self, dim, ffn, heads, enc_dim):
+        super().__init__()
+        self.self_attn, self.self_attn_layer_norm = _MHA(dim, heads), nn.LayerNorm(dim)
+        self.encoder_attn, self.encoder_attn_layer_norm = _MHA(dim, heads, enc_dim), nn.LayerNorm(dim)
+        self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
+
+    def forward(self, x, self_pad, enc, enc_pad):
+        x = self.self_attn_layer_norm(x + self.self_attn(x, x, self_pad))
+        x = self.encoder_attn_layer_norm(x + self.encoder_attn(x, enc, enc_pad))
+        return self.final_layer_norm(x + self.fc2(F.gelu(self.fc1(x))))
+
+
+class DAGDecoder(nn.Module):
+    def __init__(self, a):
+        super().__init__()
+        d = a.decoder_embed_dim
+        self.a = a
+        self.embed_tokens = nn.Embedding(a.vocab_size, d, padding_idx=PAD)
+        self.embed_positions = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
+        self.embed_scale = math.sqrt(d)
+        self.layers = nn.ModuleList(NATDecoderLayer(d, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.encoder_embed_dim)
+                                    for _ in range(a.decoder_layers))
+        # links head (s2t_conformer_dag.py:75-92: links_feature = feature:position)
+        self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
+        self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
+        self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
+
+    @staticmethod
+    def positions(tokens: Tensor) -> Tensor:
+        keep = tokens.ne(PAD).int()
+        return (torch.cumsum(keep, dim=1) * keep).long() + PAD
+
+    def extract_features(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]) -> Tensor:
+        x = self.embed_scale * self.embed_tokens(prev_output_tokens) + self.embed_positions(self.positions(prev_output_tokens))
+        pad = prev_output_tokens.eq(PAD)
+        for layer in self.layers:
+            x = layer(x, pad, enc["encoder_out"], enc["encoder_padding_mask"])
+        return x
+
+    def output_layer(self, feats: Tensor) -> Tensor:
+        return F.linear(feats, self.embed_tokens.weight)          # --share-decoder-input-output-embed
+
+    def extract_links(self, feats: Tensor, prev_output_tokens: Tensor) -> Tensor:
+        """Compact transition log-probs [B, L, TR] fp32 (s2t_conformer_dag.py:171-212, banded branch :191-202)."""
+        a = self.a
+        B, L, d = feats.shape
+        h, ck = a.decoder_attention_heads, d // a.decoder_attention_heads
+        fp = torch.cat([feats, self.link_positional(self.positions(prev_output_tokens))], dim=-1)
+        q = self.query_linear(fp).view(B, L, h, ck).float()
+        k = self.key_linear(fp).view(B, L, h, ck).float()
+        log_gates = F.log_softmax(self.gate_linear(fp), dim=-1, dtype=torch.float)                   # [B,L,h]
+        content = torch.einsum("bicf,bjcf->bijc", q, k) / (ck ** 0.5)                               # [B,L,L,h]
+        TR = min(a.max_transition_length, L - 1)
+        idx = torch.arange(L, device=feats.device).unsqueeze(1) + torch.arange(TR, device=feats.device).unsqueeze(0) + 1
+        out_len = prev_output_tokens.ne(PAD).sum(-1)
+        invalid = idx.unsqueeze(0) >= out_len.view(B, 1, 1)                                          # [B,L,TR]
+        gidx = idx.unsqueeze(0).masked_fill(invalid, 0)
+        band = content.gather(2, gidx.unsqueeze(-1).expand(-1, -1, -1, h)).masked_fill(invalid.unsqueeze(-1), float("-inf"))
+        nouse = invalid.all(-1)                                                                      # [B,L]
+        band = band.masked_fill(nouse.view(B, L, 1, 1), 0.0)                # avoid NaN rows; re-masked below (:199-201)
+        band = F.log_softmax(band, dim=2).masked_fill(invalid.unsqueeze(-1), float("-inf"))
+        band = band.masked_fill(nouse.view(B, L, 1, 1), float("-inf"))
+        return torch.logsumexp(band + log_gates.unsqueeze(2), dim=-1).masked_fill(invalid, float("-inf"))
+
+
+# ------------------------------------------------------------------------------------------------ models
+class S2TConformerDAGModel(nn.Module):
+    """registered name: s2t_conformer_dag"""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.args = SimpleNamespace(**{**DEFAULT_ARGS, **kw})
+        self.pad, self.bos, self.eos, self.unk = PAD, BOS, EOS, UNK
+        self.encoder = ConformerEncoder(self.args)
+        self.decoder = DAGDecoder(self.args)
+
+    # graph size: L = clamp(src_upsample_scale * src_frames, 2, max_target_positions)   (s2t_conformer_dag.py:281-283)
+    def initialize_output_tokens_by_src(self, src_lengths: Tensor) -> Tensor:
+        L = (src_lengths.float() * self.args.src_upsample_scale).long().clamp(2, self.args.max_target_positions)
+        maxl = int(L.max().item())
+        ar = torch.arange(maxl, device=src_lengths.device).unsqueeze(0)
+        toks = torch.full((len(L), maxl), self.unk, dtype=torch.long, device=src_lengths.device)
+        toks = toks.masked_fill(ar >= L.unsqueeze(1), self.pad)
+        toks[:, 0] = self.bos
+        return toks.scatter(1, (L - 1).unsqueeze(1), self.eos)
+
+    def forward_encoder(self, src_tokens, src_lengths):
+        return self.encoder(src_tokens, src_lengths)
+
+    def decode_graph(self, prev_output_tokens, enc):
+        feats = self.decoder.extract_features(prev_output_tokens, enc)
+        return self.decoder.output_layer(feats), self.decoder.extract_links(feats, prev_output_tokens), feats
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, tgt_tokens=None, glat=None, glat_function=None):
+        """Training forward with the GLAT two-pass scheme (s2s_conformer_dag_fastspeech2.py:143-173): pass 1 without grad
+        picks the glanced positions, pass 2 (with grad) produces word_ins / links / features."""
+        enc = self.encoder(src_tokens, src_lengths)
+        if glat is not None and glat_function is not None and tgt_tokens is not None:
+            with torch.no_grad():
+                logits, links, _ = self.decode_graph(prev_output_tokens, enc)
+                prev_output_tokens, tgt_tokens, glat_info = glat_function(self, logits, links, prev_output_tokens, tgt_tokens, glat)
+        logits, links, feats = self.decode_graph(prev_output_tokens, enc)
+        return {"word_ins": {"out": logits, "tgt": tgt_tokens, "mask": tgt_tokens.ne(self.pad) if tgt_tokens is not None else None,
+                             "features": feats, "nll_loss": True},
+                "links": links, "prev_output_tokens": prev_output_tokens}
+
+
+class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
+    """registered name: s2s_conformer_dag_fastspeech2"""
+
+    def __init__(self, **kw):
+        tts_kw = kw.pop("tts", {})
+        super().__init__(**kw)
+        a = self.args
+        self.tts = FastSpeech2NoEmb(**tts_kw)
+        self.adaptor = FFNAdapter(a.decoder_embed_dim, a.adaptor_ffn_dim, self.tts.args.embed_dim)
+
+    @torch.no_grad()
+    def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]):
+        """Lookahead / greedy graph decode on the GPU (s2s_conformer_dag_fastspeech2.py:194-243)."""
+        logits, links, feats = self.decode_graph(prev_output_tokens, enc)
+        out_len = prev_output_tokens.ne(self.pad).sum(-1)
+        toks, ofeat, mask, lens = decode_ops.graph_decode(logits, links, feats, out_len, self.pad, self.args.decode_beta,
+                                                          self.args.decode_strategy)
+        return {"output_tokens": toks, "features": ofeat, "features_padding_mask": mask, "feature_lengths": lens}

@@ -1,0 +1,49 @@
+"""Synthetic CVSS-C fr-en shaped batches and the two task shells that hand them out.  The sample dict keys are
+the contract the criteria read (datasets/nat_speech_to_speech_dataset.py:196-209,270-287)."""
+import torch
+
+from .models.daspeech import BOS, EOS, PAD
+
+
+def make_s2st_batch(B: int, device, seed: int = 0, vocab: int = 512, min_frames: int = 300, max_frames: int = 800):
+    g = torch.Generator().manual_seed(seed)
+    frames = torch.randint(min_frames, max_frames + 1, (B,), generator=g)
+    Fm = int(frames.max())
+    fbank = torch.randn(B, Fm, 80, generator=g)
+    L = (frames.float() * 0.5).long()
+    n_ph = (frames.float() / 13).round().long().clamp(min=8)
+    n_ph = torch.minimum(n_ph, L - 2)
+    T = int(n_ph.max()) + 2
+    tgt = torch.full((B, T), PAD, dtype=torch.long)
+    dur = torch.zeros(B, T - 1, dtype=torch.long)
+    pitch = torch.zeros(B, T - 1); energy = torch.zeros(B, T - 1)
+    for b in range(B):
+        n = int(n_ph[b])
+        tgt[b, 0] = BOS; tgt[b, 1:n + 1] = torch.randint(4, vocab, (n,), generator=g); tgt[b, n + 1] = EOS
+        dur[b, :n] = 1 + torch.poisson(torch.full((n,), 7.5), generator=g).long()      # eos gets 0 frames
+        pitch[b, :n + 1] = torch.rand(n + 1, generator=g) * 10.39 - 4.66
+        energy[b, :n + 1] = torch.rand(n + 1, generator=g) * 8.18 - 4.95
+    mel_len = dur.sum(1).clamp(max=1200)
+    Fo = int(mel_len.max())
+    mel = torch.randn(B, Fo, 80, generator=g)
+    s = {"net_input": {"src_tokens": fbank, "src_lengths": frames}, "target_text": tgt, "target_text_lengths": n_ph + 2,
+         "target_audio": mel, "target_audio_lengths": mel_len, "durations": dur, "pitches": pitch, "energies": energy}
+
+    def mv(x):
+        return {k: mv(v) for k, v in x.items()} if isinstance(x, dict) else x.to(device)
+    return mv(s)
+
+
+class NATSpeechToSpeechTask:
+    """Shell of tasks/nat_speech_to_speech.py (:32): argument names kept, data = synthetic batches."""
+    name = "nat_speech_to_speech"
+
+    def __init__(self, max_tokens: int = 20000, batch_size: int = 32, seed: int = 1):
+        self.max_tokens, self.batch_size, self.seed = max_tokens, batch_size, seed
+
+    def get_batch(self, device, step: int = 0):
+        return make_s2st_batch(self.batch_size, device, self.seed + step)
+
+
+class NATSpeechToTextTask(NATSpeechToSpeechTask):
+    name = "nat_speech_to_text"
