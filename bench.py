@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--graph-len", type=int, default=4096)
     ap.add_argument("--tgt-len", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=8192)
+    ap.add_argument("--workload", default="dag", choices=["dag", "s2st", "train"],
+                    help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2st = C4 full fbank->waveform pipeline; "
+                         "train = C5 DASpeech training step (s2s_dag_fastspeech2_loss + flat-bucket gradient all-reduce)")
+    ap.add_argument("--vocoder-backend", default="torch", choices=["torch", "hip"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     return ap.parse_args()
@@ -71,6 +75,80 @@ def cpu_baseline(args):
     }
 
 
+def run_model_workload(args, torch, dist, dev, world, rank):
+    """C4 (s2st) / C5 (train): released architecture (93.6 M parameters), random weights, synthetic CVSS-C shaped batches."""
+    from daspeech_amd.criterions import s2s_dag_fastspeech2_loss
+    from daspeech_amd.distributed import all_reduce_gradients
+    from daspeech_amd.generator import S2SNATGenerator
+    from daspeech_amd.models import HiFiGANGenerator
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model
+    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
+    torch.manual_seed(1234)
+    B = args.batch
+    model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev)
+    batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    if args.workload == "s2st":
+        model.eval()
+        voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
+        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev))
+        frames = [0]
+
+        def step(i):
+            out = gen.generate(model, batches[i % len(batches)])
+            frames[0] += sum(o["feature"].shape[0] for o in out)
+            return out
+        wl = (f"C4 full S2ST pipeline, lookahead decode: Conformer(12L,256) -> DA-Transformer(4L,512) + links -> HIP graph decode -> "
+              f"FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) -> HiFi-GAN V1 ({args.vocoder_backend} convs), "
+              f"B={B}/GPU, fbank80 300-800 frames, fp32")
+    else:
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
+
+        def step(i):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, log = s2s_dag_fastspeech2_loss(model, batches[i % len(batches)])
+            loss.backward()
+            all_reduce_gradients(model.parameters(), world)            # ONE flat bucket (SURVEY §2.4)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            return loss
+        wl = (f"C5 DASpeech training step: s2s_dag_fastspeech2_loss (GLAT two-pass, HIP DAG ops, expect strategy) fwd+bwd + "
+              f"flat-bucket gradient all-reduce + Adam, B={B}/GPU (global {B * world}), bf16 autocast dense / fp32 DAG ops")
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if args.workload == "s2st":
+        extra["mel_frames_per_utt"] = frames[0] / max(1, (args.steps + args.warmup) * B)
+    result = {
+        "metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.workload == "s2st" else "bf16", "data": "synthetic",
+        "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"dp{world}", **extra},
+        "roofline": None, "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -89,6 +167,8 @@ def main():
     from daspeech_amd import custom_ops as ops
     from daspeech_amd import _lib
     _lib.load()
+    if args.workload != "dag":
+        return run_model_workload(args, torch, dist, dev, world, rank)
     import sys as _sys
     _mod = _sys.modules["daspeech_amd.custom_ops.dag_loss"]
     lsg_fwd, lsg_bwd = _mod._lsg_forward, _mod._lsg_backward

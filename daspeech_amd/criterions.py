@@ -14,15 +14,16 @@ from . import custom_ops, decode_ops
 
 
 def compute_dag_loss(outputs: Tensor, output_masks: Tensor, targets: Tensor, target_masks: Tensor, links: Tensor,
-                     glat_keep_mask: Tensor = None, with_alpha_beta: bool = False):
+                     glat_keep_mask: Tensor = None, matchmask: Tensor = None, with_alpha_beta: bool = False):
     """loss = -(dag_loss / T_b).mean(), non-finite samples zeroed and counted (nat_dag_loss.py:114-156)."""
     B, L, _ = outputs.shape
     out_len = output_masks.sum(-1)
     tgt_len = target_masks.sum(-1)
     _, match = custom_ops.dag_logsoftmax_gather_inplace(outputs, targets.unsqueeze(1).expand(-1, L, -1))
     match = match.transpose(1, 2)                                                     # [B,T,L], already contiguous
-    if glat_keep_mask is not None:                                                    # force-emit mask (:130-132)
-        match = match.masked_fill(glat_keep_mask, 0) + match.masked_fill(~glat_keep_mask, float("-inf")).detach()
+    if glat_keep_mask is not None and matchmask is not None:                          # force-emit mask (:130-132)
+        gl = glat_keep_mask.unsqueeze(1)                                              # [B,1,L] glanced vertices
+        match = match.masked_fill(gl, 0) + match.masked_fill(~matchmask, float("-inf")).masked_fill(~gl, 0).detach()
     if with_alpha_beta:
         loss_b, (alpha, beta) = custom_ops.dag_loss_with_alpha_beta(match, links, out_len, tgt_len)
     else:
@@ -51,9 +52,8 @@ def glat_function(model, logits: Tensor, links: Tensor, prev_output_tokens: Tens
     keep_prob = ((tgt_len - same) / tgt_len.clamp(min=1) * glat["context_p"]).unsqueeze(-1) * predict_align_mask.float()
     keep_mask = (torch.rand_like(keep_prob) < keep_prob) & predict_align_mask
     glat_prev = prev_output_tokens.masked_fill(keep_mask, 0) + oracle.masked_fill(~keep_mask, 0)
-    keep_tgt = matchmask & keep_mask.unsqueeze(1)                                     # [B,T,L] cells forced to emit
-    return glat_prev, tgt_tokens, {"glat_keep": keep_tgt, "glat_acc": (same.sum() / tgt_len.sum().clamp(min=1)),
-                                   "path": path}
+    return glat_prev, tgt_tokens, {"glat_keep": keep_mask, "matchmask": matchmask,
+                                   "glat_acc": (same.sum() / tgt_len.sum().clamp(min=1)), "path": path}
 
 
 def s2s_dag_fastspeech2_loss(model, sample: Dict[str, Tensor], glat_p: float = 0.1, tts_loss_weight: float = 5.0):
@@ -72,7 +72,7 @@ def s2s_dag_fastspeech2_loss(model, sample: Dict[str, Tensor], glat_p: float = 0
     logits, links, feats = out["word_ins"]["out"], out["links"], out["word_ins"]["features"]
     prev = out["prev_output_tokens"]
     dag = compute_dag_loss(logits, prev.ne(model.pad), tgt, tgt.ne(model.pad), links, glat_state.get("glat_keep"),
-                           with_alpha_beta=True)
+                           glat_state.get("matchmask"), with_alpha_beta=True)
     # expect strategy: z_i = sum_j P(a_i = j | x, y) v_j   (:252-265)
     expect = decode_ops.posterior(dag["alpha"], dag["beta"]).to(feats.dtype)
     tts_in = model.adaptor(torch.matmul(expect, feats)[:, 1:, :])

@@ -198,6 +198,7 @@ class DAGDecoder(nn.Module):
         self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
         self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
+        self.synthetic_link_bias = None
 
     @staticmethod
     def positions(tokens: Tensor) -> Tensor:
@@ -229,12 +230,16 @@ class DAGDecoder(nn.Module):
         out_len = prev_output_tokens.ne(PAD).sum(-1)
         invalid = idx.unsqueeze(0) >= out_len.view(B, 1, 1)                                          # [B,L,TR]
         gidx = idx.unsqueeze(0).masked_fill(invalid, 0)
-        band = content.gather(2, gidx.unsqueeze(-1).expand(-1, -1, -1, h)).masked_fill(invalid.unsqueeze(-1), float("-inf"))
+        band = content.gather(2, gidx.unsqueeze(-1).expand(-1, -1, -1, h))
+        if self.synthetic_link_bias is not None:       # benchmark calibration only (synthetic.calibrate_synthetic_weights)
+            band = band + self.synthetic_link_bias[:TR].to(band).view(1, 1, TR, 1)
+        band = band.masked_fill(invalid.unsqueeze(-1), float("-inf"))
         nouse = invalid.all(-1)                                                                      # [B,L]
         band = band.masked_fill(nouse.view(B, L, 1, 1), 0.0)                # avoid NaN rows; re-masked below (:199-201)
         band = F.log_softmax(band, dim=2).masked_fill(invalid.unsqueeze(-1), float("-inf"))
         band = band.masked_fill(nouse.view(B, L, 1, 1), float("-inf"))
-        return torch.logsumexp(band + log_gates.unsqueeze(2), dim=-1).masked_fill(invalid, float("-inf"))
+        from ..custom_ops import logsumexp_keepdim                 # -inf safe (no NaN gradients on fully masked entries)
+        return logsumexp_keepdim(band + log_gates.unsqueeze(2), -1).squeeze(-1).masked_fill(invalid, float("-inf"))
 
 
 # ------------------------------------------------------------------------------------------------ models

@@ -171,6 +171,9 @@ class FastSpeech2NoEmb(nn.Module):
     def forward(self, x: Tensor, padding_mask: Tensor, durations=None, pitches=None, energies=None):
         """x [B,N,256] adaptor output, padding_mask [B,N] bool -> (mel [B,F,80], out_lens, log_dur, pitch, energy)
         (fastspeech2_noemb.py:140-174)."""
+        if x.shape[1] == 0:                       # nothing decoded (the reference would fail in torch.cat([]), SURVEY §9.2)
+            z = x.new_zeros(x.shape[0], 0)
+            return x.new_zeros(x.shape[0], 0, self.args.out_dim), x.new_zeros(x.shape[0], dtype=torch.long), z, z, z
         x = x + self.pos_emb_alpha * self._pos(padding_mask)
         for layer in self.encoder_fft_layers:
             x = layer(x, padding_mask)

@@ -66,13 +66,15 @@ def test_generator_end_to_end():
     from daspeech_amd.generator import S2SNATGenerator
     from daspeech_amd.models import HiFiGANGenerator
     from daspeech_amd.synthetic import make_s2st_batch
-    m = small_model().eval()
+    from daspeech_amd.synthetic import calibrate_synthetic_weights
+    m = calibrate_synthetic_weights(small_model().eval())
     voc = HiFiGANGenerator({"upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4], "upsample_initial_channel": 64,
                             "resblock_kernel_sizes": [3, 7, 11], "resblock_dilation_sizes": [[1, 3, 5]] * 3}).cuda().eval()
     gen = S2SNATGenerator(voc, torch.zeros(80), torch.ones(80))
     s = make_s2st_batch(2, "cuda", seed=3, min_frames=100, max_frames=140)
     out = gen.generate(m, s)
     assert len(out) == 2
+    assert all(8 <= o["feature"].shape[0] <= 1200 for o in out)          # calibrated shapes: tens of phonemes x ~7.5 frames
     for o in out:
         assert o["feature"].shape[1] == 80 and o["waveform"].shape[0] == o["feature"].shape[0] * 256
         assert torch.isfinite(o["waveform"]).all()
