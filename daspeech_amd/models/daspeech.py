@@ -252,6 +252,7 @@ class S2TConformerDAGModel(nn.Module):
         self.pad, self.bos, self.eos, self.unk = PAD, BOS, EOS, UNK
         self.encoder = ConformerEncoder(self.args)
         self.decoder = DAGDecoder(self.args)
+        self.synthetic_token_cycle = 0
 
     # graph size: L = clamp(src_upsample_scale * src_frames, 2, max_target_positions)   (s2t_conformer_dag.py:281-283)
     def initialize_output_tokens_by_src(self, src_lengths: Tensor) -> Tensor:
@@ -268,7 +269,12 @@ class S2TConformerDAGModel(nn.Module):
 
     def decode_graph(self, prev_output_tokens, enc):
         feats = self.decoder.extract_features(prev_output_tokens, enc)
-        return self.decoder.output_layer(feats), self.decoder.extract_links(feats, prev_output_tokens), feats
+        logits = self.decoder.output_layer(feats)
+        if self.synthetic_token_cycle:               # benchmark calibration only: vertex j prefers token 4 + (j mod cycle)
+            L, V = logits.shape[1], logits.shape[2]
+            tok = 4 + torch.arange(L, device=logits.device) % min(self.synthetic_token_cycle, V - 4)
+            logits = 0.0 * logits + 20.0 * F.one_hot(tok, V).to(logits).unsqueeze(0)     # GEMM still runs; values replaced
+        return logits, self.decoder.extract_links(feats, prev_output_tokens), feats
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, tgt_tokens=None, glat=None, glat_function=None):
         """Training forward with the GLAT two-pass scheme (s2s_conformer_dag_fastspeech2.py:143-173): pass 1 without grad

@@ -53,8 +53,9 @@ class NATSpeechToTextTask(NATSpeechToSpeechTask):
 def calibrate_synthetic_weights(model, mean_jump: float = 6.5, frames_per_phoneme: float = 7.5):
     """Random weights decode degenerate graphs (a handful of tokens, zero-length durations).  For throughput runs the two
     data-dependent SHAPES are pinned to CVSS-C statistics (README.md:165-167: ~13 source frames per phoneme, ~7.5 mel frames
-    per phoneme): a distance prior on the transition logits (mean jump 6.5 vertices at L = frames/2) and the duration
-    predictor's bias.  Values elsewhere stay random — throughput does not depend on them."""
+    per phoneme): a distance prior on the transition logits (mean jump 6.5 vertices at L = frames/2), distinct argmax tokens on
+    neighbouring vertices (a random output layer collapses every vertex onto one token), and the duration predictor's bias.  Values elsewhere stay random — throughput does not depend on them."""
+    model.synthetic_token_cycle = 97           # distinct neighbouring tokens: no repeat-collapse, no <pad> emissions
     d = torch.arange(1, model.args.max_target_positions + 1, dtype=torch.float)
     model.decoder.synthetic_link_bias = -4.0 * ((d - mean_jump) / 2.0) ** 2
     dp = model.tts.var_adaptor.duration_predictor
