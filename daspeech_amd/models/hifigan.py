@@ -110,6 +110,11 @@ class HiFiGANGenerator(nn.Module):
 
     def forward(self, mel: Tensor) -> Tensor:
         """mel [B, 80, T] (de-normalised log-mel) -> waveform [B, 1, T*256] in (-1, 1)."""
+        if self.conv_backend == "hip" and mel.is_cuda:
+            if getattr(self, "_hip_runner", None) is None:
+                from ..hifigan_ops import HiFiGANHipRunner
+                self._hip_runner = HiFiGANHipRunner(self)
+            return self._hip_runner(mel)
         x = self._conv(mel, self.conv_pre)
         nk = len(self.rb_kernels)
         for i, up in enumerate(self.ups):
