@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--workload", default="dag", choices=["dag", "s2st", "train"],
                     help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2st = C4 full fbank->waveform pipeline; "
                          "train = C5 DASpeech training step (s2s_dag_fastspeech2_loss + flat-bucket gradient all-reduce)")
-    ap.add_argument("--vocoder-backend", default="torch", choices=["torch", "hip"])
+    ap.add_argument("--vocoder-backend", default="hip", choices=["torch", "hip"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     return ap.parse_args()

@@ -12,8 +12,9 @@ from torch import Tensor
 
 
 class S2SNATGenerator:
-    def __init__(self, vocoder=None, gcmvn_mean: Optional[Tensor] = None, gcmvn_std: Optional[Tensor] = None):
-        self.vocoder, self.mean, self.std = vocoder, gcmvn_mean, gcmvn_std
+    def __init__(self, vocoder=None, gcmvn_mean: Optional[Tensor] = None, gcmvn_std: Optional[Tensor] = None,
+                 vocoder_group: int = 8):
+        self.vocoder, self.mean, self.std, self.vocoder_group = vocoder, gcmvn_mean, gcmvn_std, vocoder_group
 
     def gcmvn_denormalize(self, x: Tensor) -> Tensor:
         if self.mean is None:
@@ -29,17 +30,28 @@ class S2SNATGenerator:
         tts_in = model.adaptor(dec["features"])
         mel, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
         mel = self.gcmvn_denormalize(mel)
-        wav = None
-        if generate_waveform and self.vocoder is not None and mel.shape[1] > 0:
-            fmask = torch.arange(mel.shape[1], device=mel.device).unsqueeze(0) >= out_lens.unsqueeze(1)
-            wav = self.vocoder(mel.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2)).squeeze(1)   # batched, by length
         hop = getattr(self.vocoder, "hop", 256)
         lens = out_lens.tolist()
+        wavs = [None] * len(lens)
+        if generate_waveform and self.vocoder is not None and mel.shape[1] > 0:
+            # vocode in length-sorted groups: the batch is padded to each GROUP's maximum, not the batch maximum
+            # (the reference vocodes one file at a time, hifi-gan/inference_e2e.py:47-56)
+            order = sorted(range(len(lens)), key=lambda i: lens[i])
+            gsz = max(1, self.vocoder_group)
+            for g0 in range(0, len(order), gsz):
+                idx = order[g0:g0 + gsz]
+                gmax = max(1, max(lens[i] for i in idx))
+                sel = torch.tensor(idx, device=mel.device)
+                sub = mel.index_select(0, sel)[:, :gmax]
+                fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= out_lens.index_select(0, sel).unsqueeze(1)
+                w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2)).squeeze(1)
+                for k, i in enumerate(idx):
+                    wavs[i] = w[k, : max(lens[i], 1) * hop]
         res = []
         for b, n in enumerate(lens):
             feat = mel[b, :n] if n > 0 else mel.new_zeros(1, mel.shape[-1])              # zeros[1,80] when empty (:263)
             item = {"tokens": dec["output_tokens"][b], "feature": feat}
-            if wav is not None:
-                item["waveform"] = wav[b, : max(n, 1) * hop]
+            if wavs[b] is not None:
+                item["waveform"] = wavs[b]
             res.append(item)
         return res
