@@ -9,6 +9,9 @@
 // Replaces: calculate_alpha_kernel (dag_loss.cu:40-140), calculate_beta_kernel (:178-274),
 //           calculate_maxalpha_kernel (dag_best_alignment.cu:39-130), calculate_backtrace_kernel (:170-206).
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 
 namespace dsp {
 
@@ -18,7 +21,7 @@ constexpr int DP_THREADS = 1024;
 __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
     const float* __restrict__ match, const float* __restrict__ links,
     const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-    float* __restrict__ alpha, float* __restrict__ beta, int B, int T, int L, int TR)
+    float* __restrict__ alpha, float* __restrict__ beta, int B, int T, int L, int TR, long sR, long sD, long sB)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* rowA = smem;
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
     const bool do_beta = (alpha == nullptr) ? true : (blockIdx.y == 1);
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const float* M = match + (size_t)b * T * L;
-    const float* K = links + (size_t)b * L * TR;
+    const float* K = links + (size_t)b * sB;        // links[b][i][d] at K[i*sR + d*sD] (original or transposed copy)
     float* O = (do_beta ? beta : alpha) + (size_t)b * T * L;
     const int tid = threadIdx.x;
 
@@ -58,11 +61,11 @@ __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
                     const int maxd = min(j, TR);                         // :96
                     float mx = NEG_INF;
                     for (int d = 1; d <= maxd; ++d)
-                        mx = fmaxf(mx, prev[j - d] + K[(size_t)(j - d) * TR + (d - 1)]);
+                        mx = fmaxf(mx, prev[j - d] + K[(size_t)(j - d) * sR + (size_t)(d - 1) * sD]);
                     if (mx != NEG_INF) {                                 // :113-115
                         float s = 0.f;
                         for (int d = 1; d <= maxd; ++d)
-                            s += __expf(prev[j - d] + K[(size_t)(j - d) * TR + (d - 1)] - mx);
+                            s += __expf(prev[j - d] + K[(size_t)(j - d) * sR + (size_t)(d - 1) * sD] - mx);
                         res = __logf(s) + mx + Mt[j];                    // :126
                     }
                 }
@@ -88,12 +91,12 @@ __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
                 float res = NEG_INF;
                 if (j >= t && j < Lb) {                                  // dag_loss.cu:229-230
                     const int maxd = min(Lb - 1 - j, TR);                // :232
-                    const float* Kj = K + (size_t)j * TR;
+                    const float* Kj = K + (size_t)j * sR;
                     float mx = NEG_INF;
-                    for (int d = 1; d <= maxd; ++d) mx = fmaxf(mx, prev[j + d] + Kj[d - 1]);
+                    for (int d = 1; d <= maxd; ++d) mx = fmaxf(mx, prev[j + d] + Kj[(size_t)(d - 1) * sD]);
                     if (mx != NEG_INF) {
                         float s = 0.f;
-                        for (int d = 1; d <= maxd; ++d) s += __expf(prev[j + d] + Kj[d - 1] - mx);
+                        for (int d = 1; d <= maxd; ++d) s += __expf(prev[j + d] + Kj[(size_t)(d - 1) * sD] - mx);
                         res = __logf(s) + mx + Mt[j];
                     }
                 }
@@ -120,7 +123,7 @@ __global__ void dag_pick_loss_kernel(const float* alpha, const float* beta, cons
 __global__ __launch_bounds__(DP_THREADS) void dag_maxalpha_generic_kernel(
     const float* __restrict__ match, const float* __restrict__ links,
     const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-    float* __restrict__ alpha, int32_t* __restrict__ trace, int B, int T, int L, int TR)
+    float* __restrict__ alpha, int32_t* __restrict__ trace, int B, int T, int L, int TR, long sR, long sD, long sB)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* prev = smem;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(DP_THREADS) void dag_maxalpha_generic_kernel(
     const int b = blockIdx.x;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const float* M = match + (size_t)b * T * L;
-    const float* K = links + (size_t)b * L * TR;
+    const float* K = links + (size_t)b * sB;
     float* O = alpha + (size_t)b * T * L;
     int32_t* Tr = trace + (size_t)b * T * L;
     const int tid = threadIdx.x;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(DP_THREADS) void dag_maxalpha_generic_kernel(
                 const int maxd = min(j, TR);
                 float mx = NEG_INF;
                 for (int d = maxd; d >= 1; --d) {
-                    float v = prev[j - d] + K[(size_t)(j - d) * TR + (d - 1)];
+                    float v = prev[j - d] + K[(size_t)(j - d) * sR + (size_t)(d - 1) * sD];
                     if (v > mx) { mx = v; arg = j - d; }
                 }
                 res = mx + Mt[j];
@@ -188,6 +191,198 @@ __global__ __launch_bounds__(256) void dag_backtrace_kernel(
     for (int j = threadIdx.x; j < L; j += blockDim.x) path[(size_t)b * L + j] = lp[j];
 }
 
+// links[b][i][d] -> ET[b][d][i]: with lanes mapped to vertices the row-sequential kernels read links[j-d][d-1] (alpha) /
+// links[j][d-1] (beta) for consecutive j — a stride-TR gather in the original layout (one 64-byte sector per lane and term;
+// 39 GB of L2 sector traffic per training step at L~400, TR=L-1), unit stride in the transposed copy.
+__global__ __launch_bounds__(256) void dag_transpose_links_kernel(const float* __restrict__ links, float* __restrict__ et, int L, int TR)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+    const float* src = links + (size_t)b * L * TR;
+    float* dst = et + (size_t)b * L * TR;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const int i = i0 + r, d = d0 + tx; tile[r][tx] = (i < L && d < TR) ? src[(size_t)i * TR + d] : 0.f; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int d = d0 + r, i = i0 + tx; if (i < L && d < TR) dst[(size_t)d * L + i] = tile[tx][r]; }
+}
+
+static std::mutex g_et_mutex;
+static std::unordered_map<unsigned long long, std::pair<void*, size_t>> g_et;
+
+static const float* transposed_links(const float* links, int B, int L, int TR, hipStream_t st, long* sR, long* sD, long* sB)
+{
+    *sR = TR; *sD = 1; *sB = (long)L * TR;
+    if (TR <= 64) return links;                         // short windows: the original layout is fine
+    std::lock_guard<std::mutex> lock(g_et_mutex);
+    int dev = 0; (void)hipGetDevice(&dev);
+    const unsigned long long key = ((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st;
+    auto& e = g_et[key];
+    const size_t need = (size_t)B * L * TR * sizeof(float);
+    if (e.second < need) {
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr; e.second = 0;
+        if (hipMalloc(&e.first, need) != hipSuccess) { (void)hipGetLastError(); return links; }      // fall back to the gather
+        e.second = need;
+    }
+    hipLaunchKernelGGL(dag_transpose_links_kernel, dim3((TR + 31) / 32, (L + 31) / 32, B), dim3(256), 0, st, links, (float*)e.first, L, TR);
+    *sR = 1; *sD = L;
+    return (const float*)e.first;
+}
+
+
+// ------------------------------------------------------------------------------------------------ dense window (TR > 64)
+// README's --max-transition-length 99999 makes TR = L-1: every vertex sees ALL earlier vertices.  Thread-per-column then
+// serialises up to L terms per lane (94 us per DP row at L=400).  Here a WAVE owns a column and its 64 lanes split the
+// predecessor distance d: the previous row is read from LDS at consecutive addresses and the transition weights at unit stride
+// — for alpha / max-alpha from the "incoming" copy IN[b][j][d-1] = links[b][j-d][d-1] built by dag_incoming_links_kernel, for
+// beta straight from links[b][j][:].  One online (max, sum) per lane, a wave shuffle reduction per column, one coalesced row
+// store per DP row.
+__global__ __launch_bounds__(256) void dag_incoming_links_kernel(const float* __restrict__ links, float* __restrict__ in, int L, int TR)
+{
+    const int b = blockIdx.z, j = blockIdx.y;
+    const float* src = links + (size_t)b * L * TR;
+    float* dst = in + ((size_t)b * L + j) * TR;
+    for (int d = blockIdx.x * blockDim.x + threadIdx.x + 1; d <= TR; d += gridDim.x * blockDim.x)
+        dst[d - 1] = (j - d >= 0) ? src[(size_t)(j - d) * TR + (d - 1)] : NEG_INF;
+}
+
+template <int MODE>      // 0: log-sum (alpha, or beta when blockIdx.y == 1 / alpha == nullptr); 1: max + trace (alpha direction)
+__global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
+    const float* __restrict__ match, const float* __restrict__ links, const float* __restrict__ incoming,
+    const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
+    float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ trace, int B, int T, int L, int TR)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* prev = smem;
+    float* cur = smem + L;
+    int* carg = reinterpret_cast<int*>(smem + 2 * L);          // MODE 1: argmax row
+    const int b = blockIdx.x;
+    const bool do_beta = (MODE == 0) && ((alpha == nullptr) ? true : (blockIdx.y == 1));
+    const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
+    const float* M = match + (size_t)b * T * L;
+    float* O = (do_beta ? beta : alpha) + (size_t)b * T * L;
+    int32_t* Tr = (MODE == 1) ? trace + (size_t)b * T * L : nullptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = DP_THREADS / 64;
+    const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    for (int t = valid ? Tb : 0; t < T; ++t)
+        for (int j = tid; j < L; j += DP_THREADS) { O[(size_t)t * L + j] = NEG_INF; if (MODE == 1) Tr[(size_t)t * L + j] = -1; }
+    if (!valid) return;
+    {   // seed row
+        const int t = do_beta ? Tb - 1 : 0;
+        for (int j = tid; j < L; j += DP_THREADS) {
+            const float v = (do_beta ? (j == Lb - 1) : (j == 0)) ? M[(size_t)t * L + j] : NEG_INF;
+            prev[j] = v; O[(size_t)t * L + j] = v; if (MODE == 1) Tr[(size_t)t * L + j] = -1;
+        }
+    }
+    __syncthreads();
+    for (int it = 1; it < Tb; ++it) {
+        const int t = do_beta ? (Tb - 1 - it) : it;
+        const float* Mt = M + (size_t)t * L;
+        for (int j = tid; j < L; j += DP_THREADS) { cur[j] = NEG_INF; if (MODE == 1) carg[j] = -1; }
+        __syncthreads();
+        // QUARTER-WAVE per column: 16 lanes split the predecessor distance d, 4 columns per wave in flight; the per-column
+        // reduction is 4 DPP steps inside a 16-lane row (no LDS permutes).
+        const int q = lane >> 4, l16 = lane & 15;
+        for (int jb = t + (wave * 4); jb < Lb; jb += NW * 4) {
+            const int j = jb + q;
+            const bool live = j < Lb;
+            const int maxd = live ? (do_beta ? min(Lb - 1 - j, TR) : min(j, TR)) : 0;
+            const float* Kj = (do_beta ? links : incoming) + ((size_t)b * L + (live ? j : 0)) * TR;
+            if (MODE == 0) {
+                float m = NEG_INF, sacc = 0.f;
+                for (int d0 = 0; d0 < maxd; d0 += 128) {                     // 8 independent loads per lane in flight
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int d = d0 + 16 * u + l16 + 1;
+                        const int dc = min(d, max(maxd, 1));                    // unconditional (clamped) loads: all 8 in flight
+                        const float kk = Kj[dc - 1];
+                        const float pp = do_beta ? prev[min(j + dc, L - 1)] : prev[max(j - dc, 0)];
+                        v[u] = (d <= maxd) ? (pp + kk) : NEG_INF;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (v[u] > m) { sacc = sacc * __expf(m - v[u]) + 1.f; m = v[u]; }
+                        else if (v[u] != NEG_INF) sacc += __expf(v[u] - m);
+                    }
+                }
+                auto merge = [&](float m2, float s2) {
+                    const float nm = fmaxf(m, m2);
+                    sacc = (nm == NEG_INF) ? 0.f : sacc * __expf(m - nm) + s2 * __expf(m2 - nm);
+                    m = nm;
+                };
+                merge(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)),
+                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xF, 0xF, true)));
+                merge(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)),
+                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xF, 0xF, true)));
+                merge(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)),
+                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xF, 0xF, true)));
+                merge(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)),
+                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x140, 0xF, 0xF, true)));
+                if (l16 == 0 && live) cur[j] = (m == NEG_INF) ? NEG_INF : (__logf(sacc) + m + Mt[j]);
+            } else {
+                float best = NEG_INF; int bd = 0;                  // among equal maxima keep the LARGEST d (smallest predecessor)
+                for (int d0 = 0; d0 < maxd; d0 += 128) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int d = d0 + 16 * u + l16 + 1;
+                        const int dc = min(d, max(maxd, 1));
+                        const float kk = Kj[dc - 1];
+                        const float pp = prev[max(j - dc, 0)];
+                        v[u] = (d <= maxd) ? (pp + kk) : NEG_INF;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int d = d0 + 16 * u + l16 + 1;
+                        if (v[u] > best || (v[u] == best && v[u] != NEG_INF)) { best = v[u]; bd = d; }
+                    }
+                }
+                auto mergeb = [&](float b2, int d2) { if (b2 > best || (b2 == best && d2 > bd)) { best = b2; bd = d2; } };
+                mergeb(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0xB1, 0xF, 0xF, true)),
+                       __builtin_amdgcn_update_dpp(0, bd, 0xB1, 0xF, 0xF, true));
+                mergeb(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0x4E, 0xF, 0xF, true)),
+                       __builtin_amdgcn_update_dpp(0, bd, 0x4E, 0xF, 0xF, true));
+                mergeb(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0x141, 0xF, 0xF, true)),
+                       __builtin_amdgcn_update_dpp(0, bd, 0x141, 0xF, 0xF, true));
+                mergeb(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0x140, 0xF, 0xF, true)),
+                       __builtin_amdgcn_update_dpp(0, bd, 0x140, 0xF, 0xF, true));
+                if (l16 == 0 && live) { cur[j] = best + Mt[j]; carg[j] = (best == NEG_INF) ? -1 : (j - bd); }
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < L; j += DP_THREADS) {               // coalesced row store
+            O[(size_t)t * L + j] = cur[j];
+            if (MODE == 1) Tr[(size_t)t * L + j] = carg[j];
+        }
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
+    }
+}
+
+static std::mutex g_in_mutex;
+static std::unordered_map<unsigned long long, std::pair<void*, size_t>> g_in;
+
+static const float* incoming_links(const float* links, int B, int L, int TR, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_in_mutex);
+    int dev = 0; (void)hipGetDevice(&dev);
+    const unsigned long long key = ((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st;
+    auto& e = g_in[key];
+    const size_t need = (size_t)B * L * TR * sizeof(float);
+    if (e.second < need) {
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr; e.second = 0;
+        if (hipMalloc(&e.first, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e.second = need;
+    }
+    int gx = (TR + 255) / 256; if (gx > 8) gx = 8;
+    hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx, L, B), dim3(256), 0, st, links, (float*)e.first, L, TR);
+    return (const float*)e.first;
+}
+
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st)
 {
     const size_t lds2 = (size_t)L * sizeof(int32_t);
@@ -204,8 +399,19 @@ int launch_dag_fwd_generic(const float* match, const float* links, const int64_t
     if (lds > 160 * 1024) { set_error("dag_loss: graph size L=%d exceeds the generic kernel's LDS rows (max 20480)", L); return DSP_EINVAL; }
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_logsum_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int ndir = (alpha && beta) ? 2 : 1;
-    hipLaunchKernelGGL(dag_logsum_generic_kernel, dim3(B, ndir), dim3(DP_THREADS), lds, st, match, links, out_len, tgt_len,
-                       alpha, beta, B, T, L, TR);
+    if (TR > 64) {                                       // dense window: wave-per-column kernel
+        const float* in = alpha ? incoming_links(links, B, L, TR, st) : links;
+        if (in) {
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
+                               alpha, beta, (int32_t*)nullptr, B, T, L, TR);
+            return check_launch("dag_loss_fwd(dense)");
+        }
+    }
+    long sR, sD, sB;
+    const float* lk = transposed_links(links, B, L, TR, st, &sR, &sD, &sB);
+    hipLaunchKernelGGL(dag_logsum_generic_kernel, dim3(B, ndir), dim3(DP_THREADS), lds, st, match, lk, out_len, tgt_len,
+                       alpha, beta, B, T, L, TR, sR, sD, sB);
     return check_launch("dag_loss_fwd(generic)");
 }
 
@@ -222,8 +428,22 @@ int launch_best_alignment_generic(const float* match, const float* links, const 
     const size_t lds = 2 * (size_t)L * sizeof(float);
     if (lds > 160 * 1024) { set_error("dag_best_alignment: graph size L=%d too large (max 20480)", L); return DSP_EINVAL; }
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_maxalpha_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dag_maxalpha_generic_kernel, dim3(B), dim3(DP_THREADS), lds, st, match, links, out_len, tgt_len,
-                       alpha, trace, B, T, L, TR);
+    if (TR > 64) {
+        const float* in = incoming_links(links, B, L, TR, st);
+        const size_t lds3 = 3 * (size_t)L * sizeof(float);
+        if (in && lds3 <= 160 * 1024) {
+            if (lds3 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL(dag_dense_kernel<1>, dim3(B, 1), dim3(DP_THREADS), lds3, st, match, links, in, out_len, tgt_len,
+                               alpha, (float*)nullptr, trace, B, T, L, TR);
+            int rc2 = check_launch("dag_best_alignment(dense)");
+            if (rc2) return rc2;
+            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+        }
+    }
+    long sR, sD, sB;
+    const float* lk = transposed_links(links, B, L, TR, st, &sR, &sD, &sB);
+    hipLaunchKernelGGL(dag_maxalpha_generic_kernel, dim3(B), dim3(DP_THREADS), lds, st, match, lk, out_len, tgt_len,
+                       alpha, trace, B, T, L, TR, sR, sD, sB);
     int rc = check_launch("dag_best_alignment(max-alpha)");
     if (rc) return rc;
     return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);

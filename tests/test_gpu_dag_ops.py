@@ -106,6 +106,8 @@ SHAPES = [
     (2, 30, 1500, 32),     # banded fast path, 3 strips, full window
     (3, 25, 1031, 7),      # odd L (scalar store path), odd TR
     (2, 70, 2048, 32),     # strip boundary exactly at L
+    (3, 30, 300, 299),     # dense window TR = L-1 at a realistic graph size (wave-per-column kernels)
+    (2, 17, 200, 130),     # dense window, TR < L-1
 ]
 
 
