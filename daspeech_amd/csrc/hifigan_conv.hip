@@ -13,6 +13,7 @@
 //     that wave's time tiles);
 //   * mfma_f32_16x16x32_f16, fp32 accumulate; 8 waves as WM (channel) x WN (time) sub-tiles.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/daspeech_hifigan.h"
 
 namespace dsp {
@@ -26,6 +27,7 @@ struct HgParams {
     float pre_slope, scale;
     int shifts[DSP_HG_MAX_TAPS];
     int min_shift, max_shift;
+    int dbg;                      // ablation bits (HG_ABLATE env, timing experiments only): 1 no staging loads, 2 no MFMA loop, 4 no epilogue
 };
 
 template <int CI>
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
         const int row = e / CH, ch = e - row * CH;
         const int tg = t0 + p.min_shift + row;
         h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (tg >= 0 && tg < p.T) {
+        if (tg >= 0 && tg < p.T && !(p.dbg & 1)) {
             v = *reinterpret_cast<const h8*>(X + (size_t)tg * CI + ch * 8);
             if (p.pre_slope != 1.0f) {
 #pragma unroll
@@ -78,61 +80,91 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     const int co_base = m0 + wm * (MI * 16);
     const int tl_base = wn * (NI * 16);
     const int lr = lane & 15, lk = lane >> 4;
-    for (int k = 0; k < p.ntaps; ++k) {
+    // flattened (tap, 32-channel chunk) loop; 3-deep register ring of weight fragments (static indices: unrolled by 3) so the
+    // L2 latency of the weight stream is covered by two steps of MFMAs
+    constexpr int NC = CI / 32;
+    const int nsteps = (p.dbg & 2) ? 0 : p.ntaps * NC;
+    auto load_a = [&](int step, h8 (&a)[MI]) {
+        const int k = step / NC, c = step - k * NC;
         const _Float16* Wk = p.w + (size_t)k * p.M * CI;
-        const int rshift = p.shifts[k] - p.min_shift;
-#pragma unroll 2
-        for (int c = 0; c < CI / 32; ++c) {
-            h8 a[MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int co = co_base + i * 16 + lr;
-                a[i] = (co < p.M) ? *reinterpret_cast<const h8*>(Wk + (size_t)co * CI + c * 32 + lk * 8) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int row = tl_base + j * 16 + lr + rshift;
-                const h8 bf = *reinterpret_cast<const h8*>(smem + ((size_t)row * CH + hg_swz<CI>(row, c * 4 + lk)) * 16);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf, acc[i][j], 0, 0, 0);
-            }
+        for (int i = 0; i < MI; ++i) {
+            const int co = co_base + i * 16 + lr;
+            a[i] = (co < p.M) ? *reinterpret_cast<const h8*>(Wk + (size_t)co * CI + c * 32 + lk * 8) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
         }
-    }
-
-    // ---- epilogue: D fragment = 4 consecutive output rows (channels) x one column (time) per lane ----
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mrow = co_base + i * 16 + lk * 4;         // first of this lane's 4 M rows
-        if (mrow >= p.M) continue;
+    };
+    h8 a0[MI], a1[MI], a2[MI];
+    if (nsteps > 0) load_a(0, a0);
+    if (nsteps > 1) load_a(1, a1);
+    auto do_step = [&](int step, const h8 (&a)[MI]) {
+        const int k = step / NC, c = step - k * NC;
+        const int rshift = p.shifts[k] - p.min_shift;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int q = t0 + tl_base + j * 16 + lr;
-            int tout, co;
-            if (p.out_mode == DSP_HG_OUT_UPSAMPLE) {
-                const int r = mrow / p.Cout;                 // 4 consecutive rows share the phase (Cout multiple of 4)
-                co = mrow - r * p.Cout;
-                tout = q * p.up_u + r - p.up_pad;
-            } else { co = mrow; tout = q; }
-            if (tout < 0 || tout >= p.Tout) continue;
-            const size_t o = ((size_t)b * p.Tout + tout) * p.Cout + co;
-            float v[4];
+            const int row = tl_base + j * 16 + lr + rshift;
+            const h8 bf = *reinterpret_cast<const h8*>(smem + ((size_t)row * CH + hg_swz<CI>(row, c * 4 + lk)) * 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + (p.bias ? p.bias[co + e] : 0.f);
-            if (p.res) {
-                const _Float16* rp = p.res + o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
-            }
-            _Float16 hv[4];
-            if (p.out_mode == DSP_HG_OUT_ACCUM) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)((float)p.out[o + e] + p.scale * v[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(p.scale * v[e]);
-            }
-            *reinterpret_cast<uint2*>(p.out + o) = *reinterpret_cast<uint2*>(hv);
+            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf, acc[i][j], 0, 0, 0);
         }
+    };
+    for (int step = 0; step < nsteps; step += 3) {
+        if (step + 2 < nsteps) load_a(step + 2, a2);
+        do_step(step, a0);
+        if (step + 1 < nsteps) {
+            if (step + 3 < nsteps) load_a(step + 3, a0);
+            do_step(step + 1, a1);
+        }
+        if (step + 2 < nsteps) {
+            if (step + 4 < nsteps) load_a(step + 4, a1);
+            do_step(step + 2, a2);
+        }
+    }
+    if (p.dbg & 4) return;
+
+    // ---- epilogue through LDS: the D fragments (4 channels x 1 time step per lane) are transposed into a [NT][MT] fp16 tile
+    //      so that global memory sees 16-byte, row-contiguous accesses for the residual / accumulate loads and the stores
+    //      (fragment-shaped 8-byte stores at a row stride cost as much as the whole MFMA loop: 6.1 of 15.8 ms, ablation r01) ----
+    constexpr int OPITCH = MT + 8;                    // halfs; +16 bytes per row de-conflicts the transposing ds_write_b64
+    __syncthreads();                                  // all waves are done reading the input tile
+    _Float16* otile = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = wm * (MI * 16) + i * 16 + lk * 4;          // row inside the M tile
+        const int mrow = m0 + ml;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && mrow < p.M) {
+            const int co = (p.out_mode == DSP_HG_OUT_UPSAMPLE) ? (mrow % p.Cout) : mrow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = p.bias[co + e];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int tl = tl_base + j * 16 + lr;
+            _Float16 hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[i][j][e] + bv[e]);
+            *reinterpret_cast<uint2*>(otile + (size_t)tl * OPITCH + ml) = *reinterpret_cast<uint2*>(hv);
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = MT / 8;                       // 16-byte chunks per tile row
+    for (int e = tid; e < NT * CPR; e += 512) {
+        const int tl = e / CPR, ch = e - tl * CPR;
+        const int mrow = m0 + ch * 8;
+        if (mrow >= p.M) continue;
+        const int q = t0 + tl;
+        int tout = q, co = mrow;
+        if (p.out_mode == DSP_HG_OUT_UPSAMPLE) { const int r = mrow / p.Cout; co = mrow - r * p.Cout; tout = q * p.up_u + r - p.up_pad; }
+        if (tout < 0 || tout >= p.Tout) continue;
+        const size_t o = ((size_t)b * p.Tout + tout) * p.Cout + co;
+        const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
+        h8 r8 = {0, 0, 0, 0, 0, 0, 0, 0}, a8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.res) r8 = *reinterpret_cast<const h8*>(p.res + o);
+        if (p.out_mode == DSP_HG_OUT_ACCUM) a8 = *reinterpret_cast<const h8*>(p.out + o);
+        h8 w8;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[x]) + (float)a8[x]);
+        *reinterpret_cast<h8*>(p.out + o) = w8;
     }
 }
 
@@ -140,7 +172,9 @@ template <int CI, int MT, int NT, int WM, int WN>
 static int hg_launch(const HgParams& p, hipStream_t st)
 {
     const int R = NT + (p.max_shift - p.min_shift);
-    const size_t lds = (size_t)R * CI * 2;
+    size_t lds = (size_t)R * CI * 2;
+    const size_t lds_out = (size_t)NT * (MT + 8) * 2;
+    if (lds_out > lds) lds = lds_out;
     if (lds > 160 * 1024) { set_error("hifigan_conv: input tile %zu bytes exceeds LDS", lds); return DSP_EINVAL; }
     auto k = hifigan_conv_kernel<CI, MT, NT, WM, WN>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -200,6 +234,7 @@ extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias,
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.res = (const _Float16*)res; p.out = (_Float16*)out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.Tout = Tout; p.Cout = Cout; p.out_mode = out_mode; p.up_u = up_u; p.up_pad = up_pad;
     p.pre_slope = pre_slope; p.scale = scale;
+    { const char* ab = getenv("HG_ABLATE"); p.dbg = ab ? atoi(ab) : 0; }
     p.min_shift = p.max_shift = host_shifts[0];
     for (int k = 0; k < ntaps; ++k) { p.shifts[k] = host_shifts[k]; p.min_shift = min(p.min_shift, host_shifts[k]); p.max_shift = max(p.max_shift, host_shifts[k]); }
     hipStream_t st = as_stream(stream);
