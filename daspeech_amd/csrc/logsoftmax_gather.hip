@@ -180,6 +180,18 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
         for (int r = 0; r < nr; ++r) {
             T* row = x + ((size_t)b * L + (j0 + r)) * V;
             if (r + 1 < nr) load_row(r + 1, nxt);
+            // the S gathered logits of this row are requested NOW (independent of max / sum): their L2 / fabric latency
+            // overlaps the reduction instead of following it (2 per lane for S = 512; S <= 8*256 on this path)
+            float graw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = tid + u * 256;
+                if (k < S) {
+                    int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+                    graw[u] = to_f(row[t]);
+                }
+            }
             float f[NV][N];
             float m = NEG_INF;
 #pragma unroll
@@ -208,10 +220,10 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
 #pragma unroll
             for (int w = 1; w < 4; ++w) online_merge(m, s, red[w], red[8 + w]);
             const float ls = __logf(s);
-            for (int k = tid; k < S; k += 256) {
-                int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
-                t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-                stage[k * RT + r] = (to_f(row[t]) - m) - ls;            // L2-hot re-read of single elements
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = tid + u * 256;
+                if (k < S) stage[k * RT + r] = (graw[u] - m) - ls;
             }
             if (write_softmax) {
                 __syncthreads();                                          // gathers read the ORIGINAL logits
@@ -318,7 +330,7 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     // register-resident variant when the row fits NV x 256 sixteen-byte vectors
     const int nvec = (V + 256 * N - 1) / (256 * N);
-    if (vec && nvec <= 8) {
+    if (vec && nvec <= 8 && S <= 8 * 256) {
         auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : lsg_fwd_reg_kernel<T, 8>);
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kr, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
