@@ -13,6 +13,7 @@
 //     RT-float contiguous runs instead of 4-byte scatters — the reference wrote [B,L,S] and paid a transpose copy
 //     (nat_dag_loss.py:128 + dag_loss.py:103).
 #include "common.h"
+#include <stdlib.h>
 
 namespace dsp {
 
@@ -332,9 +333,15 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
     const int nvec = (V + 256 * N - 1) / (256 * N);
     if (vec && nvec <= 8 && S <= 8 * 256) {
         auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : lsg_fwd_reg_kernel<T, 8>);
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kr, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
-                           B, L, V, S, RT, ws);
+        int RTr = RT, gridr = grid;
+        // storing the softmax makes the launch a 1:1 read/write stream: two resident workgroups per CU (64 KB of stage per
+        // workgroup at RT = 32) sustain 4.9 TB/s, four only 4.1 TB/s (sweep in tools/k1_bench.py, r01)
+        if (ws && (size_t)S * 32 * 4 <= 96 * 1024 && L >= 32) { RTr = 32; const long nt = (long)B * ((L + 31) / 32); gridr = (int)(nt < 4096 ? nt : 4096); }
+        if (getenv("DSP_K1_RT")) { RTr = atoi(getenv("DSP_K1_RT")); const long nt = (long)B * ((L + RTr - 1) / RTr); gridr = (int)(nt < 65535 * 4 ? nt : 65535 * 4); if (getenv("DSP_K1_GRID")) gridr = atoi(getenv("DSP_K1_GRID")); }
+        const size_t ldsr = (16 + (size_t)S * RTr) * sizeof(float);
+        if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+        hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
+                           B, L, V, S, RTr, ws);
         return check_launch("logsoftmax_gather(reg)");
     }
     auto k = vec ? lsg_fwd_kernel<T, true> : lsg_fwd_kernel<T, false>;
@@ -350,8 +357,9 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
 {
     constexpr int N = Vec<T>::N;
     const bool vec = (V % N == 0) && ((uintptr_t)sm % 16 == 0);
-    const size_t lds = (16 + (size_t)V) * sizeof(float);
+    size_t lds = (16 + (size_t)V) * sizeof(float);
     if (lds > 160 * 1024) { set_error("logsoftmax_gather_bwd: V=%d exceeds the LDS row image (max ~40k)", V); return DSP_EINVAL; }
+    if (getenv("DSP_K1B_LDS")) { const size_t want = (size_t)atoi(getenv("DSP_K1B_LDS")); if (want > lds) lds = want; }
     const long nrows = (long)B * L;
     const int grid = (int)(nrows < 2048 ? nrows : 2048);
     auto k = vec ? lsg_bwd_kernel<T, true> : lsg_bwd_kernel<T, false>;
