@@ -160,3 +160,70 @@ def length_regulate(x: Tensor, durations: Tensor) -> Tuple[Tensor, Tensor]:
             _lib.check(lib.dsp_length_regulator_expand(_lib.ptr(xx), _code(xx), _lib.ptr(cum), _lib.ptr(out), B, N, C, maxlen,
                                                        _lib.current_stream_handle()), "dsp_length_regulator_expand")
     return out, lens
+
+
+def restore_valid_links(links: Tensor) -> Tensor:
+    """compact [B,L,TR] -> dense [B,L,L] with -inf elsewhere (s2t_conformer_dag.py:157-169); only the Viterbi strategies need
+    it — lookahead / greedy run on the compact layout."""
+    B, L, TR = links.shape
+    idx = torch.arange(L, device=links.device).unsqueeze(1) + torch.arange(TR, device=links.device).unsqueeze(0) + 1
+    idx = idx.masked_fill(idx >= L, L)
+    res = torch.full((B, L, L + 1), float("-inf"), dtype=torch.float, device=links.device)
+    res.scatter_(2, idx.unsqueeze(0).expand(B, -1, -1), links.float())
+    return res[:, :, :L]
+
+
+@torch.no_grad()
+def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_length: Tensor, pad: int, decode_beta: float = 1.0,
+                   decode_viterbibeta: float = 1.0, joint: bool = True, src_upsample_scale: float = 0.5):
+    """`viterbi` / `jointviterbi` strategies of forward_decoder (s2s_conformer_dag_fastspeech2.py:244-304), batched on the GPU:
+    max_length = int(L / 8 / scale) max-product steps over the dense links, length-normalised best end, back-trace by batched
+    gathers (the reference back-traces per sample on the host).  Returns like graph_decode."""
+    B, L, V = logits.shape
+    dense = restore_valid_links(links)
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    sc, tok = logp.max(dim=-1)                                           # unreduced_logits / unreduced_tokens (:207-208)
+    alpha = dense[:, 0].clone()                                          # (:248) — the reference aliases links[:,0]; harmless
+    if joint:
+        alpha = alpha + sc[:, 0].unsqueeze(1) * decode_beta              # (:249-250)
+    alpha = alpha + sc * decode_beta                                     # (:252) applied for both strategies
+    max_length = max(1, int(L / 8 / src_upsample_scale))                 # (:256)
+    scores, indexs = [alpha], []
+    for _ in range(max_length - 1):
+        alpha, index = torch.max(alpha.unsqueeze(-1) + dense, dim=1)     # (:258)
+        if joint:
+            alpha = alpha + sc * decode_beta
+        scores.append(alpha); indexs.append(index)
+    scores = torch.stack(scores, 0)                                      # [M,B,L]
+    ar = torch.arange(B, device=logits.device)
+    link_last = dense[ar, :, (output_length - 1)].unsqueeze(0)           # link of every vertex into the final vertex (:267)
+    best, max_idx = torch.max(scores + link_last, dim=-1)                # [M,B]
+    lengths = (torch.arange(max_length, device=logits.device) + 1).unsqueeze(-1).float()
+    _, pred_length = torch.max(best / lengths ** decode_viterbibeta, dim=0)
+    pred_length = pred_length + 1                                        # (:275-276)
+    j = max_idx.gather(0, (pred_length - 1).unsqueeze(0)).squeeze(0)     # end vertex per sample (:278)
+    # batched back-trace: path[b, k] = k-th vertex from the END
+    path = torch.full((B, max_length), -1, dtype=torch.long, device=logits.device)
+    path[:, 0] = j
+    if indexs:
+        idx_all = torch.stack(indexs, 0)                                 # [M-1,B,L]
+        for k in range(max_length - 1):
+            step = pred_length - k - 2                                   # (:287) indexs[length-k-2]
+            live = step >= 0
+            nj = idx_all[step.clamp(min=0), ar, j]
+            j = torch.where(live, nj, j)
+            path[:, k + 1] = torch.where(live, j, torch.full_like(j, -1))
+    valid = path >= 0
+    ptok = tok.gather(1, path.clamp(min=0))
+    nxt_tok = torch.cat([torch.full((B, 1), -12345, device=ptok.device, dtype=ptok.dtype), ptok[:, :-1]], dim=1)   # token visited just before (backward order)
+    keep = valid & ((torch.arange(max_length, device=ptok.device).unsqueeze(0) == 0) | ((ptok != pad) & (ptok != nxt_tok)))
+    n_keep = keep.sum(1)
+    fmax = int(n_keep.max().item())
+    # forward order = reversed backward order; compact the kept entries to the left
+    order = torch.argsort((~keep.flip(1)).to(torch.int8), dim=1, stable=True)
+    fwd_path = path.flip(1).gather(1, order)[:, :fmax]
+    fwd_tok = ptok.flip(1).gather(1, order)[:, :fmax]
+    mask = torch.arange(fmax, device=ptok.device).unsqueeze(0) >= n_keep.unsqueeze(1)
+    out_tok = fwd_tok.masked_fill(mask, pad)
+    out_feat = features.gather(1, fwd_path.clamp(min=0).unsqueeze(-1).expand(-1, -1, features.shape[-1])).masked_fill(mask.unsqueeze(-1), 0)
+    return out_tok, out_feat, mask, n_keep

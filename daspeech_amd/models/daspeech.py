@@ -28,7 +28,7 @@ DEFAULT_ARGS = dict(
     encoder_layers=12, encoder_embed_dim=256, encoder_ffn_embed_dim=2048, encoder_attention_heads=4, depthwise_kernel=31,
     decoder_layers=4, decoder_embed_dim=512, decoder_ffn_embed_dim=2048, decoder_attention_heads=8,
     vocab_size=512, max_target_positions=1024, src_upsample_scale=0.5, max_transition_length=99999,
-    decode_strategy="lookahead", decode_beta=1.0, adaptor_ffn_dim=1024,
+    decode_strategy="lookahead", decode_beta=1.0, decode_viterbibeta=1.0, adaptor_ffn_dim=1024,
 )
 
 
@@ -302,9 +302,15 @@ class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
 
     @torch.no_grad()
     def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]):
-        """Lookahead / greedy graph decode on the GPU (s2s_conformer_dag_fastspeech2.py:194-243)."""
+        """Graph decode on the GPU: lookahead / greedy (s2s_conformer_dag_fastspeech2.py:194-243) through the HIP decode ops, viterbi /
+        jointviterbi (:244-304) batched in torch on the restored dense links."""
         logits, links, feats = self.decode_graph(prev_output_tokens, enc)
         out_len = prev_output_tokens.ne(self.pad).sum(-1)
+        if self.args.decode_strategy in ("viterbi", "jointviterbi"):
+            toks, ofeat, mask, lens = decode_ops.viterbi_decode(
+                logits, links, feats, out_len, self.pad, self.args.decode_beta, getattr(self.args, "decode_viterbibeta", 1.0),
+                self.args.decode_strategy == "jointviterbi", self.args.src_upsample_scale)
+            return {"output_tokens": toks, "features": ofeat, "features_padding_mask": mask, "feature_lengths": lens}
         toks, ofeat, mask, lens = decode_ops.graph_decode(logits, links, feats, out_len, self.pad, self.args.decode_beta,
                                                           self.args.decode_strategy)
         return {"output_tokens": toks, "features": ofeat, "features_padding_mask": mask, "feature_lengths": lens}

@@ -64,3 +64,61 @@ def test_logsumexp_keepdim(golden_dir):
     y = logsumexp_keepdim(torch.from_numpy(g["x"]), 1)
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-6)
     assert np.isneginf(y.numpy()[0, 0, 1])
+
+
+def _viterbi_reference_loop(logits, dense, feats, out_len, pad, beta, vbeta, joint, scale):
+    """Per-sample restatement of s2s_conformer_dag_fastspeech2.py:244-304 with Python loops (host back-trace like the reference)."""
+    B, L, V = logits.shape
+    logp = torch.log_softmax(logits, -1)
+    sc, tok = logp.max(-1)
+    alpha = dense[:, 0].clone()
+    if joint:
+        alpha = alpha + sc[:, 0].unsqueeze(1) * beta
+    alpha = alpha + sc * beta
+    M = max(1, int(L / 8 / scale))
+    scores, indexs = [alpha], []
+    for _ in range(M - 1):
+        alpha, index = torch.max(alpha.unsqueeze(-1) + dense, dim=1)
+        if joint:
+            alpha = alpha + sc * beta
+        scores.append(alpha); indexs.append(index)
+    scores = torch.stack(scores, 0)
+    link_last = torch.stack([dense[b, :, out_len[b] - 1] for b in range(B)], 0).unsqueeze(0)
+    best, max_idx = torch.max(scores + link_last, dim=-1)
+    lengths = (torch.arange(M) + 1).unsqueeze(-1).float()
+    _, pred = torch.max(best / lengths ** vbeta, dim=0)
+    pred = pred + 1
+    outs = []
+    for b in range(B):
+        length = int(pred[b]); j = int(max_idx[length - 1, b])
+        last = int(tok[b, j]); res = [last]; fl = [feats[b, j]]
+        for k in range(length - 1):
+            j = int(indexs[length - k - 2][b, j]); now = int(tok[b, j])
+            if now != pad and now != last:
+                res.insert(0, now); fl.insert(0, feats[b, j])
+            last = now
+        outs.append((res, torch.stack(fl)))
+    return outs
+
+
+@pytest.mark.parametrize("joint", [True, False])
+def test_viterbi_decode_matches_loop_restatement(joint):
+    from daspeech_amd import decode_ops
+    torch.manual_seed(5)
+    B, L, TR, V, D, pad = 3, 40, 6, 11, 4, 1
+    logits = torch.randn(B, L, V) * 2
+    logits[:, ::4, pad] += 6                                   # some <pad> emissions
+    raw = torch.randn(B, L, TR)
+    out_len = torch.tensor([40, 37, 33])
+    i = torch.arange(L).view(1, L, 1); d = torch.arange(TR).view(1, 1, TR)
+    valid = (i + d + 1) < out_len.view(B, 1, 1)
+    links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1)
+    links = links.masked_fill(~valid, float("-inf"))
+    feats = torch.randn(B, L, D)
+    toks, of, mask, n = decode_ops.viterbi_decode(logits, links, feats, out_len, pad, 1.0, 1.0, joint, 0.5)
+    ref = _viterbi_reference_loop(logits, decode_ops.restore_valid_links(links), feats, out_len.tolist(), pad, 1.0, 1.0, joint, 0.5)
+    for b, (res, fl) in enumerate(ref):
+        assert n[b].item() == len(res)
+        assert toks[b, : len(res)].tolist() == res and (toks[b, len(res):] == pad).all()
+        torch.testing.assert_close(of[b, : len(res)], fl)
+        assert (of[b, len(res):] == 0).all() and mask[b].tolist() == [False] * len(res) + [True] * (toks.shape[1] - len(res))
