@@ -34,7 +34,7 @@ struct StripParams {
 
 constexpr int S2_RING = 8;
 constexpr int S2_PD = 6;                      // prefetch distance (rows) of the loader wave
-constexpr int S2_NEGSENT = -100000;
+constexpr int S2_NEGSENT = -(1 << 30);     // "dead" exponent; far below any finite fp32 score
 constexpr u32 S2_SPIN_LIMIT = 1u << 22;
 constexpr float S2_LOG2E = 1.4426950408889634f;
 constexpr float S2_LN2 = 0.6931471805599453f;

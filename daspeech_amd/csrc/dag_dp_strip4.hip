@@ -42,7 +42,7 @@ struct StripParams {
 constexpr int S4_TRP = 32;
 constexpr int S4_RING = 8;
 constexpr int S4_CH = 8;                      // halo chunk (rows per memory round trip of the fetch wave)
-constexpr int NEGSENT = -100000;
+constexpr int NEGSENT = -(1 << 30);        // "dead" exponent; far below any finite fp32 score
 constexpr u32 S4_SPIN_LIMIT = 1u << 22;
 constexpr float S4_LOG2E = 1.4426950408889634f;
 constexpr float S4_LN2 = 0.6931471805599453f;

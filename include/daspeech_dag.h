@@ -94,8 +94,9 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family: 0 = auto, 1 = generic row-sequential, 2 = banded
- *   2-column log-space strips, 3 = strip4 (exp-space, wave-specialised); used by tests to cross-check the families.  dsp_dag_last_launch_status copies the device-side status word of the last
- *   fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
+ *   2-column log-space strips, 3 = strip4 (exp-space, per-vertex exponents), 4 = strip2 (2 vertices per lane), 5 = strip4g
+ *   (exp-space, one exponent per lane group; the auto choice for the log-sum DP); used by tests to cross-check the families.
+ *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_set_option(const char* name, int value);
 int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);

@@ -275,7 +275,7 @@ def test_fast_paths_match_generic_kernels(shape):
     m.requires_grad_()
     res = {}
     try:
-        for path in (1, 2, 3, 4):
+        for path in (1, 2, 3, 4, 5):
             _lib.set_option("dp_path", path)
             loss, (a, b) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
@@ -286,7 +286,7 @@ def test_fast_paths_match_generic_kernels(shape):
         _lib.set_option("dp_path", 0)
     _, a_g, b_g, p_g = res[1]
     fa = torch.isfinite(a_g); fb = torch.isfinite(b_g)
-    for path in (2, 3, 4):
+    for path in (2, 3, 4, 5):
         _, a_f, b_f, p_f = res[path]
         assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)), path
         assert torch.equal(torch.isneginf(b_f), torch.isneginf(b_g)), path
@@ -309,7 +309,7 @@ def test_strip4_exactness_guard():
     m.requires_grad_()
     try:
         res = {}
-        for path in (3, 4):
+        for path in (3, 4, 5):
             _lib.set_option("dp_path", path)
             loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
@@ -324,6 +324,35 @@ def test_strip4_exactness_guard():
         fa = np.isfinite(a64); fb = np.isfinite(b64)
         np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
         np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("slope", [2.0, 12.0, 40.0])
+def test_exp_space_paths_on_peaked_scores(slope):
+    """Sharply peaked emissions (a trained model: the score falls `slope` nats per vertex away from the aligned position) give
+    DP rows whose neighbouring vertices differ by tens of binades — the regime where the exp-space kernels' shared exponents
+    run out of range and the escape / medium / exact paths take over.  Must match the fp64 oracle."""
+    from daspeech_amd import _lib
+    B, T, L, TR = 2, 40, 1024, 32
+    match, links, ol, tl = make_dag_inputs(123, B, T, L, TR, ragged=True)
+    jj = np.arange(L, dtype=np.float32)[None, None, :]
+    centre = (np.arange(T, dtype=np.float32) * (L - 1) / (T - 1))[None, :, None]
+    match = (match * 0.1 - slope * np.abs(jj - centre)).astype(np.float32)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_()
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    try:
+        for path in (3, 5):
+            _lib.set_option("dp_path", path)
+            loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+            assert _lib.last_launch_status() == 0
+            a, b = alpha.cpu().numpy(), beta.cpu().numpy()
+            assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), path
+            fa = np.isfinite(a64); fb = np.isfinite(b64)
+            np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
+            np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
+    finally:
+        _lib.set_option("dp_path", 0)
 
 
 def test_banded_repeated_launches_reuse_workspace():

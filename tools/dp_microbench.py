@@ -31,6 +31,13 @@ def timeit(fn, n=5, w=2):
     return min(es), sum(es) / len(es)
 
 
+def dbg_cells():
+    import struct
+    w = _lib.load().dsp_dag_debug_words()
+    n = min(14, max(int(w[1]), int(w[2])))
+    return [(int(w[7 + 4 * i]), int(w[8 + 4 * i]), int(w[9 + 4 * i]), struct.unpack('f', struct.pack('I', w[10 + 4 * i]))[0]) for i in range(n)]
+
+
 def main():
     B, T, L, TR = [int(v) for v in sys.argv[1:5]]
     paths = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [3]
@@ -42,8 +49,8 @@ def main():
         with torch.no_grad():
             a = timeit(lambda: ops.dag_loss(m, k, ol, tl))
             v = timeit(lambda: ops.dag_best_alignment(m, k, ol, tl))
-        with torch.no_grad(): ops.dag_loss(m, k, ol, tl)
-        st = (_lib.last_launch_status(), _lib.last_fallback_count(), _lib.debug_fallback_cells()[:8], ol[:4].tolist(), tl[:4].tolist())
+        ops.dag_loss(mg, k, ol, tl)
+        st = (_lib.last_launch_status(), _lib.last_fallback_count(), int(_lib.load().dsp_dag_debug_words()[2]), dbg_cells(), ol[:4].tolist(), tl[:4].tolist())
         gb = 2 * (B * T * L * 4 * 2 + B * L * TR * 4) / 1e9
         print(f"path {path} B={B} T={T} L={L} TR={TR}: fwd(a+b) min {f[0]:.3f} ms ({gb / f[0] * 1e3:.0f} GB/s) | alpha-only {a[0]:.3f} ms | align {v[0]:.3f} ms | status {st}")
     _lib.set_option("dp_path", 0)
