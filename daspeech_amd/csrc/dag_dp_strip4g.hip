@@ -48,7 +48,7 @@ __device__ __forceinline__ void g4_gran_store(u64* p, u32 tag, float v) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // DSP_DEBUG=prof: per-wave cycle accounting (s_memtime) of own work / barrier wait / LDS-read wait, for two workgroups
-struct G4Prof { u64 last, work, wait, rd; };
+struct G4Prof { u64 last, work, wait, rd, fma, tmid; };
 template <bool PROF>
 __device__ __forceinline__ void g4_barrier(G4Prof& pf) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -70,7 +70,7 @@ template <bool BETA> __device__ __forceinline__ constexpr int gqidx(int c, int d
 template <int NT, int MODE, bool BETA, bool PROF>
 __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_raw, int b, int s, int dirslot, int so, int profslot)
 {
-    G4Prof pf; pf.last = PROF ? __builtin_amdgcn_s_memtime() : 0; pf.work = pf.wait = pf.rd = 0;
+    G4Prof pf; pf.last = PROF ? __builtin_amdgcn_s_memtime() : 0; pf.work = pf.wait = pf.rd = pf.fma = pf.tmid = 0;
     if (PROF && profslot >= 0 && threadIdx.x == 0) p.counters[50 + profslot * 3] = (u32)__builtin_amdgcn_s_memrealtime();
     constexpr int W = 4 * NT, RL = W + 32, GL = NT + 8, NCW = NT / 64, DPR = W / 256;
     float* Abuf = reinterpret_cast<float*>(smem_raw);          // [2][RL]  a2 = alpha * log2(e)  (exact row, log2 domain)
@@ -128,10 +128,10 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
         const bool col_ok = j < L;
         // structural reachability (cells outside are -inf in the reference too: their LSE runs over -inf terms only):
         // alpha: t <= col <= min(L_b-1, t*TR);  beta: col >= t, T_b-1-t <= L_b-1-col <= (T_b-1-t)*TR
-        auto cell_active = [&](int col, int t) -> bool {
-            if (col < t || col >= Lb) return false;
-            if (!BETA) return (long)col <= (long)t * TR;
-            return (long)(Lb - 1 - col) <= (long)(Tb - 1 - t) * TR && col + (Tb - 1 - t) <= Lb - 1;   // >= 1 vertex per remaining row
+        auto cell_active = [&](int col, int t) -> bool {       // (T * TR fits an int: T, L < 2^20 and TR <= 32)
+            if (!BETA) return col >= t && col < Lb && col <= t * TR;
+            const int rem = Tb - 1 - t, gap = Lb - 1 - col;       // rows left / vertices left: 1..TR vertices per row
+            return col >= t && gap >= rem && gap <= rem * TR;
         };
         float E[4][32];
         float lmax[4];
@@ -190,100 +190,121 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
         __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         g4_barrier<PROF>(pf);                            // prologue barrier: match row 0 is in the ring
 
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        typedef float v4f __attribute__((ext_vector_type(4)));
         for (int it = 0; it < nrows; ++it) {
             const int t = BETA ? (Tb - 1 - it) : it;
             const int cur = it & 1, prv = cur ^ 1;
             if (PROF && profslot >= 0 && tid == 0 && it == 64) p.counters[51 + profslot * 3] = (u32)__builtin_amdgcn_s_memrealtime();
-            const float4 mt = *reinterpret_cast<const float4*>(Mring + (size_t)(it % G4_RING) * W + 4 * l);
-            float m2[4] = {mt.x, mt.y, mt.z, mt.w};
             float a2[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
-            int arg[4] = {-1, -1, -1, -1};
+            float vn[4] = {0.f, 0.f, 0.f, 0.f};
+            int xn = GNEGSENT;
             if (it == 0) {
+                const float4 mt = *reinterpret_cast<const float4*>(Mring + (size_t)(it % G4_RING) * W + 4 * l);
+                const float m2[4] = {mt.x, mt.y, mt.z, mt.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const bool seed = BETA ? (j + c == Lb - 1) : (j + c == 0);
-                    if (seed) a2[c] = (MODE == 0) ? m2[c] * G4_LOG2E : m2[c];
+                    if (seed) a2[c] = m2[c] * G4_LOG2E;
                 }
-            } else if (MODE == 0) {
-                // nine group exponents and the 36-value window (li 4l .. 4l+35; groups l .. l+8)
-                // The 14 LDS reads of the row head as ONE issue group and one wait.  Left to the scheduler, the window reads are
-                // sunk between the FMA groups one or two at a time to save registers — with one compute wave per SIMD that
+            } else {
+                // ---- row head: all 15 LDS reads (match, nine group exponents, the 36-value window: li 4l .. 4l+35, groups
+                // l .. l+8) leave as ONE issue group; consumers wait with counted lgkmcnt (LDS returns in order, and this
+                // stretch issues no other LDS / scalar-memory operation).  Left to the scheduler the window reads are sunk
+                // between the FMA groups one or two at a time to save registers, which with one compute wave per SIMD
                 // exposes six LDS round trips per row.
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v2i x01, x23, x45, x67; int x8;
-                v4f pv[9];
+                v4f mt; v2i x01, x23, x45, x67; int x8; v4f pv[9];
                 {
+                    const u32 maddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Mring + (size_t)(it % G4_RING) * W + 4 * l);
                     const u32 xaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Xbuf + prv * GL + l);
                     const u32 vaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Vbuf + prv * RL + 4 * l);
-                    asm volatile(
-                        "ds_read2_b32 %0, %14 offset1:1\n\t"
-                        "ds_read2_b32 %1, %14 offset0:2 offset1:3\n\t"
-                        "ds_read2_b32 %2, %14 offset0:4 offset1:5\n\t"
-                        "ds_read2_b32 %3, %14 offset0:6 offset1:7\n\t"
-                        "ds_read_b32 %4, %14 offset:32\n\t"
-                        "ds_read_b128 %5, %15\n\t"
-                        "ds_read_b128 %6, %15 offset:16\n\t"
-                        "ds_read_b128 %7, %15 offset:32\n\t"
-                        "ds_read_b128 %8, %15 offset:48\n\t"
-                        "ds_read_b128 %9, %15 offset:64\n\t"
-                        "ds_read_b128 %10, %15 offset:80\n\t"
-                        "ds_read_b128 %11, %15 offset:96\n\t"
-                        "ds_read_b128 %12, %15 offset:112\n\t"
-                        "ds_read_b128 %13, %15 offset:128\n\t"
-                        "s_waitcnt lgkmcnt(0)"
-                        : "=&v"(x01), "=&v"(x23), "=&v"(x45), "=&v"(x67), "=&v"(x8),
-                          "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]),
-                          "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8])
-                        : "v"(xaddr), "v"(vaddr)
-                        : "memory");
+#define G4_ROW_HEAD_READS \
+                        "ds_read_b128 %0, %15\n\t" \
+                        "ds_read2_b32 %1, %16 offset1:1\n\t" \
+                        "ds_read2_b32 %2, %16 offset0:2 offset1:3\n\t" \
+                        "ds_read2_b32 %3, %16 offset0:4 offset1:5\n\t" \
+                        "ds_read2_b32 %4, %16 offset0:6 offset1:7\n\t" \
+                        "ds_read_b32 %5, %16 offset:32\n\t" \
+                        "ds_read_b128 %6, %17\n\t" \
+                        "ds_read_b128 %7, %17 offset:16\n\t" \
+                        "ds_read_b128 %8, %17 offset:32\n\t" \
+                        "ds_read_b128 %9, %17 offset:48\n\t" \
+                        "ds_read_b128 %10, %17 offset:64\n\t" \
+                        "ds_read_b128 %11, %17 offset:80\n\t" \
+                        "ds_read_b128 %12, %17 offset:96\n\t" \
+                        "ds_read_b128 %13, %17 offset:112\n\t" \
+                        "ds_read_b128 %14, %17 offset:128"
+#define G4_ROW_HEAD_OPERANDS \
+                        : "=&v"(mt), "=&v"(x01), "=&v"(x23), "=&v"(x45), "=&v"(x67), "=&v"(x8), \
+                          "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]), \
+                          "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8]) \
+                        : "v"(maddr), "v"(xaddr), "v"(vaddr) \
+                        : "memory"
+                    if (PROF) asm volatile(G4_ROW_HEAD_READS "\n\ts_waitcnt lgkmcnt(0)" G4_ROW_HEAD_OPERANDS);   // stamps are scalar-memory ops
+                    else asm volatile(G4_ROW_HEAD_READS G4_ROW_HEAD_OPERANDS);
                 }
-                const int xw[9] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y, x67.x, x67.y, x8};
-                float vw[36];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { vw[4 * k] = pv[k].x; vw[4 * k + 1] = pv[k].y; vw[4 * k + 2] = pv[k].z; vw[4 * k + 3] = pv[k].w; }
-                // reference = largest of the nine group exponents.  Groups are stored with a +100 bias (see the row write), so
-                // scaled values reach 2^100 at most (sums < 2^106) and a column whose predecessors all sit up to ~190 binades
-                // under the window maximum still sums to >= 2^-97.  Next to the DP's diagonal neighbouring vertices are 25-35
-                // binades apart, so this headroom is used on every row.
                 if (PROF) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     const u64 tm = __builtin_amdgcn_s_memtime();
-                    pf.rd += tm - pf.last;
+                    pf.rd += tm - pf.last; pf.tmid = tm;
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // (1) match row landed: everything that depends on it alone is computed under the remaining reads
+                asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(mt));
+                const float m2[4] = {mt.x, mt.y, mt.z, mt.w};
+                float base[4]; bool okc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    okc[c] = cell_active(j + c, t);
+                    base[c] = lmax[c] + m2[c] * G4_LOG2E;                    // log2(strongest link * emission)
+                }
+                // (2) group exponents landed.  Reference = largest of the nine: groups are stored with a +100 bias (see the
+                // row write), so scaled values reach 2^100 at most (sums < 2^106) and a column whose predecessors all sit up
+                // to ~190 binades under the window maximum still sums to >= 2^-97.  Next to the DP's diagonal neighbouring
+                // vertices are 25-35 binades apart, so this headroom is used on every row.
+                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67), "+v"(x8));
+                const int xw[9] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y, x67.x, x67.y, x8};
                 int refi = max(max(max(xw[0], xw[1]), max(xw[2], xw[3])), max(max(xw[4], xw[5]), max(max(xw[6], xw[7]), xw[8])));
                 const bool any_live = refi != GNEGSENT;
                 if (!any_live) refi = 0;
-                // group factors 2^(X - ref) (0 for dead groups: ldexp saturates), applied with v_pk_mul_f32
+                // group factors 2^(X - ref) <= 1 (0 for dead groups: ldexp saturates), applied with v_pk_mul_f32
                 float fg[9];
 #pragma unroll
                 for (int g = 0; g < 9; ++g) fg[g] = ldexpf(1.0f, xw[g] - refi);
+                // (3) the window, group by group as it lands
                 v2f S2[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { S2[c].x = 0.f; S2[c].y = 0.f; }
-#pragma unroll
-                for (int i = 0; i < 18; ++i) {
-                    v2f w2;
-                    w2.x = vw[2 * i] * fg[i >> 1];
-                    w2.y = vw[2 * i + 1] * fg[i >> 1];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) S2[c] = __builtin_elementwise_fma(w2, E2[c][i], S2[c]);
-                }
+#define G4_GROUP(k, n) \
+                { asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(pv[k])); \
+                  v2f wa, wb; wa.x = pv[k].x * fg[k]; wa.y = pv[k].y * fg[k]; wb.x = pv[k].z * fg[k]; wb.y = pv[k].w * fg[k]; \
+                  _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
+                      S2[c] = __builtin_elementwise_fma(wa, E2[c][2 * k], S2[c]); \
+                      S2[c] = __builtin_elementwise_fma(wb, E2[c][2 * k + 1], S2[c]); } }
+                G4_GROUP(0, 8) G4_GROUP(1, 7) G4_GROUP(2, 6) G4_GROUP(3, 5) G4_GROUP(4, 4)
+                G4_GROUP(5, 3) G4_GROUP(6, 2) G4_GROUP(7, 1) G4_GROUP(8, 0)
+#undef G4_GROUP
                 float S[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) S[c] = S2[c].x + S2[c].y;
+                if (PROF) {
+                    // the stamp must follow the sums: tie it to them through an empty asm the scheduler cannot cross
+                    asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u64 tf = __builtin_amdgcn_s_memtime();
+                    pf.fma += tf - pf.tmid;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const float ref = (float)refi;
+                // ---- row tail
                 bool need_fb = false;
                 const bool R_live = any_live;
                 bool flag[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float cand = __builtin_amdgcn_logf(S[c]) + ref + lmax[c] + m2[c] * G4_LOG2E;
-                    const bool okc = cell_active(j + c, t) & any_live;
-                    flag[c] = okc & !(S[c] >= sthr[c] && S[c] <= 0x1p110f);       // too small, NaN (escaped input) or inf
-                    a2[c] = (okc & !flag[c]) ? cand : NEG_INF;
+                    const bool okl = okc[c] & any_live;
+                    flag[c] = okl & !(S[c] >= sthr[c] && S[c] <= 0x1p110f);       // too small, NaN (escaped input) or inf
                     need_fb |= flag[c];
+                    a2[c] = (okl & !flag[c]) ? (__builtin_amdgcn_logf(S[c]) + (ref + base[c])) : NEG_INF;
                 }
                 if (__builtin_expect(need_fb, 0)) {
                     { const u32 slot = atomicAdd(&p.counters[3], 1u);          // diagnostics: lane-rows that left the fast path
@@ -310,7 +331,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                             for (int d = 1; d <= 32; ++d)
                                 sc = fmaf(__builtin_amdgcn_exp2f(aw[gqidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
                             S[c] = sc;
-                            if (sc >= 0x1p-97f) a2[c] = __builtin_amdgcn_logf(sc) + cmx + lmax[c] + m2[c] * G4_LOG2E;
+                            if (sc >= 0x1p-97f) a2[c] = __builtin_amdgcn_logf(sc) + cmx + base[c];
                         } else {
                             S[c] = 1.f;                      // settled by the fast path (or inactive)
                         }
@@ -355,6 +376,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                         if (c == 0) a2[0] = r; else if (c == 1) a2[1] = r; else if (c == 2) a2[2] = r; else a2[3] = r;
                     }
                 }
+
             }
             // ---- write the row: LDS state for the next row, HBM output ----
             {
@@ -363,16 +385,16 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                 const float amax = fmaxf(fmaxf(a2[0], a2[1]), fmaxf(a2[2], a2[3]));
                 const bool dead = amax == NEG_INF;
                 const float cf = dead ? 0.f : ceilf(amax) - 100.f;
-                float vn[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float e = a2[c] - cf;
                     const float v = __builtin_amdgcn_exp2f(e);
                     vn[c] = (e < -120.f && e != NEG_INF) ? __builtin_nanf("") : v;
                 }
-                *reinterpret_cast<float4*>(Vbuf + cur * RL + own_li0 + 4 * l) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-                Xbuf[cur * GL + (own_li0 >> 2) + l] = dead ? GNEGSENT : (int)cf;
+                xn = dead ? GNEGSENT : (int)cf;
             }
+            *reinterpret_cast<float4*>(Vbuf + cur * RL + own_li0 + 4 * l) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+            Xbuf[cur * GL + (own_li0 >> 2) + l] = xn;
             *reinterpret_cast<float4*>(Abuf + cur * RL + own_li0 + 4 * l) = make_float4(a2[0], a2[1], a2[2], a2[3]);
             if (col_ok)
                 *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a2[0] * G4_LN2, a2[1] * G4_LN2, a2[2] * G4_LN2, a2[3] * G4_LN2);
@@ -494,6 +516,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
     if (PROF && profslot >= 0 && lane == 0) {
         u32* o = p.counters + 8 + profslot * 21 + wave * 3;
         o[0] = (u32)pf.work; o[1] = (u32)pf.wait; o[2] = (u32)pf.rd;
+        if (wave == 0) p.counters[56 + profslot] = (u32)pf.fma;
     }
 }
 

@@ -25,6 +25,7 @@ for slot, label in ((0, "ticket 0 (alpha strip 0)"), (1, "ticket 2*per (alpha st
         work, wait, rd = (int(w[7 + slot * 21 + wv * 3 + i]) for i in range(3))
         tot = work + wait
         print(f"  {nm:9s} total {tot:9d} cyc  ({tot / max(1, int(tl[0])):7.1f}/row)  own work {work / max(1, tot) * 100:5.1f}%  barrier wait {wait / max(1, tot) * 100:5.1f}%  of work: LDS-read wait {rd / max(1, work) * 100:5.1f}%")
+print("compute0 FMA-phase cycles/row: strip0 %.1f strip2 %.1f" % (int(w[55]) / int(tl[0]), int(w[56]) / int(tl[0])))
 rt = [int(w[49 + i]) for i in range(6)]
 base = rt[0]
 print("realtime (100 MHz ticks -> us): strip0 start/row64/end", [(x - base) / 100 for x in rt[:3]], " strip2 start/row64/end", [(x - base) / 100 for x in rt[3:]])
