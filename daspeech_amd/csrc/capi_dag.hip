@@ -20,12 +20,15 @@ int launch_dag_strip4(int mode, const float*, const float*, const int64_t*, cons
 bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
 int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
+bool strip4h_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
+int launch_dag_strip4h(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+
 bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 3 = strip4 (4 columns/lane, 3 helper waves), 4 = strip2 (2 columns/lane, loader wave),
-// 5 = strip4g (strip4 with one exponent per lane group)
+// 5 = strip4g (strip4 with one exponent per lane group), 6 = strip4h (strip4g, two compute waves per SIMD)
 static int g_path = 0;
 static unsigned int g_last_fallbacks = 0;
 static unsigned int g_dbg[64] = {0};
@@ -52,7 +55,9 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     hipStream_t st = as_stream(stream);
     const bool s4 = strip4_supported(match, alpha, beta, nullptr, L, TR);
     // auto: strip4g for the log-sum DP (0.56 ms at C2 vs 0.71 ms strip4, 0.94 ms strip2), strip2 for the max-DP
-    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
+    if (g_path == 6 && strip4h_supported(match, alpha, beta, L, TR))
+        rc = launch_dag_strip4h(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
+    else if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
