@@ -23,12 +23,16 @@ int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t
 bool strip4h_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
 int launch_dag_strip4h(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
+bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
+int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
+
 bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 3 = strip4 (4 columns/lane, 3 helper waves), 4 = strip2 (2 columns/lane, loader wave),
-// 5 = strip4g (strip4 with one exponent per lane group), 6 = strip4h (strip4g, two compute waves per SIMD)
+// 5 = strip4g (strip4 with one exponent per lane group), 6 = strip4h (strip4g, two compute waves per SIMD),
+// 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL)
 static int g_path = 0;
 static unsigned int g_last_fallbacks = 0;
 static unsigned int g_dbg[64] = {0};
@@ -92,8 +96,14 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
     int rc = check_dims("dag_best_alignment", B, T, L, TR);
     if (rc) return rc;
     if (B == 0) return DSP_OK;
-    if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
+    if (!match || !links || !out_len || !tgt_len || !alpha_max || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    // trace == NULL: values-only DP + lazy back-trace (no B*T*L trace tensor); only the banded strip kernel offers it
+    if (!trace || g_path == 7) {
+        if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR))
+            return launch_dag_maxstrip(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
+        if (!trace) { set_error("dag_best_alignment: this shape / kernel family needs a trace buffer (see dsp_dag_alignment_trace_optional)"); return DSP_EINVAL; }
+    }
     if ((size_t)L * 4 <= 160 * 1024) {
         const bool s4 = strip4_supported(match, alpha_max, nullptr, trace, L, TR);
         if ((g_path == 0 || g_path == 4) && strip2_supported(match, alpha_max, nullptr, trace, L, TR)) {
@@ -113,6 +123,11 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
         }
     }
     return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, st);
+}
+
+extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
+{
+    return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 12288) ? 1 : 0;
 }
 
 extern "C" int dsp_dag_set_option(const char* name, int value)

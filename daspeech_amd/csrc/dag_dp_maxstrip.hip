@@ -1,0 +1,458 @@
+// dag_dp_maxstrip.hip — dag_best_alignment (K6 + K7) for banded graphs (TR <= 32) WITHOUT a trace tensor.
+//
+// Replaces calculate_maxalpha_kernel + the host-driven back-trace (DASpeech/custom_ops/dag_best_alignment.cu:39-130,160-201).
+// The reference (and dag_dp_strip2.hip / the generic kernel here) keep, for every one of the B*T*L cells, the arg-max
+// predecessor: 4 VALU instructions per transition (add, compare, two selects) and a B*T*L int32 tensor written to HBM, of
+// which the back-trace then reads T entries per sample.  Here:
+//   * the DP keeps VALUES only: per vertex 32 adds and a 3-input max tree (1.5 instructions per transition, no trace store);
+//     same strip / tagged-granule / ticket / helper-wave structure as dag_dp_strip4g.hip, 4 vertices per lane, log domain
+//     (add / max only => alpha_max is bit-identical to the sequential scan);
+//   * the back-trace recomputes the arg-max for the one cell per row it visits, from alpha_max and the links, with the
+//     reference's tie rule (smallest predecessor index; -1 when every candidate is -inf).
+// Used when the caller passes trace == NULL (the Python operator does); with a trace pointer the eager kernels run.
+#include "common.h"
+
+namespace dsp {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct MStripParams {
+    const float* match; const float* links; const int64_t* out_len; const int64_t* tgt_len;
+    float* alpha;
+    u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
+    u32 tag_base;
+    int B, T, L, TR, NS;
+};
+
+constexpr int MX_TRP = 32;
+constexpr int MX_RING = 8;
+constexpr int MX_CH = 4;                      // halo prefetch distance of the fetch wave (rows)
+constexpr u32 MX_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ u64 mx_gran_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mx_gran_store(u64* p, u32 tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mx_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+typedef float mx_v4f __attribute__((ext_vector_type(4)));
+typedef float mx_v2f __attribute__((ext_vector_type(2)));
+
+template <int NT, int CPL>
+__device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_raw, int b, int s, int so)
+{
+    constexpr int W = CPL * NT, RL = W + 32, NCW = NT / 64, DPR = W / 256;
+    float* Abuf = reinterpret_cast<float*>(smem_raw);          // [2][RL]  alpha_max rows (natural log domain)
+    float* Mring = Abuf + 2 * RL;                              // [RING][W] match rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T, L = p.L, TR = p.TR;
+    const int j0 = s * W;
+    const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
+    const float* M = p.match + (size_t)b * T * L;
+    const float* K = p.links + (size_t)b * L * TR;
+    float* O = p.alpha + (size_t)b * T * L;
+    const int nrows = Tb;
+
+    const bool has_producer = so > 0;
+    const bool has_consumer = s < p.NS - 1 && j0 + W < Lb;
+    const u64* hin = p.halo + ((size_t)b * p.NS + (has_producer ? s - 1 : 0)) * (size_t)T * MX_TRP;
+    u64* hout = p.halo + ((size_t)b * p.NS + s) * (size_t)T * MX_TRP;
+    // LDS geometry: li = col - j0 + 32 (halo [0,32), own [32, W+32))
+
+    // ---- prologue: the strip's transition rows -> LDS tile (coalesced, once), then -> registers ----
+    {
+        float* tile = reinterpret_cast<float*>(smem_raw);
+        constexpr int NTHR = NT + 192, RPP = NTHR / 32;       // rows per pass
+        const int rlo = j0 - 32;
+        const int dd = tid & 31, r0 = tid >> 5;
+        for (int rb = r0; rb < W + 32; rb += 8 * RPP) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                       // 8 independent (clamped, unconditional) loads in flight
+                const int i = rlo + rb + u * RPP;
+                const bool ok = dd < TR && i >= 0 && i < L;
+                const float raw = K[(size_t)(ok ? i : 0) * TR + (ok ? dd : 0)];
+                v[u] = ok ? raw : NEG_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int r = rb + u * RPP; if (r < W + 32) tile[r * 33 + dd] = v[u]; }
+        }
+    }
+    __syncthreads();
+
+    if (wave < NCW) {
+        // =========================================================== compute waves: CPL vertices per lane
+        const int l = tid;
+        const int j = j0 + CPL * l;
+        const bool col_ok = j < L;
+        float E[CPL][32];                        // E[c][k]: link of predecessor j + c - 32 + k into vertex j + c (k ascending = index ascending)
+        const float* tile = reinterpret_cast<const float*>(smem_raw);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) E[c][k] = tile[(CPL * l + c + k) * 33 + (31 - k)];   // row (j+c-32+k) - (j0-32), transition d-1 = 31-k
+        __syncthreads();                         // tile consumed: the loader may start filling the ring over it
+        mx_barrier();                            // prologue barrier: match row 0 is in the ring
+
+        for (int it = 0; it < nrows; ++it) {
+            const int t = it;
+            const int cur = it & 1, prv = cur ^ 1;
+            float a[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) a[c] = NEG_INF;
+            if (it == 0) {
+                if (j == 0) a[0] = Mring[(size_t)(it % MX_RING) * W];        // the start vertex
+            } else {
+                // row head: the match values and the (32 + CPL)-value window leave as one issue group (see dag_dp_strip4g.hip)
+                float w[32 + CPL], m2[CPL];
+                const u32 maddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Mring + (size_t)(it % MX_RING) * W + CPL * l);
+                const u32 vaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Abuf + prv * RL + CPL * l);
+                if constexpr (CPL == 4) {
+                    mx_v4f mt, pv[9];
+                    asm volatile(
+                        "ds_read_b128 %0, %10\n\t"
+                        "ds_read_b128 %1, %11\n\t"
+                        "ds_read_b128 %2, %11 offset:16\n\t"
+                        "ds_read_b128 %3, %11 offset:32\n\t"
+                        "ds_read_b128 %4, %11 offset:48\n\t"
+                        "ds_read_b128 %5, %11 offset:64\n\t"
+                        "ds_read_b128 %6, %11 offset:80\n\t"
+                        "ds_read_b128 %7, %11 offset:96\n\t"
+                        "ds_read_b128 %8, %11 offset:112\n\t"
+                        "ds_read_b128 %9, %11 offset:128\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(mt), "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]),
+                          "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8])
+                        : "v"(maddr), "v"(vaddr)
+                        : "memory");
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { w[4 * k] = pv[k].x; w[4 * k + 1] = pv[k].y; w[4 * k + 2] = pv[k].z; w[4 * k + 3] = pv[k].w; }
+                    m2[0] = mt.x; m2[1] = mt.y; m2[2] = mt.z; m2[3] = mt.w;
+                } else {
+                    mx_v2f mt, pl; mx_v4f pq[8];          // 17 eight-byte slots: eight ds_read2_b64 + one ds_read_b64
+                    asm volatile(
+                        "ds_read_b64 %0, %10\n\t"
+                        "ds_read2_b64 %1, %11 offset1:1\n\t"
+                        "ds_read2_b64 %2, %11 offset0:2 offset1:3\n\t"
+                        "ds_read2_b64 %3, %11 offset0:4 offset1:5\n\t"
+                        "ds_read2_b64 %4, %11 offset0:6 offset1:7\n\t"
+                        "ds_read2_b64 %5, %11 offset0:8 offset1:9\n\t"
+                        "ds_read2_b64 %6, %11 offset0:10 offset1:11\n\t"
+                        "ds_read2_b64 %7, %11 offset0:12 offset1:13\n\t"
+                        "ds_read2_b64 %8, %11 offset0:14 offset1:15\n\t"
+                        "ds_read_b64 %9, %11 offset:128\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(mt), "=&v"(pq[0]), "=&v"(pq[1]), "=&v"(pq[2]), "=&v"(pq[3]), "=&v"(pq[4]),
+                          "=&v"(pq[5]), "=&v"(pq[6]), "=&v"(pq[7]), "=&v"(pl)
+                        : "v"(maddr), "v"(vaddr)
+                        : "memory");
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { w[4 * k] = pq[k].x; w[4 * k + 1] = pq[k].y; w[4 * k + 2] = pq[k].z; w[4 * k + 3] = pq[k].w; }
+                    w[32] = pl.x; w[33] = pl.y;
+                    m2[0] = mt.x; m2[1] = mt.y;
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    // max over the 32 predecessors: window element c + k, a 3-input max tree (values only — the arg-max is
+                    // recomputed by the back-trace for the 1 cell per row that needs it)
+                    float x[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) x[k] = w[c + k] + E[c][k];
+                    float m10[11];
+#pragma unroll
+                    for (int g = 0; g < 10; ++g) m10[g] = fmaxf(fmaxf(x[3 * g], x[3 * g + 1]), x[3 * g + 2]);
+                    m10[10] = fmaxf(x[30], x[31]);
+                    const float m4a = fmaxf(fmaxf(m10[0], m10[1]), m10[2]), m4b = fmaxf(fmaxf(m10[3], m10[4]), m10[5]);
+                    const float m4c = fmaxf(fmaxf(m10[6], m10[7]), m10[8]), m4d = fmaxf(m10[9], m10[10]);
+                    const float mx = fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                    const bool act = (j + c >= t) && (j + c < Lb);
+                    a[c] = act ? (mx + m2[c]) : NEG_INF;
+                }
+            }
+            if constexpr (CPL == 4) {
+                *reinterpret_cast<float4*>(Abuf + cur * RL + 32 + 4 * l) = make_float4(a[0], a[1], a[2], a[3]);
+                if (col_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
+            } else {
+                *reinterpret_cast<float2*>(Abuf + cur * RL + 32 + 2 * l) = make_float2(a[0], a[1]);
+                if (col_ok) *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(a[0], a[1]);
+            }
+            mx_barrier();
+        }
+        if (col_ok) for (int t = Tb; t < T; ++t) {
+            if constexpr (CPL == 4) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            else *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(NEG_INF, NEG_INF);
+        }
+    } else if (wave == NCW) {
+        // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA)
+        auto issue_row = [&](int itr) {
+            const float* rowp = M + (size_t)itr * L;
+            float* slot = Mring + (size_t)(itr % MX_RING) * W;
+#pragma unroll
+            for (int i = 0; i < DPR; ++i) {
+                const int col = j0 + i * 256 + lane * 4;
+                const float* g = rowp + (col < L ? col : 0);          // out-of-range lanes re-read a valid address
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(slot + i * 256), 16, 0, 0);
+            }
+        };
+        __syncthreads();                         // link tile consumed
+        for (int r = 0; r < MX_RING - 1 && r < nrows; ++r) issue_row(r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mx_barrier();                            // prologue barrier
+        for (int it = 0; it < nrows; ++it) {
+            const int nx = it + MX_RING - 1;     // slot (it-1) % RING was last read during iteration it-1: free now
+            if (nx < nrows) {
+                issue_row(nx);
+                if (DPR == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // rows it+2 .. it+7 may stay in flight
+                else if (DPR == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            mx_barrier();
+        }
+    } else if (wave == NCW + 1) {
+        // =========================================================== fetch wave: left neighbour's last 32 vertices -> LDS halo
+        const bool hl = lane < MX_TRP;
+        u64 g[MX_CH];
+#pragma unroll
+        for (int k = 0; k < MX_CH; ++k) g[k] = 0;
+        auto load_row = [&](int itr) -> u64 {    // rolling prefetch, MX_CH rows ahead (see dag_dp_strip4g.hip)
+            if (itr < nrows && hl) return mx_gran_load(hin + (size_t)itr * MX_TRP + lane);
+            return 0;
+        };
+        if (has_producer) {
+#pragma unroll
+            for (int k = 0; k < MX_CH; ++k) g[k] = load_row(k);
+        }
+        __syncthreads();                         // link tile consumed
+        mx_barrier();                            // prologue barrier
+        for (int itb = 0; itb < nrows; itb += MX_CH) {
+#pragma unroll
+            for (int k = 0; k < MX_CH; ++k) {
+                const int it = itb + k;
+                if (it >= nrows) break;
+                const int cur = it & 1;
+                float hv = NEG_INF;
+                if (has_producer && hl) {
+                    const u32 want = p.tag_base + 1u + (u32)it;
+                    u64 xg = g[k];
+                    u32 spins = 0;
+                    while (!__all((u32)(xg >> 32) == want)) {
+                        if ((u32)(xg >> 32) != want) xg = mx_gran_load(hin + (size_t)it * MX_TRP + lane);
+                        if (++spins > MX_SPIN_LIMIT) { if (lane == 0) atomicOr(&p.counters[1], 1u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    hv = __uint_as_float((u32)xg);
+                }
+                if (hl) Abuf[cur * RL + lane] = hv;
+                if (has_producer) g[k] = load_row(it + MX_CH);
+                mx_barrier();
+            }
+        }
+    } else {
+        // =========================================================== publish wave: last 32 vertices -> granules
+        const bool pl = has_consumer && lane < MX_TRP;
+        __syncthreads();                         // link tile consumed
+        mx_barrier();                            // prologue barrier
+        for (int it = 0; it <= nrows; ++it) {
+            if (it > 0 && pl) {                  // row it-1 is complete; compute now writes the other buffer
+                const float v = Abuf[((it - 1) & 1) * RL + W + lane];
+                mx_gran_store(hout + (size_t)(it - 1) * MX_TRP + lane, p.tag_base + 1u + (u32)(it - 1), v);
+            }
+            if (it < nrows) mx_barrier();
+        }
+    }
+}
+
+template <int NT, int CPL>
+__global__ __launch_bounds__(NT + 192) void dag_maxstrip_kernel(MStripParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int W = CPL * NT;
+    u32* s_ticket = reinterpret_cast<u32*>(smem_raw);          // 16-byte header; everything else starts at +16
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_ticket = atomicAdd(&p.counters[0], 1u);
+    __syncthreads();
+    const u32 ticket = *s_ticket;                              // producers hold smaller tickets than their consumers
+    const int so = (int)(ticket / p.B);
+    const int b = (int)(ticket % p.B);
+    const int s = so;
+    const int j0 = s * W;
+    const int T = p.T, L = p.L;
+    const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
+    const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    if (!valid || j0 >= Lb) {                    // nothing reachable in this strip: -inf everywhere, no hand-off
+        float* O = p.alpha + (size_t)b * T * L;
+        for (int j = j0 + 4 * tid; j < j0 + W && j < L; j += 4 * (NT + 192))
+            for (int t = 0; t < T; ++t)
+                *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+        return;
+    }
+    maxstrip_body<NT, CPL>(p, smem_raw + 16, b, s, so);
+}
+
+// ---- lazy back-trace (replaces the trace tensor of dag_best_alignment.cu:39-130 + the pointer chase of :160-201) ----------
+// One workgroup per sample.  At row t and vertex j the predecessor is  argmax_i alpha_max[t-1][i] + links[i][j-i-1]  over
+// i in [j-TR, j-1], the smallest i on ties, -1 if every candidate is -inf: exactly what the eager kernels store in
+// trace[t][j] — but only T cells per sample are ever asked for, not T*L.
+// A pointer chase costs one dependent memory round trip per row.  Here a round trip buys BT_HOPS rows: the path moves left by
+// 1..TR vertices per row, so the next h-th hop can only need alpha_max[t-h][pos-32h .. pos-h]; all BT_HOPS segments are
+// fetched at once into LDS by the whole workgroup, and the transition rows below `pos` sit in an LDS window that is refilled
+// in bulk every few dozen hops.  Wave 0 then resolves the hops from LDS (lane d evaluates predecessor pos-1-d).
+constexpr int BT_HOPS = 10;
+constexpr int BT_LW = 768;                    // transition rows cached in LDS
+constexpr int BT_SEG = 64 * BT_HOPS;          // widest segment (frame one iteration old: up to 2*HOPS rows back)
+constexpr int BT_PER = (BT_HOPS * BT_SEG + 191) / 192;     // the three fetch waves (wave 0 resolves hops)
+
+__device__ __forceinline__ float bt_row16_max(float v) {      // all-reduce max within each row of 16 lanes
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
+    const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len,
+    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L, int TR)
+{
+    extern __shared__ __attribute__((aligned(16))) char bt_smem[];
+    float* lk = reinterpret_cast<float*>(bt_smem);                       // [BT_LW][TR]  rows lbase .. lbase + BT_LW - 1
+    float* seg = lk + (size_t)BT_LW * TR;                                // [BT_HOPS][BT_SEG]
+    int32_t* lp = reinterpret_cast<int32_t*>(seg + BT_HOPS * BT_SEG);    // [L]
+    __shared__ int s_state[4];                                           // pos, t, done
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    for (int j = tid; j < L; j += 256) lp[j] = -1;
+    const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
+    const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    const float* A = amax + (size_t)b * T * L;
+    const float* K = links + (size_t)b * L * TR;
+    int pos = Lb - 1, t = Tb - 1, lbase = 0x3fffffff;
+    bool done = !valid;
+    // segments are fetched one iteration AHEAD, relative to the frame (tF, pF) = (t, pos) at that time: slot k holds
+    // alpha_max[tF - HOPS - k][pF - 32(HOPS+k) .. pF - (HOPS+k)], a superset of what hop k of the next iteration can touch
+    // (the path moves 1..32 vertices left per row), so the memory round trip overlaps the hop resolution of this iteration.
+    float pre[BT_PER];
+    auto fetch = [&](int tF, int pF) {
+        if (tid < 64) return;
+#pragma unroll
+        for (int u = 0; u < BT_PER; ++u) {
+            const int e = (tid - 64) + u * 192;
+            const int k = e / BT_SEG + 1, q = e % BT_SEG;
+            const int row = tF - BT_HOPS - k, col = pF - 32 * (BT_HOPS + k) + q;
+            float v = NEG_INF;
+            if (e < BT_HOPS * BT_SEG && q <= 31 * (BT_HOPS + k) && row >= 0 && col >= 0 && col < L) v = A[(size_t)row * L + col];
+            pre[u] = v;
+        }
+    };
+    auto stash = [&]() {
+        if (tid < 64) return;
+#pragma unroll
+        for (int u = 0; u < BT_PER; ++u) { const int e = (tid - 64) + u * 192; if (e < BT_HOPS * BT_SEG) seg[e] = pre[u]; }
+    };
+    int tF = t + BT_HOPS, pF = pos + BT_HOPS;                            // pretend frame of the iteration before the first
+    if (!done) { fetch(tF, pF); stash(); }
+    __syncthreads();
+    while (!done) {
+        // (a) transition window: rows [pos - 32*HOPS, pos) must be cached
+        if (pos - 32 * BT_HOPS < lbase || pos > lbase + BT_LW) {
+            lbase = pos - BT_LW;
+            const long lo = (long)lbase * TR, n = (long)BT_LW * TR;
+            for (long e0 = tid; e0 < n; e0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const long e = e0 + u * 256; const long g = lo + e; v[u] = (e < n && g >= 0) ? K[g] : NEG_INF; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const long e = e0 + u * 256; if (e < n) lk[e] = v[u]; }
+            }
+            __syncthreads();
+        }
+        // (b) request the NEXT iteration's segments (frame = now); they land while wave 0 works
+        const int t0 = t, p0 = pos;
+        fetch(t0, p0);
+        // (c) wave 0 resolves up to HOPS hops from LDS (segments of frame (tF, pF))
+        if (tid < 64) {
+            for (int h = 1; h <= BT_HOPS; ++h) {
+                if (lane == 0) lp[pos] = t;
+                if (t == 0 || pos < t) { done = true; break; }           // row 0 / under the diagonal: trace = -1
+                const int d = lane, i = pos - 1 - d;
+                float x = NEG_INF;
+                if (d < TR && i >= 0) x = seg[(h - 1) * BT_SEG + (i - (pF - 32 * (BT_HOPS + h)))] + lk[(size_t)(i - lbase) * TR + d];
+                const float r = bt_row16_max(x);                         // every lane: maximum of its row of 16
+                const float mx = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)),
+                                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16)));
+                // the LARGEST d (smallest predecessor index) among the lanes that attain the maximum
+                const unsigned long long hit = __ballot(lane < 32 && x == mx && x != NEG_INF);
+                --t;
+                if (hit == 0ull) { pos = -1; done = true; break; }
+                pos = pos - 1 - (63 - __builtin_clzll(hit));
+            }
+            if (lane == 0) { s_state[0] = pos; s_state[1] = t; s_state[2] = done ? 1 : 0; }
+        }
+        __syncthreads();
+        pos = s_state[0]; t = s_state[1]; done = s_state[2] != 0;
+        stash();                                 // seg <- the segments requested in (b); their frame:
+        tF = t0; pF = p0;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int j = tid; j < L; j += 256) path[(size_t)b * L + j] = lp[j];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
+
+bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR)
+{
+    if (TR > 32 || (L & 3)) return false;
+    if (L > 12288) return false;                               // back-trace: path image + transition window in LDS
+    const uintptr_t a = (uintptr_t)match | (uintptr_t)alpha_max;
+    return (a & 15) == 0;
+}
+
+template <int NT, int CPL>
+static int launch_one_mx(const MStripParams& p, int nwg, hipStream_t st)
+{
+    constexpr int W = CPL * NT, RL = W + 32;
+    const size_t lds_main = (size_t)(2 * RL + MX_RING * W) * 4 + 16;
+    const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
+    const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
+    auto k = dag_maxstrip_kernel<NT, CPL>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(NT + 192), lds, st, p);
+    return check_launch("dag_best_alignment(maxstrip)");
+}
+
+// alpha_max by column strips (values only), then the lazy back-trace: no trace tensor
+int launch_dag_maxstrip(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                        float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+{
+    // one direction only: 4 vertices per lane in 1024-vertex strips when that still fills the chip (>= ~200 workgroups),
+    // otherwise 2 vertices per lane in 512-vertex strips (twice the waves for the same vertices)
+    const int ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
+    const bool wide = (long)B * ns1024 >= 200;
+    const int NS = wide ? ns1024 : ns512;
+    MStripParams p;
+    p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS;
+    const size_t halo_bytes = (size_t)B * NS * T * MX_TRP * sizeof(u64);
+    int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
+    if (rc) return rc;
+    rc = wide ? launch_one_mx<256, 4>(p, B * NS, st) : launch_one_mx<256, 2>(p, B * NS, st);
+    if (rc) return rc;
+    const size_t lds2 = ((size_t)BT_LW * TR + BT_HOPS * BT_SEG + (size_t)L) * 4;
+    (void)hipFuncSetAttribute((const void*)dag_backtrace_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(dag_backtrace_lazy_kernel, dim3(B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR);
+    return check_launch("dag_best_alignment(lazy back-trace)");
+}
+
+}  // namespace dsp

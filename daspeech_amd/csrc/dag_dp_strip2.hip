@@ -326,18 +326,37 @@ __device__ __forceinline__ void strip2_body(const StripParams& p, char* smem_raw
                     }
                 }
             } else {
-                // MODE 1: max-DP, natural domain; ascending predecessor index (ascending q), strict '>' keeps the smallest
-                float mxv[2] = {NEG_INF, NEG_INF};
-                int av[2] = {-1, -1};
+                // MODE 1: max-DP, natural domain.  The reference scans predecessors in ascending index with a strict '>' (the
+                // smallest index wins a tie, -1 if every candidate is -inf).  A serial scan is a 32-deep compare -> select
+                // chain per vertex; the same rule as a TOURNAMENT (the right contender wins only if strictly greater) is five
+                // levels deep, so the 93 compare/select nodes of a vertex issue back to back.
+                float wv[34];
 #pragma unroll
                 for (int i = 0; i < 17; ++i) {
                     const float2 v = *reinterpret_cast<const float2*>(Abuf + prv * RL + 2 * l + 2 * i);
+                    wv[2 * i] = v.x; wv[2 * i + 1] = v.y;
+                }
+                float mxv[2]; int av[2];
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int da = 32 + c - 2 * i, db = 32 + c - (2 * i + 1);
-                        if (da >= 1 && da <= 32) { const float x = v.x + E2[c][i].x; if (x > mxv[c]) { mxv[c] = x; av[c] = j + c - da; } }
-                        if (db >= 1 && db <= 32) { const float x = v.y + E2[c][i].y; if (x > mxv[c]) { mxv[c] = x; av[c] = j + c - db; } }
+                for (int c = 0; c < 2; ++c) {
+                    float xv[32]; int xi[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {                 // candidate k: window element q = c + k, transition d = 32 - k
+                        const int q = c + k;
+                        xv[k] = wv[q] + ((q & 1) ? E2[c][q >> 1].y : E2[c][q >> 1].x);
+                        xi[k] = q;
                     }
+#pragma unroll
+                    for (int n = 16; n >= 1; n >>= 1) {
+#pragma unroll
+                        for (int pidx = 0; pidx < n; ++pidx) {
+                            const bool gt = xv[2 * pidx + 1] > xv[2 * pidx];
+                            xv[pidx] = gt ? xv[2 * pidx + 1] : xv[2 * pidx];
+                            xi[pidx] = gt ? xi[2 * pidx + 1] : xi[2 * pidx];
+                        }
+                    }
+                    mxv[c] = xv[0];
+                    av[c] = (xv[0] == NEG_INF) ? -1 : (j - 32 + xi[0]);
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) if (cell_active(j + c, t)) { a2[c] = mxv[c] + m2[c]; arg[c] = av[c]; }

@@ -180,7 +180,8 @@ class DagBestAlignmentFunc(Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
-            trace = torch.empty((B, T, L), dtype=torch.int32, device=dev)
+            # the banded fast path back-traces lazily from alpha_max: no [B,T,L] trace tensor (the reference always writes one)
+            trace = None if lib.dsp_dag_alignment_trace_optional(L, TR) else torch.empty((B, T, L), dtype=torch.int32, device=dev)
             path = torch.empty((B, L), dtype=torch.long, device=dev)
             rc = lib.dsp_dag_best_alignment(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
                                             _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.current_stream_handle())

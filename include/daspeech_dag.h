@@ -86,7 +86,10 @@ int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* bet
 /* K6/K7  Viterbi alignment            replaces `dag_best_alignment` (dag_loss.cpp:27; dag_best_alignment.cu:209-253)
  *   alpha_max [B,T,L] fp32 out, trace [B,T,L] int32 out (scratch the caller owns), path [B,L] int64 out
  *   (the reference returns int32 and casts in Python, dag_loss.py:228).  path[b,j] = t or -1.
- *   Tie rule: smallest predecessor index among equal maxima (torch.max rule, dag_loss.py:320). */
+ *   Tie rule: smallest predecessor index among equal maxima (torch.max rule, dag_loss.py:320).
+ *   trace may be NULL where dsp_dag_alignment_trace_optional(L, TR) returns 1: the DP then keeps values only and the
+ *   back-trace recomputes the arg-max of the T cells it visits (same tie rule) — no B*T*L trace tensor is produced.
+ */
 int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                            float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                            dsp_stream_t stream);
@@ -95,9 +98,11 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family: 0 = auto, 1 = generic row-sequential, 2 = banded
  *   2-column log-space strips, 3 = strip4 (exp-space, per-vertex exponents), 4 = strip2 (2 vertices per lane), 5 = strip4g
- *   (exp-space, one exponent per lane group; the auto choice for the log-sum DP); used by tests to cross-check the families.
+ *   (exp-space, one exponent per lane group; the auto choice for the log-sum DP), 6 = strip4h (strip4g with two compute
+ *   waves per SIMD), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment); used by tests to cross-check the families.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
+int dsp_dag_alignment_trace_optional(int L, int TR);
 int dsp_dag_set_option(const char* name, int value);
 int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);
 /* cells that took the exp-space kernel's exact log-space fallback in the launch last queried by the call above */

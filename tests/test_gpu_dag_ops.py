@@ -275,7 +275,7 @@ def test_fast_paths_match_generic_kernels(shape):
     m.requires_grad_()
     res = {}
     try:
-        for path in (1, 2, 3, 4, 5, 6):
+        for path in (1, 2, 3, 4, 5, 6, 7):
             _lib.set_option("dp_path", path)
             loss, (a, b) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
@@ -286,7 +286,7 @@ def test_fast_paths_match_generic_kernels(shape):
         _lib.set_option("dp_path", 0)
     _, a_g, b_g, p_g = res[1]
     fa = torch.isfinite(a_g); fb = torch.isfinite(b_g)
-    for path in (2, 3, 4, 5, 6):
+    for path in (2, 3, 4, 5, 6, 7):
         _, a_f, b_f, p_f = res[path]
         assert torch.equal(torch.isneginf(a_f), torch.isneginf(a_g)), path
         assert torch.equal(torch.isneginf(b_f), torch.isneginf(b_g)), path

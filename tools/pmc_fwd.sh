@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_fwd.sh "<counters>" B T L TR path   -> per-dispatch averages for the strip DP kernels
 cd /tmp && export TMPDIR=/tmp
 CTRS="$1"; shift
-rm -rf /tmp/pmcx; rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/pmcx -o p --output-format csv -- python $GRAFT_REPO_ROOT/tools/run_fwd.py "$@" > /tmp/o.log 2>&1
+rm -rf /tmp/pmcx; rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/pmcx -o p --output-format csv -- python $GRAFT_REPO_ROOT/tools/${RUNNER:-run_fwd.py} "$@" > /tmp/o.log 2>&1
 python - <<PY
 import csv,collections
 rows=list(csv.DictReader(open("/tmp/pmcx/p_counter_collection.csv")))
