@@ -46,6 +46,7 @@ SIGNATURES = {
     "dsp_hifigan_pack_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
     "dsp_dag_alignment_trace_optional": (_c_int, [_c_int, _c_int]),
+    "dsp_dag_debug_k5": (_c_int, [ctypes.POINTER(ctypes.c_uint)]),
     "dsp_dag_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "dsp_dag_last_launch_status": (_c_int, [_c_p, ctypes.POINTER(ctypes.c_uint)]),
     "dsp_dag_last_fallback_count": (ctypes.c_uint, []),

@@ -10,6 +10,8 @@ int launch_dag_bwd_generic(const float*, const float*, const float*, const float
                            float*, float*, int, int, int, int, hipStream_t);
 
 bool banded_supported(int L, int TR);
+void set_k5_path(int v);
+int k5_diag(unsigned int* out);
 int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 int banded_last_error_word(hipStream_t st, unsigned int* word);
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
@@ -133,6 +135,7 @@ extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
 extern "C" int dsp_dag_set_option(const char* name, int value)
 {
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
+    if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");
     return DSP_EINVAL;
@@ -146,6 +149,8 @@ extern "C" int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* hos
     g_last_fallbacks = g_dbg[1];
     return rc;
 }
+
+extern "C" int dsp_dag_debug_k5(unsigned int* out4) { return out4 ? k5_diag(out4) : DSP_EINVAL; }
 
 extern "C" const unsigned int* dsp_dag_debug_words(void) { return g_dbg; }
 

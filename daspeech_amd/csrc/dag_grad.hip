@@ -128,6 +128,229 @@ __global__ __launch_bounds__(256) void dag_grad_links_tiled_kernel(
     }
 }
 
+// K5 for banded graphs (TR <= 32) in EXP SPACE.
+// grad_links[i][d] = go * sum_t exp(alpha[t][i] + beta[t+1][i+d+1] + link[i][d] - beta[0][0])       (dag_loss.cu:461-475)
+// The log-space kernels spend one v_exp_f32 (a quarter-rate instruction) per (t, i, d) term: 2.1e9 of them at C2.  Here the term is
+// factored as   W[t+1][j] * Ga[t][i] * Elink[i][d]   with
+//     W     = 2^(beta2[t+1][j] - R)        R = the lane's reference: the largest group exponent of its 36-value beta window
+//     Ga    = 2^(alpha2[t][i] - b00_2 + R) one v_exp per vertex and row
+//     Elink = 2^(link2[i][d])              applied once, after the sum over t
+// so the inner loop is one FMA per term.  beta rows are converted once per (row, 4-vertex group) into (value, group exponent)
+// pairs in LDS, as in dag_dp_strip4g.hip; there is no dependency between rows, so GX_TC rows are converted and consumed per
+// pass and each of the workgroup's four waves takes its own quarter of the rows (their sums meet in LDS at the end).
+// Every factor is bounded through  term <= 1  =>  W * Ga <= 1 / Elink, except for transitions weaker than 2^-100 (a finite
+// link more than 69 nats under 0) or a W * Ga beyond 2^120: such lanes redo their vertices with the exact per-term form.
+// A W under 2^-126 flushes: the dropped term is < 2^-126 * Ga <= 2^-6 ... in the scaled sum, i.e. an ABSOLUTE error below
+// 2^-100 * ... of the final gradient — the reference's relative accuracy on gradients that are themselves < 1e-30 is not kept.
+constexpr int GX_TC = 4;
+constexpr int GX_P = 296;                     // pitch of a converted beta row: 256 own + 36 halo columns, 16-byte multiple
+constexpr int GX_G = 76;                      // group exponents per row (73 used)
+constexpr int GX_NEG = -(1 << 30);
+constexpr int GX_WAVE_WORDS = 2 * GX_TC * GX_P + GX_TC * GX_G + 2 * GX_TC * 256;   // LDS words per wave
+__device__ unsigned int g_gx_diag[4];      // [0] lanes that took the exact redo, [1] of them: unsafe factor, [2] weak transition
+
+__global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
+    const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ links, const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
+    float* __restrict__ g_links, int B, int T, int L, int TR)
+{
+    extern __shared__ __attribute__((aligned(16))) char gx_smem[];
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int b = blockIdx.y, i0 = blockIdx.x * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* Bq = reinterpret_cast<float*>(gx_smem) + (size_t)wave * GX_WAVE_WORDS;   // [TC][GX_P] values
+    int* Xq = reinterpret_cast<int*>(Bq + GX_TC * GX_P);                                            // [TC][GX_G] group exponents
+    float* Aq = reinterpret_cast<float*>(Xq + GX_TC * GX_G);                                        // [TC][256]  alpha rows (own vertices)
+    float* Braw = Aq + GX_TC * 256;                                                                 // [TC][GX_P] beta rows as they arrive (LDS-DMA)
+    float* Araw = Braw + GX_TC * GX_P;                                                              // [TC][256]  alpha rows as they arrive
+    const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
+    const size_t TL = (size_t)T * L;
+    const float* A = alpha + (size_t)b * TL;
+    const float* Bp = beta + (size_t)b * TL;
+    const float b00 = Bp[0];
+    const bool dead = isinf(b00) || Tb > T || Lb > L || Tb < 1 || Lb < 1;
+    const float b00_2 = b00 * LOG2E;
+    const int v0 = i0 + 4 * lane;                               // this lane's four source vertices v0 .. v0+3
+    float acc[4][32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 32; ++d) acc[c][d] = 0.f;
+    // rows t = 0 .. Tb-2, a contiguous quarter per wave
+    const int nt = dead ? 0 : (Tb - 1);
+    const int per = (nt + 3) >> 2;
+    const int tlo = min(nt, wave * per), thi = min(nt, tlo + per);
+    bool bad = false;                                            // a factor left its safe range: redo this lane exactly
+    // The rows of pass n+1 stream into LDS (LDS-DMA, no registers) while pass n is consumed: a memory round trip per pass
+    // would otherwise be exposed (the conversion needs the data, and 190+ VGPRs of accumulators leave no room to prefetch).
+    auto request = [&](int tb0) {
+        const int nr = min(GX_TC, thi - tb0);
+        for (int r = 0; r < nr; ++r) {
+            const float* brow = Bp + (size_t)(tb0 + r + 1) * L;
+            const int c0 = i0 + 4 * lane, c1 = i0 + 256 + 4 * lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c0 < L ? c0 : 0)),
+                                             (__attribute__((address_space(3))) void*)(Braw + r * GX_P), 16, 0, 0);
+            if (lane < 9)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c1 < L ? c1 : 0)),
+                                                 (__attribute__((address_space(3))) void*)(Braw + r * GX_P + 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)(tb0 + r) * L + (c0 < L ? c0 : 0)),
+                                             (__attribute__((address_space(3))) void*)(Araw + r * 256), 16, 0, 0);
+        }
+    };
+    if (tlo < thi) request(tlo);
+    for (int tb = tlo; tb < thi; tb += GX_TC) {
+        const int rows = min(GX_TC, thi - tb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pass's rows have landed
+        // ---- convert beta rows tb+1 .. tb+rows: columns i0 .. i0+291 as 73 groups of 4 (window element q <-> column i0 + q)
+#pragma unroll
+        for (int r = 0; r < GX_TC; ++r) {
+            float4 a4 = *reinterpret_cast<const float4*>(Araw + r * 256 + 4 * lane);
+            if (!(r < rows && v0 < L)) a4 = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            *reinterpret_cast<float4*>(Aq + r * 256 + 4 * lane) = a4;
+        }
+#pragma unroll
+        for (int r = 0; r < GX_TC; ++r) {
+#pragma unroll
+            for (int pss = 0; pss < 2; ++pss) {
+                const int g = lane + 64 * pss;
+                if (g < 73) {
+                    const int col = i0 + 4 * g;
+                    float4 v = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * g);
+                    if (!(r < rows && col < L)) v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+                    const float x0 = v.x * LOG2E, x1 = v.y * LOG2E, x2 = v.z * LOG2E, x3 = v.w * LOG2E;
+                    const float gm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+                    const bool gd = gm == NEG_INF;
+                    const float cf = gd ? 0.f : ceilf(gm);
+                    *reinterpret_cast<float4*>(Bq + r * GX_P + 4 * g) = make_float4(
+                        __builtin_amdgcn_exp2f(x0 - cf), __builtin_amdgcn_exp2f(x1 - cf), __builtin_amdgcn_exp2f(x2 - cf), __builtin_amdgcn_exp2f(x3 - cf));
+                    Xq[r * GX_G + g] = gd ? GX_NEG : (int)cf;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations execute in order
+        if (tb + GX_TC < thi) request(tb + GX_TC);               // the raw rows are free again: next pass streams in meanwhile
+        // ---- consume: vertex v0+c, transition d -> window element q = c + 1 + d of the lane's 36-value window (groups lane .. lane+8)
+        for (int r = 0; r < rows; ++r) {
+            int xw[9]; float w[36];
+#pragma unroll
+            for (int g = 0; g < 9; ++g) xw[g] = Xq[r * GX_G + lane + g];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(Bq + r * GX_P + 4 * lane + 4 * k);
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            // Three scale domains per lane-row, so that no factor can leave fp32 whatever the slope of the rows (next to the
+            // DP's diagonal neighbouring vertices sit 25-35 binades apart):
+            //   groups 1..7 (inside the band of all four vertices): reference R = their largest exponent, W = value * 2^(X - R) <= 1,
+            //                 Ga[c] = 2^(alpha2 - b00_2 + R) <= 2 / Elink  because some in-band W is >= 1/2;
+            //   group 0 (elements 1..3: successors of vertices 0..2 only) and group 8 (elements 32..35): used unscaled
+            //                 (values <= 1 relative to their own exponent) with their own G0[c] / G8[c].
+            int R = max(max(max(xw[1], xw[2]), max(xw[3], xw[4])), max(max(xw[5], xw[6]), xw[7]));
+            const bool liveM = R != GX_NEG, live0 = xw[0] != GX_NEG, live8 = xw[8] != GX_NEG;
+            if (!liveM) R = 0;
+#pragma unroll
+            for (int g = 1; g < 8; ++g) {
+                const float f = ldexpf(1.0f, xw[g] - R);                    // <= 1; 0 for dead groups (ldexp saturates)
+                w[4 * g] *= f; w[4 * g + 1] *= f; w[4 * g + 2] *= f; w[4 * g + 3] *= f;
+            }
+            const float4 av = *reinterpret_cast<const float4*>(Aq + r * 256 + 4 * lane);
+            const float ua[4] = {av.x, av.y, av.z, av.w};
+            const float RM = (float)R - b00_2, R0 = (float)(live0 ? xw[0] : 0) - b00_2, R8 = (float)(live8 ? xw[8] : 0) - b00_2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float u2 = ua[c] * LOG2E;
+                const float eM = u2 + RM, e0 = u2 + R0, e8 = u2 + R8;
+                bad |= (liveM & (eM > 126.f)) | (live0 & (c < 3) & (e0 > 126.f)) | (live8 & (e8 > 126.f));   // only with transitions < 2^-100
+                const float GM = (liveM & (eM <= 126.f)) ? __builtin_amdgcn_exp2f(eM) : 0.f;
+                const float G0 = (live0 & (c < 3) & (e0 <= 126.f)) ? __builtin_amdgcn_exp2f(e0) : 0.f;
+                const float G8 = (live8 & (e8 <= 126.f)) ? __builtin_amdgcn_exp2f(e8) : 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    const int q = c + 1 + d;
+                    acc[c][d] = fmaf(w[q], q < 4 ? G0 : (q >= 32 ? G8 : GM), acc[c][d]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next pass overwrites the rows
+    }
+    // ---- transition weights; lanes with an unsafe factor or a transition under 2^-100 redo their sums term by term ----
+    const float go = dead ? 0.f : g_out[b];
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        const int vi = v0 + c;
+        float e2[32]; bool okd[32]; bool weak = false;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            okd[d] = !dead && d < TR && vi < Lb && vi + d + 1 < Lb;                                  // dag_loss.cu:461-466
+            e2[d] = okd[d] ? links[((size_t)b * L + vi) * TR + d] * LOG2E : NEG_INF;
+            weak |= okd[d] & (e2[d] != NEG_INF) & (e2[d] < -100.f);
+        }
+        float s[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s[d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
+        if (__builtin_expect(bad | weak, 0)) {
+            if (c == 0) { atomicAdd(&g_gx_diag[0], 1u); if (bad) atomicAdd(&g_gx_diag[1], 1u); if (weak) atomicAdd(&g_gx_diag[2], 1u); }
+            // exact form of dag_loss.cu:471-475 over this wave's rows (the scaled sum is discarded)
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s[d] = 0.f;
+            for (int t = tlo; t < thi; ++t) {
+                const float a = A[(size_t)t * L + vi] * LOG2E - b00_2;
+#pragma unroll
+                for (int d = 0; d < 32; ++d)
+                    if (okd[d]) s[d] += __builtin_amdgcn_exp2f(a + Bp[(size_t)(t + 1) * L + vi + d + 1] * LOG2E + e2[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s[d] = okd[d] ? s[d] * go : 0.f;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s[d] = okd[d] ? s[d] * __builtin_amdgcn_exp2f(e2[d]) * go : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { if (c == 0) acc[0][d] = s[d]; else if (c == 1) acc[1][d] = s[d]; else if (c == 2) acc[2][d] = s[d]; else acc[3][d] = s[d]; }
+    }
+    // ---- the four waves' partial sums meet in LDS (one vertex column at a time), wave 0 stores ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(gx_smem);               // [3 waves][64 lanes][33]
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (wave > 0) {
+#pragma unroll
+            for (int d = 0; d < 32; ++d)
+                red[((wave - 1) * 64 + lane) * 33 + d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int vi = v0 + c;
+            float s[32];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                s[d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
+                s[d] += red[(0 * 64 + lane) * 33 + d] + red[(1 * 64 + lane) * 33 + d] + red[(2 * 64 + lane) * 33 + d];
+            }
+            if (vi < L) {
+                float* out = g_links + ((size_t)b * L + vi) * TR;
+                if (TR == 32) {
+#pragma unroll
+                    for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(out + d) = make_float4(s[d], s[d + 1], s[d + 2], s[d + 3]);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 32; ++d) if (d < TR) out[d] = s[d];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int k5_diag(unsigned int* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gx_diag), 16);
+    unsigned int z[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gx_diag), z, 16);
+    return (int)e;
+}
+static int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel
+void set_k5_path(int v) { g_k5_path = v; }
+
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,
                            const int64_t* out_len, const int64_t* tgt_len, float* g_match, float* g_links,
                            int B, int T, int L, int TR, hipStream_t st)
@@ -139,7 +362,15 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         int rc = check_launch("dag_loss_bwd(grad_match)");
         if (rc) return rc;
     }
-    if (g_links) {
+    const bool expk = TR <= 32 && (L & 3) == 0 && ((((uintptr_t)alpha) | ((uintptr_t)beta) | ((uintptr_t)g_links)) & 15) == 0;
+    if (g_links && expk && g_k5_path != 1) {
+        const size_t lds = (size_t)4 * GX_WAVE_WORDS * 4;
+        (void)hipFuncSetAttribute((const void*)dag_grad_links_exp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(dag_grad_links_exp_kernel, dim3((L + 255) / 256, B), dim3(256), lds, st,
+                           g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
+        int rc = check_launch("dag_loss_bwd(grad_links, exp space)");
+        if (rc) return rc;
+    } else if (g_links) {
         hipLaunchKernelGGL(dag_grad_links_tiled_kernel, dim3((L + 63) / 64, (TR + 31) / 32, B), dim3(256), 0, st,
                            g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
         int rc = check_launch("dag_loss_bwd(grad_links)");

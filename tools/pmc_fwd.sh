@@ -11,5 +11,5 @@ for r in rows:
     k=r["Kernel_Name"][:48]
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
 for k in agg:
-    if "strip" in k: print(k, len(n[k]), {c: round(v/len(n[k])) for c,v in sorted(agg[k].items())})
+    if ("strip" in k or "grad_links" in k): print(k, len(n[k]), {c: round(v/len(n[k])) for c,v in sorted(agg[k].items())})
 PY
