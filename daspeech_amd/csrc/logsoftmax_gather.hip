@@ -177,22 +177,33 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
                 if (v < V) dst[k] = *reinterpret_cast<const uint4*>(row + v);
             }
         };
-        load_row(0, cur);
-        for (int r = 0; r < nr; ++r) {
-            T* row = x + ((size_t)b * L + (j0 + r)) * V;
-            if (r + 1 < nr) load_row(r + 1, nxt);
-            // the S gathered logits of this row are requested NOW (independent of max / sum): their L2 / fabric latency
-            // overlaps the reduction instead of following it (2 per lane for S = 512; S <= 8*256 on this path)
-            float graw[8];
+        // The S gathered logits of a row are requested TOGETHER WITH the row itself (one iteration before they are used): the
+        // row's lines are then in flight or freshly in L2 and the 4-byte gathers merge with them.  Requested an iteration
+        // later (when the row is reduced) ~40 % of them missed — a streaming workgroup's 64 KB per row turns the XCD's 4 MB
+        // L2 over in about one row time — and each miss was a 64-byte HBM fetch for 4 bytes (+1.7 GB of FETCH_SIZE at C2).
+        float gnx[8], graw[8];
+        auto load_gather = [&](int r, float (&dst)[8]) {
+            const T* row = x + ((size_t)b * L + (j0 + r)) * V;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = tid + u * 256;
+                dst[u] = 0.f;
                 if (k < S) {
                     int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
                     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-                    graw[u] = to_f(row[t]);
+                    dst[u] = to_f(row[t]);
                 }
             }
+        };
+        // rows (and their gathers) are requested TWO iterations ahead: a workgroup's requests come in 32 KB bursts, and with one
+        // row ahead the bytes in flight per CU average below what the HBM latency-bandwidth product asks for
+        uint4 nx2[NV]; float gn2[8];
+        load_row(0, cur);
+        load_gather(0, graw);
+        if (nr > 1) { load_row(1, nxt); load_gather(1, gnx); }
+        for (int r = 0; r < nr; ++r) {
+            T* row = x + ((size_t)b * L + (j0 + r)) * V;
+            if (r + 2 < nr) { load_row(r + 2, nx2); load_gather(r + 2, gn2); }
             float f[NV][N];
             float m = NEG_INF;
 #pragma unroll
@@ -242,7 +253,9 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NV; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { graw[u] = gnx[u]; gnx[u] = gn2[u]; }
         }
         __syncthreads();
         const int tot = S * nr;
@@ -316,6 +329,90 @@ __global__ __launch_bounds__(256) void lsg_bwd_kernel(
     }
 }
 
+// Backward, tiled: a workgroup owns RT CONSECUTIVE rows.  The row-per-workgroup kernel above reads g[b][s][j] with a stride of
+// L floats between the S gradients of a row, and the 16 rows that share each 64-byte line of g are in the hands of 16
+// different workgroups on 8 XCDs: 0.27 GB of gradients cost 1.2 GB of FETCH_SIZE at C2.  Here the [S][RT] gradient tile is
+// staged through LDS with 4*RT-byte runs along j, the softmax row is register-resident with the next row prefetched (as in
+// lsg_fwd_reg_kernel), and the per-row scatter image in LDS is unchanged.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
+    T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
+    const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
+    int B, int L, int V, int S, int RT)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                // 16 floats
+    float* delta = smem + 16;         // [V]   scatter image of the current row
+    float* gt = delta + V;            // [S][RT]
+    constexpr int N = Vec<T>::N;
+    const int tid = threadIdx.x;
+    for (int v = tid; v < V; v += 256) delta[v] = 0.f;
+    const int tiles_per_b = (L + RT - 1) / RT;
+    const long ntiles = (long)B * tiles_per_b;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_b);
+        const int j0 = (int)(tile % tiles_per_b) * RT;
+        const int nr = min(RT, L - j0);
+        uint4 cur[NV], nxt[NV];
+        auto load_row = [&](int r, uint4 (&dst)[NV]) {
+            const T* row = x + ((size_t)b * L + (j0 + r)) * V;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                if (v < V) dst[k] = *reinterpret_cast<const uint4*>(row + v);
+            }
+        };
+        uint4 nx2[NV];
+        load_row(0, cur);
+        if (nr > 1) load_row(1, nxt);
+        __syncthreads();                                   // previous tile's gt / delta use is over
+        const int tot = S * nr;
+        if (gsj == 1) {                                    // [B][S][L] gradients: runs along j
+            for (int e = tid; e < tot; e += 256) { const int k = e / nr, r = e - k * nr; gt[k * RT + r] = g[b * gsb + (int64_t)(j0 + r) + k * gss]; }
+        } else {
+            for (int e = tid; e < tot; e += 256) { const int r = e / S, k = e - r * S; gt[k * RT + r] = g[b * gsb + (int64_t)(j0 + r) * gsj + k * gss]; }
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            T* row = x + ((size_t)b * L + (j0 + r)) * V;
+            if (r + 2 < nr) load_row(r + 2, nx2);          // two rows ahead (see lsg_fwd_reg_kernel)
+            float gs = 0.f;
+            for (int k = tid; k < S; k += 256) {
+                const float gv = gt[k * RT + r];
+                int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+                gs += gv;
+                atomicAdd(&delta[t], gv);
+            }
+            gs = wave_sum(gs);
+            if ((tid & 63) == 0) red[tid >> 6] = gs;
+            __syncthreads();
+            const float neg = -(red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                if (v < V) {
+                    const T* e = reinterpret_cast<const T*>(&cur[k]);
+                    uint4 o;
+                    T* eo = reinterpret_cast<T*>(&o);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) eo[i] = from_f<T>(to_f(e[i]) * neg + delta[v + i]);     // dag_loss.py:293-295
+                    *reinterpret_cast<uint4*>(row + v) = o;
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < S; k += 256) {           // re-zero only what was touched
+                int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+                delta[t] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+            __syncthreads();
+        }
+    }
+}
+
 template <typename T>
 static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj, int64_t iss, float* match,
                       int64_t osb, int64_t osj, int64_t oss, int B, int L, int V, int S, int ws, hipStream_t st)
@@ -361,6 +458,21 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
     if (lds > 160 * 1024) { set_error("logsoftmax_gather_bwd: V=%d exceeds the LDS row image (max ~40k)", V); return DSP_EINVAL; }
     if (getenv("DSP_K1B_LDS")) { const size_t want = (size_t)atoi(getenv("DSP_K1B_LDS")); if (want > lds) lds = want; }
     const long nrows = (long)B * L;
+    const int nvec = (V + 256 * N - 1) / (256 * N);
+    {
+        int RT = 16;
+        if (getenv("DSP_K1B_RT")) RT = atoi(getenv("DSP_K1B_RT"));
+        const size_t ldsr = (16 + (size_t)V + (size_t)S * RT) * sizeof(float);
+        if (vec && nvec <= 8 && ldsr <= 76 * 1024 && L >= RT && !getenv("DSP_K1B_OLD")) {     // two workgroups per CU
+            auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4> : lsg_bwd_reg_kernel<T, 8>);
+            const long nt = (long)B * ((L + RT - 1) / RT);
+            int gridr = (int)(nt < 4096 ? nt : 4096);
+            if (getenv("DSP_K1B_GRID")) gridr = atoi(getenv("DSP_K1B_GRID"));
+            if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+            hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT);
+            return check_launch("logsoftmax_gather_bwd(reg)");
+        }
+    }
     const int grid = (int)(nrows < 2048 ? nrows : 2048);
     auto k = vec ? lsg_bwd_kernel<T, true> : lsg_bwd_kernel<T, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
