@@ -47,6 +47,9 @@ def parse():
                     help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2st = C4 full fbank->waveform pipeline; "
                          "train = C5 DASpeech training step (s2s_dag_fastspeech2_loss + flat-bucket gradient all-reduce)")
     ap.add_argument("--vocoder-backend", default="hip", choices=["torch", "hip"])
+    ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
+                    help="s2st only: autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (the reference runs --fp16); "
+                         "default fp32, the mode the mel parity (<= 1e-4) is stated for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     return ap.parse_args()
@@ -101,13 +104,16 @@ def run_model_workload(args, torch, dist, dev, world, rank):
         gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev))
         frames = [0]
 
+        amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
+
         def step(i):
-            out = gen.generate(model, batches[i % len(batches)])
+            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                out = gen.generate(model, batches[i % len(batches)])
             frames[0] += sum(o["feature"].shape[0] for o in out)
             return out
         wl = (f"C4 full S2ST pipeline, lookahead decode: Conformer(12L,256) -> DA-Transformer(4L,512) + links -> HIP graph decode -> "
               f"FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) -> HiFi-GAN V1 ({args.vocoder_backend} convs), "
-              f"B={B}/GPU, fbank80 300-800 frames, fp32")
+              f"B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"))
     else:
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
@@ -140,7 +146,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
     result = {
         "metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.workload == "s2st" else "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("f32" if args.amp == "none" else args.amp) if args.workload == "s2st" else "bf16", "data": "synthetic",
         "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"dp{world}", **extra},
         "roofline": None, "cpu_baseline": None,
     }

@@ -16,4 +16,4 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity, record_function
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     gen.generate(model, b); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=22, max_name_column_width=60))
+print(prof.key_averages().table(sort_by=os.environ.get("SORT", "self_cuda_time_total"), row_limit=28, max_name_column_width=50))
