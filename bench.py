@@ -268,6 +268,18 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes": alg_bytes, "avg_launch_ms": dag_fwd_ms}
 
+    # the same accounting for every phase of the step (SURVEY.md §8(d) byte counts; a phase = the launches of one operator call)
+    BTL, BLV, BLTR = B * T * L * 4.0, B * L * V * 4.0, B * L * TR * 4.0
+    phase_bytes = {
+        "gather_fwd": 2 * BLV + BTL,                     # logits read, softmax written in place, match written
+        "gather_bwd": 2 * BLV + BTL,                     # softmax read, gradient written in place, grad_match read
+        "dag_fwd": alg_bytes,
+        "dag_bwd": 3 * BTL + BLTR + BTL + BLTR,          # alpha, beta, match + links read; grad_match + grad_links written
+        "best_alignment": 2 * BTL + BLTR,                # match read, alpha_max written (no trace tensor), links read
+    }
+    roofline_phases = {n: {"algorithmic_bytes": phase_bytes[n], "ms": phases[n],
+                           "achieved_GBps": phase_bytes[n] / (phases[n] * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": phase_bytes[n] / (phases[n] * 1e-3) / 1e9 / HBM_PEAK_GBS} for n in names}
     result = {
         "metric": METRIC, "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -276,7 +288,7 @@ def main():
                                f"B={B}/GPU, graph_len={L}, tgt_len={T}, vocab={V}, TR={TR}, fp32",
                    "batch_per_gpu": B, "graph_len": L, "tgt_len": T, "vocab": V, "trans_len": TR,
                    "parallelism": f"dp{world} (independent utterances per rank, no data-path collective)"},
-        "roofline": roofline, "phases_ms": phases,
+        "roofline": roofline, "phases_ms": phases, "roofline_phases": roofline_phases,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
     int B, int L, int V, int S, int RT, int write_softmax)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* red = smem;                // 16 floats
-    float* stage = smem + 16;         // [S][RT]
+    float* red = smem;                // 2 x 16 floats (alternating per row)
+    float* stage = smem + 32;         // [S][RT]
     constexpr int N = Vec<T>::N;
     const int tid = threadIdx.x;
     const int tiles_per_b = (L + RT - 1) / RT;
@@ -225,12 +225,16 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
                 float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
                 online_merge(m, s, m2, s2);
             }
-            __syncthreads();                              // red[] free; previous row's softmax stores are behind us
-            if ((tid & 63) == 0) { red[tid >> 6] = m; red[8 + (tid >> 6)] = s; }
-            __syncthreads();
-            m = red[0]; s = red[8];
+            // ONE workgroup barrier per row: the cross-wave slots alternate (no "slots free" barrier), and every thread's
+            // gathers of this row have LANDED before it (they read the ORIGINAL logits; the softmax stores follow the barrier)
+            float* rs = red + ((r & 1) << 4);
+            if ((tid & 63) == 0) { rs[tid >> 6] = m; rs[8 + (tid >> 6)] = s; }
 #pragma unroll
-            for (int w = 1; w < 4; ++w) online_merge(m, s, red[w], red[8 + w]);
+            for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(graw[u]));
+            __syncthreads();
+            m = rs[0]; s = rs[8];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) online_merge(m, s, rs[w], rs[8 + w]);
             const float ls = __logf(s);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -238,7 +242,6 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
                 if (k < S) stage[k * RT + r] = (graw[u] - m) - ls;
             }
             if (write_softmax) {
-                __syncthreads();                                          // gathers read the ORIGINAL logits
                 const float inv = 1.f / s;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
@@ -435,7 +438,7 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
         // workgroup at RT = 32) sustain 4.9 TB/s, four only 4.1 TB/s (sweep in tools/k1_bench.py, r01)
         if (ws && (size_t)S * 32 * 4 <= 96 * 1024 && L >= 32) { RTr = 32; const long nt = (long)B * ((L + 31) / 32); gridr = (int)(nt < 4096 ? nt : 4096); }
         if (getenv("DSP_K1_RT")) { RTr = atoi(getenv("DSP_K1_RT")); const long nt = (long)B * ((L + RTr - 1) / RTr); gridr = (int)(nt < 65535 * 4 ? nt : 65535 * 4); if (getenv("DSP_K1_GRID")) gridr = atoi(getenv("DSP_K1_GRID")); }
-        const size_t ldsr = (16 + (size_t)S * RTr) * sizeof(float);
+        const size_t ldsr = (32 + (size_t)S * RTr) * sizeof(float);
         if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
         hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
                            B, L, V, S, RTr, ws);

@@ -25,7 +25,8 @@ class S2SNATGenerator:
     def generate(self, model, sample: Dict, generate_waveform: bool = True) -> List[Dict[str, Tensor]]:
         net = sample["net_input"]
         enc = model.forward_encoder(net["src_tokens"], net["src_lengths"])
-        prev = model.initialize_output_tokens_by_src(net["src_lengths"])
+        # the encoder's 4x subsampling keeps lengths on the device; the padded frame count is a host integer already
+        prev = model.initialize_output_tokens_by_src(net["src_lengths"], max_src_len=net["src_tokens"].shape[1])
         dec = model.forward_decoder(prev, enc)
         tts_in = model.adaptor(dec["features"])
         mel, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
@@ -36,14 +37,17 @@ class S2SNATGenerator:
         if generate_waveform and self.vocoder is not None and mel.shape[1] > 0:
             # vocode in length-sorted groups: the batch is padded to each GROUP's maximum, not the batch maximum
             # (the reference vocodes one file at a time, hifi-gan/inference_e2e.py:47-56)
+            # (sorted and regrouped on the device: the only host data needed are the lengths fetched above)
             order = sorted(range(len(lens)), key=lambda i: lens[i])
+            dev_order = torch.argsort(out_lens, stable=True)
+            mel_sorted = mel.index_select(0, dev_order)
+            len_sorted = out_lens.index_select(0, dev_order)
             gsz = max(1, self.vocoder_group)
             for g0 in range(0, len(order), gsz):
                 idx = order[g0:g0 + gsz]
                 gmax = max(1, max(lens[i] for i in idx))
-                sel = torch.tensor(idx, device=mel.device)
-                sub = mel.index_select(0, sel)[:, :gmax]
-                fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= out_lens.index_select(0, sel).unsqueeze(1)
+                sub = mel_sorted[g0:g0 + gsz, :gmax]
+                fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= len_sorted[g0:g0 + gsz].unsqueeze(1)
                 w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2)).squeeze(1)
                 for k, i in enumerate(idx):
                     wavs[i] = w[k, : max(lens[i], 1) * hop]

@@ -255,9 +255,14 @@ class S2TConformerDAGModel(nn.Module):
         self.synthetic_token_cycle = 0
 
     # graph size: L = clamp(src_upsample_scale * src_frames, 2, max_target_positions)   (s2t_conformer_dag.py:281-283)
-    def initialize_output_tokens_by_src(self, src_lengths: Tensor) -> Tensor:
+    def initialize_output_tokens_by_src(self, src_lengths: Tensor, max_src_len: int = None) -> Tensor:
+        """`max_src_len` (the padded frame count of the batch, a host integer) spares the device->host sync on `L.max()`; the
+        graph is then as wide as the longest utterance COULD be, which is what it is in a batch padded to its longest."""
         L = (src_lengths.float() * self.args.src_upsample_scale).long().clamp(2, self.args.max_target_positions)
-        maxl = int(L.max().item())
+        if max_src_len is not None:
+            maxl = min(max(int(float(max_src_len) * self.args.src_upsample_scale), 2), self.args.max_target_positions)
+        else:
+            maxl = int(L.max().item())
         ar = torch.arange(maxl, device=src_lengths.device).unsqueeze(0)
         toks = torch.full((len(L), maxl), self.unk, dtype=torch.long, device=src_lengths.device)
         toks = toks.masked_fill(ar >= L.unsqueeze(1), self.pad)
