@@ -35,6 +35,7 @@ SIGNATURES = {
     "dsp_lookahead_next": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_follow_path": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_gather_rows": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_extract_links": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
     "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_durations": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "dsp_bucketize_embed_add": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p]),

@@ -88,6 +88,25 @@ def graph_decode(logits: Tensor, links: Tensor, features: Tensor, output_length:
     return out_tok[:, : fmax + 1].contiguous(), out_feat, mask, lens
 
 
+def extract_links(q: Tensor, k: Tensor, log_gates: Tensor, output_length: Tensor, TR: int,
+                  dist_bias: Optional[Tensor] = None) -> Tensor:
+    """Fused compact transition log-probabilities [B, L, TR] fp32 from the link predictor's q / k [B,L,H,CK] and
+    log_gates [B,L,H] (s2t_conformer_dag.py:171-212); inference only (no gradient)."""
+    _gpu("extract_links", q, k, log_gates, output_length)
+    qf = q.detach().to(torch.float32).contiguous()
+    kf = k.detach().to(torch.float32).contiguous()
+    gf = log_gates.detach().to(torch.float32).contiguous()
+    ol = output_length.to(torch.long).contiguous()
+    B, L, H, CK = qf.shape
+    bias = None if dist_bias is None else dist_bias.detach().to(device=qf.device, dtype=torch.float32).contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(qf.device):
+        links = torch.empty((B, L, TR), dtype=torch.float32, device=qf.device)
+        _lib.check(lib.dsp_extract_links(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
+                                         B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links")
+    return links
+
+
 def posterior(alpha: Tensor, beta: Tensor) -> Tensor:
     """score = exp(alpha + beta - logsumexp_j(alpha + beta)), NaN -> 0   (s2s_dag_fastspeech2_loss.py:259-260)."""
     _gpu("posterior", alpha, beta)

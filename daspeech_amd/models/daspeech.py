@@ -199,6 +199,7 @@ class DAGDecoder(nn.Module):
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
         self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
         self.synthetic_link_bias = None
+        self.fused_links = True                 # inference: fused compact-band HIP kernel (False: the torch formulation)
 
     @staticmethod
     def positions(tokens: Tensor) -> Tensor:
@@ -224,8 +225,12 @@ class DAGDecoder(nn.Module):
         q = self.query_linear(fp).view(B, L, h, ck).float()
         k = self.key_linear(fp).view(B, L, h, ck).float()
         log_gates = F.log_softmax(self.gate_linear(fp), dim=-1, dtype=torch.float)                   # [B,L,h]
-        content = torch.einsum("bicf,bjcf->bijc", q, k) / (ck ** 0.5)                               # [B,L,L,h]
         TR = min(a.max_transition_length, L - 1)
+        if feats.is_cuda and not torch.is_grad_enabled() and h == 8 and ck % 4 == 0 and ck <= 128 and TR >= 1 and self.fused_links:
+            # inference: the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather
+            bias = None if self.synthetic_link_bias is None else self.synthetic_link_bias[:TR]
+            return decode_ops.extract_links(q, k, log_gates, prev_output_tokens.ne(PAD).sum(-1), TR, bias)
+        content = torch.einsum("bicf,bjcf->bijc", q, k) / (ck ** 0.5)                               # [B,L,L,h]
         idx = torch.arange(L, device=feats.device).unsqueeze(1) + torch.arange(TR, device=feats.device).unsqueeze(0) + 1
         out_len = prev_output_tokens.ne(PAD).sum(-1)
         invalid = idx.unsqueeze(0) >= out_len.view(B, 1, 1)                                          # [B,L,TR]

@@ -38,6 +38,16 @@ int dsp_follow_path(const int32_t* next, const int32_t* tok, const int64_t* out_
 int dsp_gather_rows(const void* features, int dtype, const int32_t* keep_idx, const int32_t* n_feat, void* out,
                     int B, int L, int D, int cap, int Fmax, dsp_stream_t stream);
 
+/* F0   transition log-probabilities of the graph, compact layout             (DAGDecoder.extract_links, s2t_conformer_dag.py:171-212)
+ *   q, k [B,L,H,CK] fp32 (query_linear / key_linear of [features ; link positional embedding], H = 8 heads),
+ *   log_gates [B,L,H] fp32 (log_softmax of gate_linear), out_len [B] int64, dist_bias [TR] fp32 or NULL (benchmark calibration),
+ *   scale = 1/sqrt(CK).  links[b,i,d] = logsumexp_h( log_softmax_d(q_i.k_{i+d+1} * scale, over valid successors) + log_gates[b,i,h] ),
+ *   -inf where i+d+1 >= out_len[b] or >= L; rows without a successor are all -inf.  Only the band is computed — the reference's
+ *   [B,L,L,H] content tensor and its gather (:183-196) never exist.  Inference path (no gradient). */
+int dsp_extract_links(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
+                      const float* dist_bias, float* links, int B, int L, int H, int CK, int TR, float scale,
+                      dsp_stream_t stream);
+
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */
 int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream);

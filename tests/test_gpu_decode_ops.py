@@ -151,3 +151,34 @@ def test_length_regulator_all_zero_durations():
     x = torch.randn(2, 5, 8, device=dev())
     out, lens = D().length_regulate(x, torch.zeros(2, 5, dtype=torch.long, device=dev()))
     assert out.shape == (2, 0, 8) and lens.tolist() == [0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("TRmax", [32, 99999, 7])
+def test_fused_extract_links_matches_torch_formulation(TRmax):
+    """csrc/extract_links.hip (band only, fused) vs the torch restatement of s2t_conformer_dag.py:171-212 in
+    DAGDecoder.extract_links (full [B,L,L,H] content + gather), ragged graph sizes, banded and dense windows."""
+    from daspeech_amd.models.daspeech import DAGDecoder, DEFAULT_ARGS, PAD, BOS, EOS, UNK
+    from types import SimpleNamespace
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    a = SimpleNamespace(**{**DEFAULT_ARGS, "max_transition_length": TRmax})
+    dec = DAGDecoder(a).to(dev).eval()
+    B, L = 3, 70
+    lens = [70, 51, 2]
+    prev = torch.full((B, L), PAD, dtype=torch.long, device=dev)
+    for b, n in enumerate(lens):
+        prev[b, :n] = UNK; prev[b, 0] = BOS; prev[b, n - 1] = EOS
+    feats = torch.randn(B, L, a.decoder_embed_dim, device=dev)
+    with torch.no_grad():
+        dec.fused_links = True
+        got = dec.extract_links(feats, prev)
+        dec.fused_links = False
+        want = dec.extract_links(feats, prev)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    assert torch.equal(torch.isneginf(got), torch.isneginf(want))
+    fin = torch.isfinite(want)
+    torch.testing.assert_close(got[fin], want[fin], rtol=1e-5, atol=2e-5)
+    # every row with a successor is a distribution over its valid transitions
+    rows = fin.any(-1)
+    torch.testing.assert_close(torch.logsumexp(got[rows], -1), torch.zeros_like(got[rows][:, 0]), rtol=0, atol=2e-5)
