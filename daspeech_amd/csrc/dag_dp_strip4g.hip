@@ -5,8 +5,8 @@
 //
 //   strip4 : per VERTEX (mantissa P, exponent C)  -> per lane-row 18 ds_read_b128, a 35-op max tree, 36 sub + 36 ldexp
 //   strip4g: per LANE GROUP of 4 vertices one integer exponent X, the 4 values stored as plain f32  V = 2^(a2 - X)
-//            -> per lane-row 9 ds_read_b128 + 9 dwords of X, a 4-op max tree, 9 (sub + ldexp) group factors and
-//               18 v_pk_mul_f32;  the row head no longer waits for 36 exponents before the first FMA can issue.
+//            -> per lane-row 9 ds_read_b128 + 9 dwords of X, a 4-op max tree, 9 group shifts and 36 v_ldexp_f32;
+//               the row head no longer waits for 36 exponents before the first FMA can issue.
 //
 // Exactness: X = ceil(max of the group's four a2) - 100, so V = 2^(a2 - X) lies in (2^99, 2^100] for the largest and is kept
 // down to 2^-120 for the others — a live vertex more than 220 binades under its group's maximum is stored as NaN
@@ -266,17 +266,18 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                 int refi = max(max(max(xw[0], xw[1]), max(xw[2], xw[3])), max(max(xw[4], xw[5]), max(max(xw[6], xw[7]), xw[8])));
                 const bool any_live = refi != GNEGSENT;
                 if (!any_live) refi = 0;
-                // group factors 2^(X - ref) <= 1 (0 for dead groups: ldexp saturates), applied with v_pk_mul_f32
-                float fg[9];
+                // group shifts X - ref <= 0, applied to every value with v_ldexp_f32: a group FACTOR 2^(X - ref) would itself
+                // flush below 2^-126 and cut the window at 126 binades although the stored values (bias +100) reach 226
+                int kg[9];
 #pragma unroll
-                for (int g = 0; g < 9; ++g) fg[g] = ldexpf(1.0f, xw[g] - refi);
+                for (int g = 0; g < 9; ++g) kg[g] = xw[g] - refi;                 // <= 0; hugely negative for dead groups
                 // (3) the window, group by group as it lands
                 v2f S2[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { S2[c].x = 0.f; S2[c].y = 0.f; }
 #define G4_GROUP(k, n) \
                 { asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(pv[k])); \
-                  v2f wa, wb; wa.x = pv[k].x * fg[k]; wa.y = pv[k].y * fg[k]; wb.x = pv[k].z * fg[k]; wb.y = pv[k].w * fg[k]; \
+                  v2f wa, wb; wa.x = ldexpf(pv[k].x, kg[k]); wa.y = ldexpf(pv[k].y, kg[k]); wb.x = ldexpf(pv[k].z, kg[k]); wb.y = ldexpf(pv[k].w, kg[k]); \
                   _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
                       S2[c] = __builtin_elementwise_fma(wa, E2[c][2 * k], S2[c]); \
                       S2[c] = __builtin_elementwise_fma(wb, E2[c][2 * k + 1], S2[c]); } }
@@ -306,11 +307,14 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                     need_fb |= flag[c];
                     a2[c] = (okl & !flag[c]) ? (__builtin_amdgcn_logf(S[c]) + (ref + base[c])) : NEG_INF;
                 }
-                if (__builtin_expect(need_fb, 0)) {
-                    { const u32 slot = atomicAdd(&p.counters[3], 1u);          // diagnostics: lane-rows that left the fast path
-                      if (p.dbg == 1 && slot < 14) { const int fc = flag[0] ? 0 : flag[1] ? 1 : flag[2] ? 2 : 3;
+                if (__builtin_expect(need_fb && p.dbg != 4, 0)) {      // (DSP_DEBUG=nofallback: timing experiment, WRONG results)
+                    // diagnostics (DSP_DEBUG=medium only: a returning global atomic costs the wave a memory round trip per entry)
+                    if (p.dbg == 1) {
+                        const u32 slot = atomicAdd(&p.counters[3], 1u);
+                        if (slot < 14) { const int fc = flag[0] ? 0 : flag[1] ? 1 : flag[2] ? 2 : 3;
                           p.counters[8 + 4 * slot] = (u32)b | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)t; p.counters[10 + 4 * slot] = (u32)(j + fc);
-                          p.counters[11 + 4 * slot] = __float_as_uint(fc == 0 ? S[0] : fc == 1 ? S[1] : fc == 2 ? S[2] : S[3]); } }
+                          p.counters[11 + 4 * slot] = __float_as_uint(fc == 0 ? S[0] : fc == 1 ? S[1] : fc == 2 ? S[2] : S[3]); }
+                    }
                     // (a) MEDIUM path, registers only: redo the flagged column against ITS OWN maximum (covers windows whose
                     //     four column maxima are > 2^120 apart — the diagonal at large t).  Falls through to the exact
                     //     path only if the column's own sum is still below the exactness threshold.
@@ -323,13 +327,27 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (flag[c]) {
+                            // transitions that can be alive at all: next to the DP's diagonal (where this path fires on
+                            // peaked scores: the diagonal falls hundreds of binades under its right-hand neighbours) a vertex
+                            // has a handful of live predecessors, so the 32 terms are walked in chunks of 8 that the wave skips
+                            const int dlim = min(32, max(0, BETA ? (Lb - Tb + 1 + t - (j + c)) : (j + c - t + 1)));
                             float cmx = NEG_INF;
 #pragma unroll
-                            for (int d = 1; d <= 32; ++d) cmx = fmaxf(cmx, aw[gqidx<BETA>(c, d)]);
+                            for (int d0 = 1; d0 <= 32; d0 += 8) {
+                                if (__any(dlim >= d0)) {
+#pragma unroll
+                                    for (int d = d0; d < d0 + 8; ++d) cmx = fmaxf(cmx, aw[gqidx<BETA>(c, d)]);
+                                }
+                            }
                             float sc = 0.f;
 #pragma unroll
-                            for (int d = 1; d <= 32; ++d)
-                                sc = fmaf(__builtin_amdgcn_exp2f(aw[gqidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
+                            for (int d0 = 1; d0 <= 32; d0 += 8) {
+                                if (__any(dlim >= d0)) {
+#pragma unroll
+                                    for (int d = d0; d < d0 + 8; ++d)
+                                        sc = fmaf(__builtin_amdgcn_exp2f(aw[gqidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
+                                }
+                            }
                             S[c] = sc;
                             if (sc >= 0x1p-97f) a2[c] = __builtin_amdgcn_logf(sc) + cmx + base[c];
                         } else {
@@ -594,7 +612,7 @@ int launch_dag_strip4g(const float* match, const float* links, const int64_t* ou
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = nullptr;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
-    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : 0; }
+    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
     const size_t halo_bytes = (size_t)ndir * B * NS * T * G4_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;

@@ -24,6 +24,10 @@ for path in paths:
     st = _lib.last_launch_status()
     w = _lib.load().dsp_dag_debug_words()
     a = alpha.cpu().numpy(); b = beta.cpu().numpy()
+    if os.environ.get("DSP_DEBUG") == "medium":
+        import struct
+        n = min(14, int(w[2]))
+        print("   first medium cells (sample|0x100=beta, t, vertex, S):", [(int(w[7 + 4 * i]), int(w[8 + 4 * i]), int(w[9 + 4 * i]), struct.unpack('f', struct.pack('I', w[10 + 4 * i]))[0]) for i in range(n)])
     for nm, x, r in (("alpha", a, a64), ("beta", b, b64)):
         mis = np.argwhere(np.isneginf(x) != np.isneginf(r))
         fin = np.isfinite(r) & np.isfinite(x)
