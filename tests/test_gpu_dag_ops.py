@@ -371,3 +371,61 @@ def test_banded_repeated_launches_reuse_workspace():
     with torch.no_grad():
         again = ops().dag_loss(m, k, o, t)
     assert torch.equal(again, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 1024, 32), (3, 17, 516, 20), (2, 9, 260, 7)])
+def test_lazy_alignment_ties_bit_exact(shape):
+    """Values-only max-DP + lazy back-trace (trace == NULL, dp_path 7 / auto): quantised scores give exact ties on most rows;
+    the recomputed arg-max must follow the reference's rule (smallest predecessor index) — compared with the oracle and the
+    eager trace kernels."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(71 + L, B, T, L, TR)
+    match = (np.round(match) * 1.0).astype(np.float32)
+    links = np.where(np.isfinite(links), np.round(links), links).astype(np.float32)
+    match[0, 3, :] = -np.inf; match[0, 3, 5] = 0.0                       # a forced vertex and -inf candidates on the way
+    m, k, o, t = to_dev(match, links, ol, tl)
+    ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+    try:
+        for path in (7, 1, 4):
+            _lib.set_option("dp_path", path)
+            got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
+            assert _lib.last_launch_status() == 0
+            np.testing.assert_array_equal(got, ref, err_msg=f"dp_path {path}")
+    finally:
+        _lib.set_option("dp_path", 0)
+
+
+@pytest.mark.parametrize("shape,k5", [((2, 40, 1024, 32), 2), ((2, 40, 1024, 32), 1), ((3, 30, 516, 20), 2), ((2, 40, 260, 7), 2)])   # (T-1)*TR >= L-1: the end is reachable
+def test_grad_links_exp_space_weak_and_peaked_links(shape, k5):
+    """K5 in exp space: transitions more than 100 binades under 0 (the per-lane exact redo), -inf emissions, short and ragged
+    windows; k5_path 1 = the log-space kernel it replaces.  Both against the fp64 oracle."""
+    from daspeech_amd import _lib
+    import ctypes
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(91 + L, B, T, L, TR)
+    rng = np.random.default_rng(3)
+    links = np.where(np.isfinite(links), links + (rng.integers(0, 6, links.shape) == 0) * -90.0, links).astype(np.float32)   # ~2^-130
+    match[1 % B, 4, :] = -np.inf; match[1 % B, 4, 3 * TR] = -1.0          # forced vertex; the end stays reachable
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_(); k.requires_grad_()
+    diag = (ctypes.c_uint * 4)()
+    try:
+        _lib.set_option("k5_path", k5)
+        _lib.load().dsp_dag_debug_k5(diag)
+        loss = ops().dag_loss(m, k, o, t)
+        fin = torch.isfinite(loss)
+        assert fin.any()
+        gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
+        torch.cuda.synchronize()
+        _lib.load().dsp_dag_debug_k5(diag)
+    finally:
+        _lib.set_option("k5_path", 0)
+    if k5 == 2 and L % 4 == 0:
+        assert diag[2] > 0                               # the weak-transition redo really ran
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    go = fin.cpu().numpy().astype(np.float64)
+    gm64, gl64 = orc.dag_grad(go, a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(gl.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
