@@ -24,6 +24,10 @@ SIGNATURES = {
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_logsoftmax_gather_bwd": (_c_int, [_c_p, _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
                                            _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_logsoftmax_gather_stats": (_c_int, [_c_p, _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
+                                             _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_logsoftmax_gather_bwd_lazy": (_c_int, [_c_p, _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
+                                                _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dsp_dag_loss_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                   _c_p, _c_sz, _c_p]),

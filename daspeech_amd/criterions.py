@@ -19,7 +19,13 @@ def compute_dag_loss(outputs: Tensor, output_masks: Tensor, targets: Tensor, tar
     B, L, _ = outputs.shape
     out_len = output_masks.sum(-1)
     tgt_len = target_masks.sum(-1)
-    _, match = custom_ops.dag_logsoftmax_gather_inplace(outputs, targets.unsqueeze(1).expand(-1, L, -1))
+    # `outputs` is never read again (the reference forbids it, dag_loss.py:249-251): keep the gather's backward state as two
+    # floats per row instead of an in-place softmax — the forward's B*L*V store disappears, match and gradient are unchanged
+    prev_mode = custom_ops.set_lazy_softmax(True)
+    try:
+        _, match = custom_ops.dag_logsoftmax_gather_inplace(outputs, targets.unsqueeze(1).expand(-1, L, -1))
+    finally:
+        custom_ops.set_lazy_softmax(prev_mode)
     match = match.transpose(1, 2)                                                     # [B,T,L], already contiguous
     if glat_keep_mask is not None and matchmask is not None:                          # force-emit mask (:130-132)
         gl = glat_keep_mask.unsqueeze(1)                                              # [B,1,L] glanced vertices
@@ -41,7 +47,9 @@ def glat_function(model, logits: Tensor, links: Tensor, prev_output_tokens: Tens
     pad = model.pad
     tgt_len = tgt_tokens.ne(pad).sum(-1)
     out_len = prev_output_tokens.ne(pad).sum(-1)
-    _, match = custom_ops.dag_logsoftmax_gather_inplace(logits.clone(), tgt_tokens.unsqueeze(1).expand(-1, L, -1))
+    # (no gradient here: the HIP operator then leaves the logits untouched, so the reference's defensive .clone() — a full
+    # B*L*V copy — is not needed)
+    _, match = custom_ops.dag_logsoftmax_gather_inplace(logits, tgt_tokens.unsqueeze(1).expand(-1, L, -1))
     match = match.transpose(1, 2)
     path = custom_ops.dag_best_alignment(match, links, out_len, tgt_len)              # [B,L], -1 off-path
     predict_align_mask = path >= 0

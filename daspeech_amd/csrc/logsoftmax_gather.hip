@@ -92,7 +92,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void lsg_fwd_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
-    int B, int L, int V, int S, int RT, int write_softmax)
+    int B, int L, int V, int S, int RT, int write_softmax, float* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                // 16 floats
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void lsg_fwd_kernel(
             float m, s;
             row_max_sum<T, VEC>(row, V, red, m, s);
             const float ls = __logf(s);
+            if (stats && threadIdx.x == 0) { float* st2 = stats + 2 * ((size_t)b * L + (j0 + r)); st2[0] = m; st2[1] = 1.f / s; }
             for (int k = threadIdx.x; k < S; k += blockDim.x) {
                 int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
                 t = t < 0 ? 0 : (t >= V ? V - 1 : t);
@@ -155,7 +156,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
-    int B, int L, int V, int S, int RT, int write_softmax)
+    int B, int L, int V, int S, int RT, int write_softmax, float* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                // 2 x 16 floats (alternating per row)
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
 #pragma unroll
             for (int w = 1; w < 4; ++w) online_merge(m, s, rs[w], rs[8 + w]);
             const float ls = __logf(s);
+            if (stats && tid == 0) { float* st2 = stats + 2 * ((size_t)b * L + (j0 + r)); st2[0] = m; st2[1] = 1.f / s; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = tid + u * 256;
@@ -280,11 +282,11 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
 // backward: row <- softmax * (-(sum_s g)) + scatter_add(g)     (dag_loss.py:293-295)
 // The per-row scatter targets are accumulated in an LDS image of the row (ds_add_f32), so duplicates add up
 // exactly like scatter_add_ and the row is still written once.
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool LAZY>
 __global__ __launch_bounds__(256) void lsg_bwd_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
-    int B, int L, int V, int S)
+    int B, int L, int V, int S, const float* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;            // 16 floats
@@ -310,17 +312,21 @@ __global__ __launch_bounds__(256) void lsg_bwd_kernel(
         float tot = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
         const float neg = -tot;
+        // LAZY: the buffer still holds the LOGITS; softmax = exp(x - m) * inv from the forward's row statistics
+        const float rm = LAZY ? stats[2 * rowi] : 0.f, rinv = LAZY ? stats[2 * rowi + 1] : 1.f;
         if (VEC) {
             for (int v = threadIdx.x * N; v < V; v += blockDim.x * N) {
                 float f[N];
                 load16(row + v, f);
 #pragma unroll
-                for (int i = 0; i < N; ++i) f[i] = f[i] * neg + delta[v + i];
+                for (int i = 0; i < N; ++i) f[i] = (LAZY ? __expf(f[i] - rm) * rinv : f[i]) * neg + delta[v + i];
                 store16(row + v, f);
             }
         } else {
-            for (int v = threadIdx.x; v < V; v += blockDim.x)
-                row[v] = from_f<T>(to_f(row[v]) * neg + delta[v]);
+            for (int v = threadIdx.x; v < V; v += blockDim.x) {
+                const float xv = to_f(row[v]);
+                row[v] = from_f<T>((LAZY ? __expf(xv - rm) * rinv : xv) * neg + delta[v]);
+            }
         }
         __syncthreads();
         for (int k = threadIdx.x; k < S; k += blockDim.x) {       // re-zero only what was touched
@@ -337,11 +343,11 @@ __global__ __launch_bounds__(256) void lsg_bwd_kernel(
 // different workgroups on 8 XCDs: 0.27 GB of gradients cost 1.2 GB of FETCH_SIZE at C2.  Here the [S][RT] gradient tile is
 // staged through LDS with 4*RT-byte runs along j, the softmax row is register-resident with the next row prefetched (as in
 // lsg_fwd_reg_kernel), and the per-row scatter image in LDS is unchanged.
-template <typename T, int NV>
+template <typename T, int NV, bool LAZY>
 __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
-    int B, int L, int V, int S, int RT)
+    int B, int L, int V, int S, int RT, const float* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                // 16 floats
@@ -391,6 +397,9 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
             if ((tid & 63) == 0) red[tid >> 6] = gs;
             __syncthreads();
             const float neg = -(red[0] + red[1] + red[2] + red[3]);
+            // LAZY: `cur` holds the LOGITS; softmax = exp(x - m) * inv from the forward's row statistics
+            const size_t srow = (size_t)b * L + (j0 + r);
+            const float rm = LAZY ? stats[2 * srow] : 0.f, rinv = LAZY ? stats[2 * srow + 1] : 1.f;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int v = (k * 256 + tid) * N;
@@ -399,7 +408,8 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
                     uint4 o;
                     T* eo = reinterpret_cast<T*>(&o);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) eo[i] = from_f<T>(to_f(e[i]) * neg + delta[v + i]);     // dag_loss.py:293-295
+                    for (int i = 0; i < N; ++i)
+                        eo[i] = from_f<T>((LAZY ? __expf(to_f(e[i]) - rm) * rinv : to_f(e[i])) * neg + delta[v + i]);     // dag_loss.py:293-295
                     *reinterpret_cast<uint4*>(row + v) = o;
                 }
             }
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
 
 template <typename T>
 static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj, int64_t iss, float* match,
-                      int64_t osb, int64_t osj, int64_t oss, int B, int L, int V, int S, int ws, hipStream_t st)
+                      int64_t osb, int64_t osj, int64_t oss, int B, int L, int V, int S, int ws, hipStream_t st, float* stats = nullptr)
 {
     constexpr int N = Vec<T>::N;
     const bool vec = (V % N == 0) && ((uintptr_t)logits % 16 == 0);
@@ -441,19 +451,19 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
         const size_t ldsr = (32 + (size_t)S * RTr) * sizeof(float);
         if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
         hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
-                           B, L, V, S, RTr, ws);
+                           B, L, V, S, RTr, ws, stats);
         return check_launch("logsoftmax_gather(reg)");
     }
     auto k = vec ? lsg_fwd_kernel<T, true> : lsg_fwd_kernel<T, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
-                       B, L, V, S, RT, ws);
+                       B, L, V, S, RT, ws, stats);
     return check_launch("logsoftmax_gather");
 }
 
-template <typename T>
+template <typename T, bool LAZY>
 static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, int64_t iss, const float* g,
-                      int64_t gsb, int64_t gsj, int64_t gss, int B, int L, int V, int S, hipStream_t st)
+                      int64_t gsb, int64_t gsj, int64_t gss, int B, int L, int V, int S, hipStream_t st, const float* stats)
 {
     constexpr int N = Vec<T>::N;
     const bool vec = (V % N == 0) && ((uintptr_t)sm % 16 == 0);
@@ -467,19 +477,19 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
         if (getenv("DSP_K1B_RT")) RT = atoi(getenv("DSP_K1B_RT"));
         const size_t ldsr = (16 + (size_t)V + (size_t)S * RT) * sizeof(float);
         if (vec && nvec <= 8 && ldsr <= 76 * 1024 && L >= RT && !getenv("DSP_K1B_OLD")) {     // two workgroups per CU
-            auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4> : lsg_bwd_reg_kernel<T, 8>);
+            auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2, LAZY> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4, LAZY> : lsg_bwd_reg_kernel<T, 8, LAZY>);
             const long nt = (long)B * ((L + RT - 1) / RT);
             int gridr = (int)(nt < 4096 ? nt : 4096);
             if (getenv("DSP_K1B_GRID")) gridr = atoi(getenv("DSP_K1B_GRID"));
             if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
-            hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT);
+            hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT, stats);
             return check_launch("logsoftmax_gather_bwd(reg)");
         }
     }
     const int grid = (int)(nrows < 2048 ? nrows : 2048);
-    auto k = vec ? lsg_bwd_kernel<T, true> : lsg_bwd_kernel<T, false>;
+    auto k = vec ? lsg_bwd_kernel<T, true, LAZY> : lsg_bwd_kernel<T, false, LAZY>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, stats);
     return check_launch("logsoftmax_gather_bwd");
 }
 
@@ -513,10 +523,51 @@ extern "C" int dsp_logsoftmax_gather_bwd(void* softmax_inout, int dtype, const i
     if (!softmax_inout || (S > 0 && (!idx || !g))) { set_error("logsoftmax_gather_bwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     switch (dtype) {
-        case DSP_F32: return launch_bwd<float>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
-        case DSP_F16: return launch_bwd<__half>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
-        case DSP_BF16: return launch_bwd<__hip_bfloat16>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st);
+        case DSP_F32: return launch_bwd<float, false>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, nullptr);
+        case DSP_F16: return launch_bwd<__half, false>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, nullptr);
+        case DSP_BF16: return launch_bwd<__hip_bfloat16, false>(softmax_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, nullptr);
     }
     set_error("logsoftmax_gather_bwd: unsupported dtype code %d", dtype);
+    return DSP_EINVAL;
+}
+
+// ---- "lazy" pair: the logits are NOT overwritten in the forward pass.  The reference stores the softmax in place only as
+// backward state ("word_ins_out is modified in place for storing backward tensors.  DO NOT use word_ins_out after this
+// function", dag_loss.py:249-251); the same gradient follows from the logits and two floats per row (max, 1/sum-exp), which
+// saves the forward's B*L*V store (4.3 GB of 8.9 GB at C2) — the backward reads the logits instead of the softmax.
+extern "C" int dsp_logsoftmax_gather_stats(const void* logits, int dtype, const int64_t* idx, int64_t idx_sb, int64_t idx_sj,
+                                           int64_t idx_ss, float* match, int64_t out_sb, int64_t out_sj, int64_t out_ss,
+                                           float* row_stats, int B, int L, int V, int S, dsp_stream_t stream)
+{
+    using namespace dsp;
+    if (B < 0 || L < 0 || V <= 0 || S < 0) { set_error("logsoftmax_gather_stats: bad sizes B=%d L=%d V=%d S=%d", B, L, V, S); return DSP_EINVAL; }
+    if (B == 0 || L == 0) return DSP_OK;
+    if (!logits || !row_stats || (S > 0 && (!idx || !match))) { set_error("logsoftmax_gather_stats: null pointer"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    void* lg = const_cast<void*>(logits);
+    switch (dtype) {
+        case DSP_F32: return launch_fwd<float>(lg, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, 0, st, row_stats);
+        case DSP_F16: return launch_fwd<__half>(lg, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, 0, st, row_stats);
+        case DSP_BF16: return launch_fwd<__hip_bfloat16>(lg, idx, idx_sb, idx_sj, idx_ss, match, out_sb, out_sj, out_ss, B, L, V, S, 0, st, row_stats);
+    }
+    set_error("logsoftmax_gather_stats: unsupported dtype code %d", dtype);
+    return DSP_EINVAL;
+}
+
+extern "C" int dsp_logsoftmax_gather_bwd_lazy(void* logits_inout, int dtype, const int64_t* idx, int64_t idx_sb,
+                                              int64_t idx_sj, int64_t idx_ss, const float* g, int64_t g_sb, int64_t g_sj,
+                                              int64_t g_ss, const float* row_stats, int B, int L, int V, int S, dsp_stream_t stream)
+{
+    using namespace dsp;
+    if (B < 0 || L < 0 || V <= 0 || S < 0) { set_error("logsoftmax_gather_bwd_lazy: bad sizes"); return DSP_EINVAL; }
+    if (B == 0 || L == 0) return DSP_OK;
+    if (!logits_inout || !row_stats || (S > 0 && (!idx || !g))) { set_error("logsoftmax_gather_bwd_lazy: null pointer"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case DSP_F32: return launch_bwd<float, true>(logits_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, row_stats);
+        case DSP_F16: return launch_bwd<__half, true>(logits_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, row_stats);
+        case DSP_BF16: return launch_bwd<__hip_bfloat16, true>(logits_inout, idx, idx_sb, idx_sj, idx_ss, g, g_sb, g_sj, g_ss, B, L, V, S, st, row_stats);
+    }
+    set_error("logsoftmax_gather_bwd_lazy: unsupported dtype code %d", dtype);
     return DSP_EINVAL;
 }

@@ -201,8 +201,21 @@ def _elem_strides(t: Tensor):
     return [int(s) for s in t.stride()]
 
 
-def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) -> Tensor:
-    """K1 launch: returns the contiguous [B,S,L] match buffer; word_ins_out becomes softmax if write_softmax."""
+# The reference keeps the softmax IN the logits buffer between forward and backward and forbids any other use of that
+# buffer (dag_loss.py:249-251).  LAZY_SOFTMAX = True keeps two floats per row instead and leaves the logits alone until the
+# backward overwrites them with the gradient: same match, same gradient, no B*L*V store in the forward.  Off by default —
+# the default reproduces the reference's side effect bit for bit; daspeech_amd.criterions turns it on.
+LAZY_SOFTMAX = False
+
+
+def set_lazy_softmax(flag: bool) -> bool:
+    """Select how dag_logsoftmax_gather_inplace keeps its backward state; returns the previous setting."""
+    global LAZY_SOFTMAX
+    prev, LAZY_SOFTMAX = LAZY_SOFTMAX, bool(flag)
+    return prev
+
+
+def _lsg_check(word_ins_out: Tensor, select_idx: Tensor):
     dev = _require_gpu("dag_logsoftmax_gather_inplace", word_ins_out, select_idx)
     if word_ins_out.dim() != 3 or select_idx.dim() != 3:
         raise RuntimeError("dag_logsoftmax_gather_inplace: word_ins_out and select_idx must be 3-D")
@@ -216,7 +229,12 @@ def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) 
     B, L, V = word_ins_out.shape
     if select_idx.shape[0] != B or select_idx.shape[1] != L:
         raise RuntimeError("dag_logsoftmax_gather_inplace: select_idx must be [batch, prelen, slen]")
-    S = select_idx.shape[2]
+    return dev, code, B, L, V, select_idx.shape[2]
+
+
+def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) -> Tensor:
+    """K1 launch: returns the contiguous [B,S,L] match buffer; word_ins_out becomes softmax if write_softmax."""
+    dev, code, B, L, V, S = _lsg_check(word_ins_out, select_idx)
     lib = _lib.load()
     with torch.cuda.device(dev):
         buf = torch.empty((B, S, L), dtype=torch.float32, device=dev)      # "match_all" layout
@@ -228,8 +246,23 @@ def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) 
     return buf
 
 
-def _lsg_backward(softmax_inout: Tensor, select_idx: Tensor, grad_match_bls: Tensor) -> Tensor:
-    """K1 backward launch: softmax_inout [B,L,V] -> d/d logits in place; grad_match_bls is [B,L,S]-shaped (any strides)."""
+def _lsg_forward_lazy(word_ins_out: Tensor, select_idx: Tensor):
+    """K1 launch that leaves the logits untouched: returns (match buffer [B,S,L], row statistics [B,L,2] = (max, 1/sum-exp))."""
+    dev, code, B, L, V, S = _lsg_check(word_ins_out, select_idx)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        buf = torch.empty((B, S, L), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, L, 2), dtype=torch.float32, device=dev)
+        isb, isj, iss = _elem_strides(select_idx)
+        rc = lib.dsp_logsoftmax_gather_stats(_lib.ptr(word_ins_out), code, _lib.ptr(select_idx), isb, isj, iss,
+                                             _lib.ptr(buf), S * L, 1, L, _lib.ptr(stats), B, L, V, S, _lib.current_stream_handle())
+        _lib.check(rc, "dsp_logsoftmax_gather_stats")
+    return buf, stats
+
+
+def _lsg_backward(softmax_inout: Tensor, select_idx: Tensor, grad_match_bls: Tensor, stats: Tensor = None) -> Tensor:
+    """K1 backward launch: softmax_inout [B,L,V] (softmax, or the logits when `stats` is given) -> d/d logits in place;
+    grad_match_bls is [B,L,S]-shaped (any strides)."""
     B, L, V = softmax_inout.shape
     S = select_idx.shape[2]
     g = grad_match_bls.detach()
@@ -240,9 +273,15 @@ def _lsg_backward(softmax_inout: Tensor, select_idx: Tensor, grad_match_bls: Ten
     with torch.cuda.device(softmax_inout.device):
         isb, isj, iss = _elem_strides(select_idx)
         gsb, gsj, gss = _elem_strides(g)
-        rc = lib.dsp_logsoftmax_gather_bwd(_lib.ptr(softmax_inout), code, _lib.ptr(select_idx), isb, isj, iss,
-                                           _lib.ptr(g), gsb, gsj, gss, B, L, V, S, _lib.current_stream_handle())
-        _lib.check(rc, "dsp_logsoftmax_gather_bwd")
+        if stats is None:
+            rc = lib.dsp_logsoftmax_gather_bwd(_lib.ptr(softmax_inout), code, _lib.ptr(select_idx), isb, isj, iss,
+                                               _lib.ptr(g), gsb, gsj, gss, B, L, V, S, _lib.current_stream_handle())
+            _lib.check(rc, "dsp_logsoftmax_gather_bwd")
+        else:
+            rc = lib.dsp_logsoftmax_gather_bwd_lazy(_lib.ptr(softmax_inout), code, _lib.ptr(select_idx), isb, isj, iss,
+                                                    _lib.ptr(g), gsb, gsj, gss, _lib.ptr(stats), B, L, V, S,
+                                                    _lib.current_stream_handle())
+            _lib.check(rc, "dsp_logsoftmax_gather_bwd_lazy")
     return softmax_inout
 
 
@@ -251,12 +290,19 @@ class DagLogsoftmaxGatherFunc(Function):
     @staticmethod
     def forward(ctx, word_ins_out, select_idx):
         need = ctx.needs_input_grad[0]
-        buf = _lsg_forward(word_ins_out, select_idx, need)
+        ctx.lazy = bool(need and LAZY_SOFTMAX)
+        if ctx.lazy:
+            buf, stats = _lsg_forward_lazy(word_ins_out, select_idx)
+        else:
+            buf, stats = _lsg_forward(word_ins_out, select_idx, need), None
         selected = buf.transpose(1, 2)                                         # [B, L, S] view
-        ctx.mark_dirty(word_ins_out)
+        ctx.mark_dirty(word_ins_out)                                           # (lazy: written by the backward)
         ctx.set_materialize_grads(False)
         if need:
-            ctx.save_for_backward(word_ins_out, select_idx)
+            if ctx.lazy:
+                ctx.save_for_backward(word_ins_out, select_idx, stats)
+            else:
+                ctx.save_for_backward(word_ins_out, select_idx)
             ctx.has_backward = False
         return word_ins_out, selected
 
@@ -269,6 +315,9 @@ class DagLogsoftmaxGatherFunc(Function):
             return None, None
         assert not ctx.has_backward, "Cannot backward twice in logsoftmax_gather"
         ctx.has_backward = True
+        if ctx.lazy:
+            grad_input, select_idx, stats = ctx.saved_tensors     # holds the logits, becomes the gradient in place
+            return _lsg_backward(grad_input, select_idx, grad_output, stats).detach(), None
         grad_input, select_idx = ctx.saved_tensors        # holds softmax, becomes the gradient in place
         return _lsg_backward(grad_input, select_idx, grad_output).detach(), None
 

@@ -64,6 +64,20 @@ int dsp_logsoftmax_gather_bwd(void* softmax_inout, int dtype,
                               const float* g, int64_t g_sb, int64_t g_sj, int64_t g_ss,
                               int B, int L, int V, int S, dsp_stream_t stream);
 
+/* K1 "lazy" pair: same match and the same gradient, but the logits are NOT overwritten by the forward pass.
+ *   The reference stores the softmax in place purely as backward state and forbids every other use of the buffer
+ *   ("DO NOT use word_ins_out after this function", dag_loss.py:249-251).  Here the forward writes two floats per row
+ *   (row_stats[(b*L+j)*2] = max, [..+1] = 1/sum exp(x - max)) and the backward recomputes softmax = exp(x - max) * inv from
+ *   the logits it overwrites with the gradient: the forward's B*L*V store disappears (4.3 of 8.9 GB at C2). */
+int dsp_logsoftmax_gather_stats(const void* logits, int dtype,
+                                const int64_t* idx, int64_t idx_sb, int64_t idx_sj, int64_t idx_ss,
+                                float* match, int64_t out_sb, int64_t out_sj, int64_t out_ss,
+                                float* row_stats, int B, int L, int V, int S, dsp_stream_t stream);
+int dsp_logsoftmax_gather_bwd_lazy(void* logits_inout, int dtype,
+                                   const int64_t* idx, int64_t idx_sb, int64_t idx_sj, int64_t idx_ss,
+                                   const float* g, int64_t g_sb, int64_t g_sj, int64_t g_ss,
+                                   const float* row_stats, int B, int L, int V, int S, dsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K2/K3  forward / backward DP       replaces `dag_loss` (dag_loss.cpp:25; dag_loss.cu:313-375)
  *   match [B,T,L] fp32, links [B,L,TR] fp32 (links[b,i,d] = log P(i -> i+d+1)), out_len/tgt_len int64 [B].

@@ -429,3 +429,31 @@ def test_grad_links_exp_space_weak_and_peaked_links(shape, k5):
     gm64, gl64 = orc.dag_grad(go, a64, b64, match, links, ol, tl, np.float64)
     np.testing.assert_allclose(gl.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
     np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 512), (torch.float32, 8192), (torch.float16, 1000), (torch.bfloat16, 264), (torch.float32, 37)])
+def test_lazy_softmax_mode_same_match_and_gradient(dtype, V):
+    """set_lazy_softmax(True): the forward leaves the logits untouched (two floats of row statistics instead of the in-place
+    softmax), the backward recomputes the softmax — match and d/d logits must equal the default mode's."""
+    from daspeech_amd.custom_ops import set_lazy_softmax
+    B, L, T = 3, 70, 17
+    rng = np.random.default_rng(V)
+    logits = torch.from_numpy((rng.standard_normal((B, L, V)) * 3).astype(np.float32)).to(dtype).to(dev())
+    tg = torch.from_numpy(rng.integers(0, V, (B, T))).to(dev())
+    w = torch.from_numpy(rng.standard_normal((B, L, T)).astype(np.float32)).to(dev())
+    res = {}
+    for lazy in (False, True):
+        prev = set_lazy_softmax(lazy)
+        try:
+            x = logits.clone().requires_grad_()
+            work = x.clone()
+            out_x, match = ops().dag_logsoftmax_gather_inplace(work, tg.unsqueeze(1).expand(-1, L, -1))
+            after_fwd = out_x.detach().clone()
+            (gx,) = torch.autograd.grad((match * w).sum(), [x])
+        finally:
+            set_lazy_softmax(prev)
+        res[lazy] = (match.detach().clone(), gx, after_fwd)
+    assert torch.equal(res[True][0], res[False][0])                       # same kernel, same match
+    assert torch.equal(res[True][2], logits)                              # lazy: logits untouched by the forward
+    eps = {torch.float32: 2e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]   # default mode rounds the stored softmax
+    torch.testing.assert_close(res[True][1].float(), res[False][1].float(), rtol=eps, atol=eps)
