@@ -8,12 +8,13 @@
 //            -> per lane-row 9 ds_read_b128 + 9 dwords of X, a 4-op max tree, 9 group shifts and 36 v_ldexp_f32;
 //               the row head no longer waits for 36 exponents before the first FMA can issue.
 //
-// Exactness: X = ceil(max of the group's four a2) - 100, so V = 2^(a2 - X) lies in (2^99, 2^100] for the largest and is kept
-// down to 2^-120 for the others — a live vertex more than 220 binades under its group's maximum is stored as NaN
-// ("escaped": its exact value is in the a2 row).  The window is scaled against the largest of its nine group exponents:
-// scaled values are <= 2^100 and nothing above 2^-226 of the window maximum is flushed, so a sum S >= 2^-97 has lost at most
-// 36 * 2^-126: exact to fp32.  S < 2^-97, NaN or inf sends the cell to the same register-only "medium" path and then the
-// exact log-space path as in strip4 (both work from the a2 row and the pristine weights).
+// Exactness: X = ceil(max of the group's four a2) - 120, so V = 2^(a2 - X) lies in (2^119, 2^120] for the largest; a vertex more
+// than 246 binades under its group's maximum flushes to 0 in storage — exactly what the window scaling would do to it, the
+// window reference being at least its group's exponent (an earlier version stored such vertices as NaN "escapes": they
+// poisoned every consumer's sums and bought nothing).  The window is shifted (v_ldexp per value) against the largest of its
+// nine group exponents: scaled values are <= 2^120 and nothing above 2^-246 of the window maximum is flushed, so a sum
+// S >= 2^-97 has lost at most 36 * 2^-126: exact to fp32.  S < 2^-97 or inf sends the cell to the register-only "medium" path
+// (own maximum, log-domain row) and then the exact log-space path as in strip4.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,7 @@ constexpr int G4_CH = 4;                      // halo prefetch distance of the f
 constexpr int GNEGSENT = -(1 << 30);       // "dead" exponent; far below any finite fp32 score
 constexpr u32 G4_SPIN_LIMIT = 1u << 22;
 constexpr float G4_LOG2E = 1.4426950408889634f;
+constexpr float G4_BIAS = 120.f;              // stored / scaled values reach 2^120, a row sum of 36 stays under 2^126
 constexpr float G4_LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ u64 g4_gran_load(const u64* p) {
@@ -158,10 +160,10 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                     E[c][d] = __builtin_amdgcn_exp2f(raw[d] - mx);
                     flushed |= (raw[d] != NEG_INF) & (raw[d] - mx < -120.f);
                 }
-                // Such a weight is 0 (or inexact) in fp32, and a scaled window value can be as large as 2^100, so the term it
-                // drops can reach 2^-20: a column that has one only trusts sums that dwarf that; everything else is redone by
+                // Such a weight is 0 (or inexact) in fp32, and a scaled window value can be as large as 2^120, so the term it
+                // drops can reach 2^0: a column that has one only trusts sums that dwarf that; everything else is redone by
                 // the medium path, whose values are <= 1 (dropped terms < 2^-120 against a sum >= 2^-97).
-                sthr[c] = flushed ? 0x1p10f : 0x1p-97f;
+                sthr[c] = flushed ? 0x1p30f : 0x1p-97f;
             } else {
                 lmax[c] = 0.f;
 #pragma unroll
@@ -257,8 +259,8 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                     okc[c] = cell_active(j + c, t);
                     base[c] = lmax[c] + m2[c] * G4_LOG2E;                    // log2(strongest link * emission)
                 }
-                // (2) group exponents landed.  Reference = largest of the nine: groups are stored with a +100 bias (see the
-                // row write), so scaled values reach 2^100 at most (sums < 2^106) and a column whose predecessors all sit up
+                // (2) group exponents landed.  Reference = largest of the nine: groups are stored with a +120 bias (see the
+                // row write), so scaled values reach 2^120 at most (sums < 2^126) and a column whose predecessors all sit up
                 // to ~190 binades under the window maximum still sums to >= 2^-97.  Next to the DP's diagonal neighbouring
                 // vertices are 25-35 binades apart, so this headroom is used on every row.
                 asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67), "+v"(x8));
@@ -267,7 +269,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                 const bool any_live = refi != GNEGSENT;
                 if (!any_live) refi = 0;
                 // group shifts X - ref <= 0, applied to every value with v_ldexp_f32: a group FACTOR 2^(X - ref) would itself
-                // flush below 2^-126 and cut the window at 126 binades although the stored values (bias +100) reach 226
+                // flush below 2^-126 and cut the window at 126 binades although the stored values (bias +120) reach 246
                 int kg[9];
 #pragma unroll
                 for (int g = 0; g < 9; ++g) kg[g] = xw[g] - refi;                 // <= 0; hugely negative for dead groups
@@ -303,7 +305,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const bool okl = okc[c] & any_live;
-                    flag[c] = okl & !(S[c] >= sthr[c] && S[c] <= 0x1p110f);       // too small, NaN (escaped input) or inf
+                    flag[c] = okl & !(S[c] >= sthr[c] && S[c] <= 0x1p126f);       // too small (or inf / NaN)
                     need_fb |= flag[c];
                     a2[c] = (okl & !flag[c]) ? (__builtin_amdgcn_logf(S[c]) + (ref + base[c])) : NEG_INF;
                 }
@@ -315,6 +317,22 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                           p.counters[8 + 4 * slot] = (u32)b | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)t; p.counters[10 + 4 * slot] = (u32)(j + fc);
                           p.counters[11 + 4 * slot] = __float_as_uint(fc == 0 ? S[0] : fc == 1 ? S[1] : fc == 2 ? S[2] : S[3]); }
                     }
+                    // (0) the DP's diagonal cell (vertex = row, counted from the direction's start) has ONE live transition; with
+                    //     peaked scores it sits hundreds of binades under its neighbours and lands here on every row:
+                    //     a2 = a2_prev(predecessor) + log2(weight) + base, no sum.  (A flushed weight leaves the cell flagged.)
+                    bool still = false;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int dl = BETA ? (Lb - Tb + 1 + t - (j + c)) : (j + c - t + 1);
+                        if (flag[c] && dl == 1 && sthr[c] == 0x1p-97f) {
+                            const float ap = Abuf[prv * RL + 4 * l + gqidx<BETA>(c, 1)];
+                            const float e1 = Eval(c, 1);
+                            a2[c] = (e1 > 0.f && ap != NEG_INF) ? (ap + __builtin_amdgcn_logf(e1) + base[c]) : NEG_INF;
+                            flag[c] = false;
+                        }
+                        still |= flag[c];
+                    }
+                  if (still) {
                     // (a) MEDIUM path, registers only: redo the flagged column against ITS OWN maximum (covers windows whose
                     //     four column maxima are > 2^120 apart — the diagonal at large t).  Falls through to the exact
                     //     path only if the column's own sum is still below the exactness threshold.
@@ -330,11 +348,13 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                             // transitions that can be alive at all: next to the DP's diagonal (where this path fires on
                             // peaked scores: the diagonal falls hundreds of binades under its right-hand neighbours) a vertex
                             // has a handful of live predecessors, so the 32 terms are walked in chunks of 8 that the wave skips
+                            // live transitions d_lo .. d_hi: bounded by the diagonal on one side and the reach frontier on the other
                             const int dlim = min(32, max(0, BETA ? (Lb - Tb + 1 + t - (j + c)) : (j + c - t + 1)));
+                            const int dlo = max(1, BETA ? (Lb - 1 - (Tb - 2 - t) * TR - (j + c)) : (j + c - (t - 1) * TR));
                             float cmx = NEG_INF;
 #pragma unroll
                             for (int d0 = 1; d0 <= 32; d0 += 8) {
-                                if (__any(dlim >= d0)) {
+                                if (__any(dlim >= d0 && dlo <= d0 + 7)) {
 #pragma unroll
                                     for (int d = d0; d < d0 + 8; ++d) cmx = fmaxf(cmx, aw[gqidx<BETA>(c, d)]);
                                 }
@@ -342,7 +362,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                             float sc = 0.f;
 #pragma unroll
                             for (int d0 = 1; d0 <= 32; d0 += 8) {
-                                if (__any(dlim >= d0)) {
+                                if (__any(dlim >= d0 && dlo <= d0 + 7)) {
 #pragma unroll
                                     for (int d = d0; d < d0 + 8; ++d)
                                         sc = fmaf(__builtin_amdgcn_exp2f(aw[gqidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
@@ -393,21 +413,21 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                         }
                         if (c == 0) a2[0] = r; else if (c == 1) a2[1] = r; else if (c == 2) a2[2] = r; else a2[3] = r;
                     }
+                  }
                 }
 
             }
             // ---- write the row: LDS state for the next row, HBM output ----
             {
-                // group exponent X = ceil(largest of the four) - 100, so V = 2^(a2 - X) spans (2^-120, 2^100]: a live vertex more
-                // than 220 binades below its group's maximum is "escaped" (NaN; its exact value is in the a2 row)
+                // group exponent X = ceil(largest of the four) - 120, so V = 2^(a2 - X) spans [2^-126, 2^120]
                 const float amax = fmaxf(fmaxf(a2[0], a2[1]), fmaxf(a2[2], a2[3]));
                 const bool dead = amax == NEG_INF;
-                const float cf = dead ? 0.f : ceilf(amax) - 100.f;
+                const float cf = dead ? 0.f : ceilf(amax) - G4_BIAS;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float e = a2[c] - cf;
                     const float v = __builtin_amdgcn_exp2f(e);
-                    vn[c] = (e < -120.f && e != NEG_INF) ? __builtin_nanf("") : v;
+                    vn[c] = v;                 // flushes to 0 more than 246 binades under the group maximum — as the scaling would
                 }
                 xn = dead ? GNEGSENT : (int)cf;
             }
@@ -496,12 +516,12 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                     float gm = fmaxf(hv, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hv), 0xB1, 0xF, 0xF, false)));
                     gm = fmaxf(gm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gm), 0x4E, 0xF, 0xF, false)));
                     const bool dead = gm == NEG_INF;
-                    const float cf = dead ? 0.f : ceilf(gm) - 100.f;
+                    const float cf = dead ? 0.f : ceilf(gm) - G4_BIAS;
                     const float e = hv - cf;
                     const float v = __builtin_amdgcn_exp2f(e);
                     if (hl) {
                         Abuf[cur * RL + halo_li0 + lane] = hv;
-                        Vbuf[cur * RL + halo_li0 + lane] = (e < -120.f && e != NEG_INF) ? __builtin_nanf("") : v;
+                        Vbuf[cur * RL + halo_li0 + lane] = v;
                         if ((lane & 3) == 0) Xbuf[cur * GL + (halo_li0 >> 2) + (lane >> 2)] = dead ? GNEGSENT : (int)cf;
                     }
                 }

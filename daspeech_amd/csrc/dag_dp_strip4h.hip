@@ -264,7 +264,7 @@ __device__ __forceinline__ void strip4h_compute(const HCtx& x, const float* tile
             for (int c = 0; c < 4; ++c) {
                 const float e = a2[c] - cf;
                 const float v = __builtin_amdgcn_exp2f(e);
-                vn[c] = (e < -120.f && e != NEG_INF) ? __builtin_nanf("") : v;
+                vn[c] = v;                 // flushes to 0 more than 226 binades under the group maximum — as the scaling would
             }
             *reinterpret_cast<float4*>(Vbuf + cur * RL + own_li0 + 4 * l) = make_float4(vn[0], vn[1], vn[2], vn[3]);
             Xbuf[cur * GL + (own_li0 >> 2) + l] = dead ? HNEGSENT : (int)cf;
@@ -418,7 +418,7 @@ __device__ __forceinline__ void strip4h_body(const HStripParams& p, char* smem_r
                     const float v = __builtin_amdgcn_exp2f(e);
                     if (hl) {
                         Abuf[cur * RL + halo_li0 + lane] = hv;
-                        Vbuf[cur * RL + halo_li0 + lane] = (e < -120.f && e != NEG_INF) ? __builtin_nanf("") : v;
+                        Vbuf[cur * RL + halo_li0 + lane] = v;
                         if ((lane & 3) == 0) Xbuf[cur * GL + (halo_li0 >> 2) + (lane >> 2)] = dead ? HNEGSENT : (int)cf;
                     }
                 }

@@ -39,3 +39,14 @@ def run(a, b):
 _lib.set_option("dp_path", 5)
 print("path 5 alpha-only %.3f ms | beta-only %.3f ms | both %.3f ms" % (timeit(lambda: run(alpha, None))[0], timeit(lambda: run(None, beta))[0], timeit(lambda: run(alpha, beta))[0]))
 _lib.set_option("dp_path", 0)
+
+# backward and alignment on the same data
+import ctypes
+kg = links.clone().requires_grad_()
+loss = ops.dag_loss(mg, kg, ol, tl)
+diag = (ctypes.c_uint * 4)(); lib.dsp_dag_debug_k5(diag)
+tb = timeit(lambda: torch.autograd.grad(loss.sum(), [mg, kg], retain_graph=True))
+lib.dsp_dag_debug_k5(diag)
+with torch.no_grad():
+    ta = timeit(lambda: ops.dag_best_alignment(match, links, ol, tl))
+print("dag_loss backward %.3f ms (exp-space K5 lanes redone exactly: %d) | best_alignment %.3f ms" % (tb[0], diag[0], ta[0]))
