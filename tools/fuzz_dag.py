@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the DAG ops against the CPU oracle (GPU box only).  usage: fuzz_dag.py [n_cases] [seed]
+Shapes, ragged lengths, -inf emissions, peaked transitions and unreachable samples are drawn at random; alpha / beta / loss /
+gradients are compared with the fp64 oracle, Viterbi paths bit-exactly with the fp32 oracle."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from util_inputs import make_dag_inputs
+from oracle import dag_oracle as orc
+from daspeech_amd import _lib, custom_ops as ops
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda")
+bad = 0
+for case in range(n):
+    B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32]))
+    L = int(rng.integers(2, 1500)); 
+    if rng.random() < 0.6: L = max(4, L // 4 * 4)
+    TR = min(TR, L - 1) if L > 1 else 1
+    Tmin = max(2, (L - 1 + TR - 1) // TR + 1) if rng.random() < 0.8 else 2      # mostly reachable ends
+    T = int(min(L, rng.integers(Tmin, Tmin + 40)))
+    if T < 2 or TR < 1: continue
+    match, links, ol, tl = make_dag_inputs(int(rng.integers(1 << 30)), B, T, L, TR, match_scale=float(rng.choice([0.5, 2.0, 6.0])))
+    if rng.random() < 0.5:        # peaked transitions
+        links = np.where(np.isfinite(links), links * float(rng.choice([2.0, 4.0])), links)
+        mx = np.max(np.where(np.isfinite(links), links, -1e30), -1, keepdims=True)
+        ssum = np.where(np.isfinite(links), np.exp(links - mx), 0).sum(-1, keepdims=True)
+        links = np.where(np.isfinite(links), links - mx - np.log(np.where(ssum > 0, ssum, 1)), links).astype(np.float32)
+    if rng.random() < 0.4:        # a few -inf emissions
+        mask = rng.random(match.shape) < 0.02
+        match = np.where(mask, -np.inf, match).astype(np.float32)
+    m = torch.from_numpy(match).to(dev).requires_grad_(); k = torch.from_numpy(links).to(dev).requires_grad_()
+    o = torch.from_numpy(ol).to(dev); t = torch.from_numpy(tl).to(dev)
+    tag = f"case {case}: B={B} T={T} L={L} TR={TR}"
+    try:
+        loss, (alpha, beta) = ops.dag_loss_with_alpha_beta(m, k, o, t)
+        assert _lib.last_launch_status() == 0, "launch status"
+        a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+        a = alpha.detach().cpu().numpy(); b = beta.detach().cpu().numpy()
+        assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), "-inf pattern"
+        fa = np.isfinite(a64); fb = np.isfinite(b64)
+        np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=3e-5 * T)
+        np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=3e-5 * T)
+        fin = torch.isfinite(loss)
+        if fin.any():
+            gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
+            gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+            gt = max(3e-3, 2e-5 * T)           # exp() of sums carrying fp32 rounding of T rows
+            np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=gt, atol=2e-7)
+            np.testing.assert_allclose(gl.cpu().numpy(), gl64, rtol=gt, atol=2e-7)
+        path = ops.dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+        ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+        assert np.array_equal(path, ref), "Viterbi path"
+    except Exception as e:       # noqa
+        bad += 1
+        print("FAIL", tag, "->", str(e).splitlines()[0][:200])
+print(f"{n} cases, {bad} failures")
