@@ -48,6 +48,7 @@ SIGNATURES = {
     # include/daspeech_hifigan.h
     "dsp_hifigan_conv": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.c_float, ctypes.c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_conv_chain": (_c_int, [_c_p, _c_int, _c_int, _c_p]),
     "dsp_hifigan_pack_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
     "dsp_dag_alignment_trace_optional": (_c_int, [_c_int, _c_int]),

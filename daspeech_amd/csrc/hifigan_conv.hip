@@ -221,9 +221,9 @@ __global__ __launch_bounds__(256) void hg_post_kernel(const _Float16* __restrict
 
 using namespace dsp;
 
-extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias, const void* res, void* out,
-                                int B, int T, int CI, int M, int ntaps, const int* host_shifts, float pre_slope, float scale,
-                                int out_mode, int up_u, int up_pad, int Tout, int Cout, dsp_stream_t stream)
+static int hg_conv_one(const void* x, const void* w, const float* bias, const void* res, void* out,
+                       int B, int T, int CI, int M, int ntaps, const int* host_shifts, float pre_slope, float scale,
+                       int out_mode, int up_u, int up_pad, int Tout, int Cout, hipStream_t st)
 {
     if (B < 0 || T < 1 || M < 1 || ntaps < 1 || ntaps > DSP_HG_MAX_TAPS || !host_shifts) { set_error("hifigan_conv: bad sizes"); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
@@ -234,10 +234,9 @@ extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias,
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.res = (const _Float16*)res; p.out = (_Float16*)out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.Tout = Tout; p.Cout = Cout; p.out_mode = out_mode; p.up_u = up_u; p.up_pad = up_pad;
     p.pre_slope = pre_slope; p.scale = scale;
-    { const char* ab = getenv("HG_ABLATE"); p.dbg = ab ? atoi(ab) : 0; }
+    { static int ablate = -1; if (ablate < 0) { const char* ab = getenv("HG_ABLATE"); ablate = ab ? atoi(ab) : 0; } p.dbg = ablate; }
     p.min_shift = p.max_shift = host_shifts[0];
     for (int k = 0; k < ntaps; ++k) { p.shifts[k] = host_shifts[k]; p.min_shift = min(p.min_shift, host_shifts[k]); p.max_shift = max(p.max_shift, host_shifts[k]); }
-    hipStream_t st = as_stream(stream);
     switch (CI) {
         case 512: return hg_launch<512, 256, 128, 8, 1>(p, st);
         case 256: return hg_launch<256, 256, 128, 8, 1>(p, st);
@@ -248,6 +247,29 @@ extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias,
     }
     set_error("hifigan_conv: unsupported input channel count %d", CI);
     return DSP_EINVAL;
+}
+
+extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias, const void* res, void* out,
+                                int B, int T, int CI, int M, int ntaps, const int* host_shifts, float pre_slope, float scale,
+                                int out_mode, int up_u, int up_pad, int Tout, int Cout, dsp_stream_t stream)
+{
+    return hg_conv_one(x, w, bias, res, out, B, T, CI, M, ntaps, host_shifts, pre_slope, scale, out_mode, up_u, up_pad, Tout, Cout,
+                       as_stream(stream));
+}
+
+// The generator is ~100 of these layers per call; driven one ctypes call at a time the host, not the GPU, sets the pace at
+// vocoder batch sizes.  One call walks a whole layer table.
+extern "C" int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream)
+{
+    if (n_layers < 0 || (n_layers > 0 && !layers)) { set_error("hifigan_conv_chain: bad layer table"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < n_layers; ++i) {
+        const dsp_hg_layer& l = layers[i];
+        int rc = hg_conv_one(l.x, l.w, l.bias, l.res, l.out, B, l.T, l.CI, l.M, l.ntaps, l.shifts, l.pre_slope, l.scale,
+                             l.out_mode, l.up_u, l.up_pad, l.Tout, l.Cout, st);
+        if (rc) return rc;
+    }
+    return DSP_OK;
 }
 
 extern "C" int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, int C, int Cpad, dsp_stream_t stream)

@@ -16,6 +16,17 @@ from torch import Tensor
 from . import _lib
 
 OUT_STORE, OUT_ACCUM, OUT_UPSAMPLE = 0, 1, 2
+MAX_TAPS = 16
+
+
+class HgLayerDesc(ctypes.Structure):          # include/daspeech_hifigan.h: dsp_hg_layer
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("out", ctypes.c_void_p),
+                ("T", ctypes.c_int), ("CI", ctypes.c_int), ("M", ctypes.c_int), ("ntaps", ctypes.c_int),
+                ("shifts", ctypes.c_int * MAX_TAPS),
+                ("pre_slope", ctypes.c_float), ("scale", ctypes.c_float),
+                ("out_mode", ctypes.c_int), ("up_u", ctypes.c_int), ("up_pad", ctypes.c_int), ("Tout", ctypes.c_int),
+                ("Cout", ctypes.c_int)]
 
 
 class _Layer:
@@ -44,6 +55,7 @@ class HiFiGANHipRunner:
         self.post_w = cp.weight.detach()[0].t().contiguous().float()          # [K][C]
         self.post_b = float(cp.bias.detach()[0])
         self.post_k = cp.weight.shape[2]
+        self._plans = {}
 
     def _conv_layer(self, m, ci_pad=None):
         L = _Layer()
@@ -85,41 +97,70 @@ class HiFiGANHipRunner:
         _lib.check(rc, "dsp_hifigan_conv")
         return out
 
+    # ---- one layer table per input shape -----------------------------------------------------------------------
+    # Generator.forward unrolled into ~100 dsp_hg_layer records over ONE fp16 workspace; the table (and its workspace) is
+    # cached per (B, T), so a repeated shape costs three ctypes calls: pack, chain, post.
+    def _plan(self, B: int, T: int, dev):
+        key = (B, T)
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        sizes, recs = [], []            # buffer sizes in halves; records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale)
+
+        def new_buf(t, c):
+            sizes.append(B * t * c)
+            return len(sizes) - 1
+        x = new_buf(T, self.in_pad)
+        t = T
+        y = new_buf(t, self.pre.Cout); recs.append((self.pre, x, None, y, t, 1.0, None, 1.0)); x = y
+        for i, up in enumerate(self.ups):
+            y = new_buf(t * up.u, up.Cout); recs.append((up, x, None, y, t, 0.1, None, 1.0)); x = y; t = t * up.u
+            acc = None
+            for j in range(self.nk):
+                yb = x
+                units = self.blocks[i * self.nk + j]
+                for n, (c1, c2) in enumerate(units):
+                    h = new_buf(t, c1.Cout); recs.append((c1, yb, None, h, t, 0.1, None, 1.0))
+                    if n + 1 < len(units):
+                        o = new_buf(t, c2.Cout); recs.append((c2, h, yb, o, t, 0.1, None, 1.0)); yb = o
+                    elif acc is None:
+                        acc = new_buf(t, c2.Cout); recs.append((c2, h, yb, acc, t, 0.1, None, 1.0 / self.nk))
+                    else:
+                        recs.append((c2, h, yb, acc, t, 0.1, OUT_ACCUM, 1.0 / self.nk))
+            x = acc
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot); tot += (sz + 63) // 64 * 64          # 128-byte aligned buffers
+        ws = torch.empty((tot,), dtype=torch.float16, device=dev)
+        base = ws.data_ptr()
+        table = (HgLayerDesc * len(recs))()
+        for d, (L, xb, rb, ob, tt, slope, mode, scale) in zip(table, recs):
+            d.x = base + 2 * offs[xb]; d.res = (base + 2 * offs[rb]) if rb is not None else None; d.out = base + 2 * offs[ob]
+            d.w = L.w.data_ptr(); d.bias = L.bias.data_ptr() if L.bias is not None else None
+            d.T, d.CI, d.M, d.ntaps = tt, L.CI, L.M, L.ntaps
+            for k, sh in enumerate(L.shifts):
+                d.shifts[k] = sh
+            d.pre_slope, d.scale = slope, scale
+            d.out_mode = L.mode if mode is None else mode
+            d.up_u, d.up_pad, d.Tout, d.Cout = L.u, L.pad, (tt * L.u if L.mode == OUT_UPSAMPLE else tt), L.Cout
+        plan = (ws, table, base + 2 * offs[0], base + 2 * offs[x], t, sizes[x] // (B * t))
+        if len(self._plans) >= 32:
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = plan
+        return plan
+
     @torch.no_grad()
     def __call__(self, mel: Tensor) -> Tensor:
         """mel [B, 80, T] fp32 -> waveform [B, 1, T*hop] fp32."""
         lib = _lib.load()
         B, C, T = mel.shape
         with torch.cuda.device(mel.device):
+            ws, table, x_in, x_last, Tw, Cl = self._plan(B, T, mel.device)
+            st = _lib.current_stream_handle()
             mt = mel.detach().float().transpose(1, 2).contiguous()
-            x = torch.empty((B, T, self.in_pad), dtype=torch.float16, device=mel.device)
-            _lib.check(lib.dsp_hifigan_pack_input(_lib.ptr(mt), _lib.ptr(x), B, T, C, self.in_pad, _lib.current_stream_handle()),
-                       "dsp_hifigan_pack_input")
-            x = self._run(self.pre, x, 1.0)
-            for i, up in enumerate(self.ups):
-                x = self._run(up, x, 0.1)                                           # lrelu(0.1) -> ConvTranspose1d
-                acc = None
-                for j in range(self.nk):
-                    y = x
-                    units = self.blocks[i * self.nk + j]
-                    for n, (c1, c2) in enumerate(units):
-                        h = self._run(c1, y, 0.1)
-                        if n + 1 < len(units):
-                            y = self._run(c2, h, 0.1, res=y)
-                        elif acc is None:                                           # last unit: fold the MRF mean in
-                            acc = self._run(c2, h, 0.1, res=y, scale=1.0 / self.nk)
-                        else:
-                            self._run(c2, h, 0.1, res=y, out=acc, mode=OUT_ACCUM, scale=1.0 / self.nk)
-                x = acc
-            Tw = x.shape[1]
+            _lib.check(lib.dsp_hifigan_pack_input(_lib.ptr(mt), ctypes.c_void_p(x_in), B, T, C, self.in_pad, st), "dsp_hifigan_pack_input")
+            _lib.check(lib.dsp_hifigan_conv_chain(table, len(table), B, st), "dsp_hifigan_conv_chain")
             wav = torch.empty((B, Tw), dtype=torch.float32, device=mel.device)
-            _lib.check(lib.dsp_hifigan_post(_lib.ptr(x), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, x.shape[2], self.post_k,
-                                            0.01, _lib.current_stream_handle()), "dsp_hifigan_post")
+            _lib.check(lib.dsp_hifigan_post(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl, self.post_k,
+                                            0.01, st), "dsp_hifigan_post")
         return wav.unsqueeze(1)
-
-
-def lrelu_conv1d(*a, **k):          # pragma: no cover - per-layer entry points are not used; the runner owns the whole stack
-    raise NotImplementedError("use HiFiGANHipRunner")
-
-
-lrelu_conv_transpose1d = lrelu_conv1d

@@ -32,6 +32,17 @@ int dsp_hifigan_conv(const void* x, const void* w, const float* bias, const void
                      int B, int T, int CI, int M, int ntaps, const int* host_shifts, float pre_slope, float scale,
                      int out_mode, int up_u, int up_pad, int Tout, int Cout, dsp_stream_t stream);
 
+/* A table of such layers launched back to back on one stream (the generator is ~100 of them per call: Generator.forward,
+ * hifi-gan/models.py:100-119, unrolled by the host once per input shape).  Same arguments as dsp_hifigan_conv, per layer. */
+typedef struct dsp_hg_layer {
+    const void* x; const void* w; const float* bias; const void* res; void* out;
+    int T, CI, M, ntaps;
+    int shifts[DSP_HG_MAX_TAPS];
+    float pre_slope, scale;
+    int out_mode, up_u, up_pad, Tout, Cout;
+} dsp_hg_layer;
+int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream);
+
 /* fp32 [B,T,C] -> fp16 [B,T,Cpad] zero padded channels (mel input) */
 int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, int C, int Cpad, dsp_stream_t stream);
 
