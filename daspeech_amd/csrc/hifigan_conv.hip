@@ -242,7 +242,8 @@ static int hg_conv_one(const void* x, const void* w, const float* bias, const vo
         case 256: return hg_launch<256, 256, 128, 8, 1>(p, st);
         case 128: return hg_launch<128, 128, 256, 4, 2>(p, st);
         case 96:  return hg_launch<96, 256, 128, 8, 1>(p, st);
-        case 64:  return hg_launch<64, 64, 256, 2, 4>(p, st);
+        case 64:  return hg_launch<64, 64, 512, 2, 4>(p, st);      // 512-column tiles: 12.1 vs 13.0 ms per B=32 pass (sweep r01e;
+                                                                    // 64x64 wave tiles, and larger tiles for C = 32 / 128 / 256, were slower or equal)
         case 32:  return hg_launch<32, 32, 512, 1, 8>(p, st);
     }
     set_error("hifigan_conv: unsupported input channel count %d", CI);
