@@ -129,7 +129,7 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
 {
-    return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 12288) ? 1 : 0;
+    return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 8192) ? 1 : 0;
 }
 
 extern "C" int dsp_dag_set_option(const char* name, int value)

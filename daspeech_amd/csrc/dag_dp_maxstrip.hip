@@ -414,7 +414,7 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR)
 {
     if (TR > 32 || (L & 3)) return false;
-    if (L > 12288) return false;                               // back-trace: path image + transition window in LDS
+    if (L > 8192) return false;                                // back-trace: path image (4L) + transition window (96 KB) + segments (25 KB) in LDS
     const uintptr_t a = (uintptr_t)match | (uintptr_t)alpha_max;
     return (a & 15) == 0;
 }

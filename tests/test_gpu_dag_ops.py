@@ -457,3 +457,21 @@ def test_lazy_softmax_mode_same_match_and_gradient(dtype, V):
     assert torch.equal(res[True][2], logits)                              # lazy: logits untouched by the forward
     eps = {torch.float32: 2e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]   # default mode rounds the stored softmax
     torch.testing.assert_close(res[True][1].float(), res[False][1].float(), rtol=eps, atol=eps)
+
+
+@pytest.mark.parametrize("L", [8192, 8196])
+def test_alignment_large_graph_properties(L):
+    """The largest graph the trace-free alignment takes (L = 8192: path image + transition window + segments fill the LDS) and
+    the first size past it (eager trace kernels): the path must be a valid monotone alignment with the Viterbi score."""
+    B, T, TR = 2, 300, 32
+    match, links, ol, tl = make_dag_inputs(5 + L, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    path = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
+    for b in range(B):
+        pos = np.nonzero(path[b] >= 0)[0]
+        Tb, Lb = int(tl[b]), int(ol[b])
+        assert len(pos) == Tb and pos[0] == 0 and pos[-1] == Lb - 1
+        assert np.array_equal(path[b][pos], np.arange(Tb))
+        assert np.all(np.diff(pos) >= 1) and np.all(np.diff(pos) <= TR)
+    ref = orc.dag_best_alignment(match[:1], links[:1], ol[:1], tl[:1], np.float32)
+    np.testing.assert_array_equal(path[:1], ref)
