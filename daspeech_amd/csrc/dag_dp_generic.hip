@@ -9,6 +9,7 @@
 // Replaces: calculate_alpha_kernel (dag_loss.cu:40-140), calculate_beta_kernel (:178-274),
 //           calculate_maxalpha_kernel (dag_best_alignment.cu:39-130), calculate_backtrace_kernel (:170-206).
 #include "common.h"
+#include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -251,13 +252,20 @@ template <int MODE>      // 0: log-sum (alpha, or beta when blockIdx.y == 1 / al
 __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
     const float* __restrict__ match, const float* __restrict__ links, const float* __restrict__ incoming,
     const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-    float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ trace, int B, int T, int L, int TR)
+    float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ trace, int B, int T, int L, int TR,
+    unsigned int* __restrict__ row_count, unsigned long long* __restrict__ gran, unsigned int tag_base)
 {
+    // gridDim.z = NS workgroups share one (sample, direction): workgroup s takes every NS-th group of NW*4 columns of a row
+    // (interleaved: the work per column grows with the column index), writes its cells straight to the output row in HBM,
+    // and publishes them in a tagged hand-off row from which all NS workgroups re-read the complete row into LDS.
+    // The launcher keeps B * ndir * NS within what is co-resident (the hand-off spins), and the spin is bounded.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* prev = smem;
     float* cur = smem + L;
     int* carg = reinterpret_cast<int*>(smem + 2 * L);          // MODE 1: argmax row
     const int b = blockIdx.x;
+    const int NS = gridDim.z, slice = blockIdx.z;
+    unsigned int* err = row_count + 1;                                              // the strip kernels' status word (dsp_dag_last_launch_status)
     const bool do_beta = (MODE == 0) && ((alpha == nullptr) ? true : (blockIdx.y == 1));
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const float* M = match + (size_t)b * T * L;
@@ -266,16 +274,20 @@ __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = DP_THREADS / 64;
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
-    for (int t = valid ? Tb : 0; t < T; ++t)
+    for (int t = (valid ? Tb : 0) + slice; t < T; t += NS)
         for (int j = tid; j < L; j += DP_THREADS) { O[(size_t)t * L + j] = NEG_INF; if (MODE == 1) Tr[(size_t)t * L + j] = -1; }
     if (!valid) return;
-    {   // seed row
+    {   // seed row (every workgroup keeps it in LDS; slice 0 writes it out)
         const int t = do_beta ? Tb - 1 : 0;
         for (int j = tid; j < L; j += DP_THREADS) {
             const float v = (do_beta ? (j == Lb - 1) : (j == 0)) ? M[(size_t)t * L + j] : NEG_INF;
-            prev[j] = v; O[(size_t)t * L + j] = v; if (MODE == 1) Tr[(size_t)t * L + j] = -1;
+            prev[j] = v;
+            if (slice == 0) { O[(size_t)t * L + j] = v; if (MODE == 1) Tr[(size_t)t * L + j] = -1; }
         }
     }
+    __syncthreads();
+    __shared__ unsigned int s_abort;                 // set by a thread whose hand-off poll timed out: the workgroup gives up
+    if (tid == 0) s_abort = 0;
     __syncthreads();
     for (int it = 1; it < Tb; ++it) {
         const int t = do_beta ? (Tb - 1 - it) : it;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
         // QUARTER-WAVE per column: 16 lanes split the predecessor distance d, 4 columns per wave in flight; the per-column
         // reduction is 4 DPP steps inside a 16-lane row (no LDS permutes).
         const int q = lane >> 4, l16 = lane & 15;
-        for (int jb = t + (wave * 4); jb < Lb; jb += NW * 4) {
+        for (int jb = t + ((slice * NW + wave) * 4); jb < Lb; jb += NS * NW * 4) {
             const int j = jb + q;
             const bool live = j < Lb;
             const int maxd = live ? (do_beta ? min(Lb - 1 - j, TR) : min(j, TR)) : 0;
@@ -353,12 +365,43 @@ __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
             }
         }
         __syncthreads();
-        for (int j = tid; j < L; j += DP_THREADS) {               // coalesced row store
-            O[(size_t)t * L + j] = cur[j];
-            if (MODE == 1) Tr[(size_t)t * L + j] = carg[j];
+        if (NS == 1) {
+            for (int j = tid; j < L; j += DP_THREADS) {               // coalesced row store
+                O[(size_t)t * L + j] = cur[j];
+                if (MODE == 1) Tr[(size_t)t * L + j] = carg[j];
+            }
+            __syncthreads();
+            float* tmp = prev; prev = cur; cur = tmp;
+        } else {
+            // own cells -> HBM output, and -> the hand-off row as 8-byte {tag, value} granules (agent-scope relaxed stores: a
+            // granule is valid exactly when its tag says so — no fence, no counter; cdna_hip_programming.md G16 R2).  Two
+            // hand-off rows alternate: a workgroup can only write row it+1 after it has read all of row it.
+            unsigned long long* G = gran + ((size_t)(b * gridDim.y + blockIdx.y) * 2 + (it & 1)) * L;
+            const unsigned int tag = tag_base + (unsigned int)it;
+            for (int j = tid; j < L; j += DP_THREADS) {
+                const int grp = (j - t) >> 2;                                       // 4-column group index along the row
+                const bool mine = (j < t) ? (slice == 0) : (j >= Lb ? (slice == 0) : ((grp / NW) % NS == slice));
+                if (mine) {
+                    const float v = cur[j];
+                    O[(size_t)t * L + j] = v; if (MODE == 1) Tr[(size_t)t * L + j] = carg[j];
+                    __hip_atomic_store(G + j, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // the complete row, all workgroups' cells
+            for (int j = tid; j < L; j += DP_THREADS) {
+                unsigned long long x = __hip_atomic_load(G + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned int spins = 0;
+                while ((unsigned int)(x >> 32) != tag) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(G + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 18)) { atomicOr(err, 2u); s_abort = 1u; break; }
+                }
+                prev[j] = __uint_as_float((unsigned int)x);
+            }
+            __syncthreads();
+            if (s_abort) return;                     // every workgroup of the launch times out once at most (status word says so)
         }
-        __syncthreads();
-        float* tmp = prev; prev = cur; cur = tmp;
     }
 }
 
@@ -392,6 +435,30 @@ int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t
     return check_launch("dag_best_alignment(back-trace)");
 }
 
+int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, unsigned int** counters, unsigned long long** halo, unsigned int* tag_base);
+
+// how many workgroups may share one (sample, direction): everything the launch puts on the device must be co-resident (the
+// per-row hand-off spins), with a factor 2 of slack for whatever else is running
+template <typename K>
+static int dense_slices(K kernel, size_t lds, int groups, int L)
+{
+    static int forced = -1;                      // DSP_DENSE_NS: sweeps only — the co-residency bound below still applies
+    if (forced < 0) { const char* e = getenv("DSP_DENSE_NS"); forced = e ? atoi(e) : 0; }
+    int nb = 0, dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, DP_THREADS, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); return 1; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); return 1; }
+    // one workgroup per CU is assumed whatever the occupancy query says (it has over-reported for this launch shape, §5 census),
+    // and a quarter of the CUs is left to whatever else is running: a launch that is not co-resident would time out
+    (void)nb;
+    int ns = (int)(((long)cus * 3 / 4) / (groups > 0 ? groups : 1));
+    const int by_cols = L / (4 * (DP_THREADS / 64));               // at least one 64-column round per workgroup and row
+    if (ns > by_cols) ns = by_cols;
+    if (ns > 32) ns = 32;
+    if (forced > 0 && forced < ns) ns = forced;
+    return ns < 1 ? 1 : ns;
+}
+
 int launch_dag_fwd_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                            float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
 {
@@ -403,8 +470,12 @@ int launch_dag_fwd_generic(const float* match, const float* links, const int64_t
         const float* in = alpha ? incoming_links(links, B, L, TR, st) : links;
         if (in) {
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
-                               alpha, beta, (int32_t*)nullptr, B, T, L, TR);
+            const int NS = dense_slices(dag_dense_kernel<0>, lds, B * ndir, L);
+            unsigned int* cnt = nullptr; unsigned long long* gran = nullptr; unsigned int tag_base = 0;
+            int rcw = banded_acquire_ws(st, (size_t)B * ndir * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);
+            if (rcw) return rcw;
+            hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir, NS), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
+                               alpha, beta, (int32_t*)nullptr, B, T, L, TR, cnt, gran, tag_base);
             return check_launch("dag_loss_fwd(dense)");
         }
     }
@@ -433,8 +504,12 @@ int launch_best_alignment_generic(const float* match, const float* links, const 
         const size_t lds3 = 3 * (size_t)L * sizeof(float);
         if (in && lds3 <= 160 * 1024) {
             if (lds3 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            hipLaunchKernelGGL(dag_dense_kernel<1>, dim3(B, 1), dim3(DP_THREADS), lds3, st, match, links, in, out_len, tgt_len,
-                               alpha, (float*)nullptr, trace, B, T, L, TR);
+            const int NS = dense_slices(dag_dense_kernel<1>, lds3, B, L);
+            unsigned int* cnt = nullptr; unsigned long long* gran = nullptr; unsigned int tag_base = 0;
+            int rcw = banded_acquire_ws(st, (size_t)B * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);
+            if (rcw) return rcw;
+            hipLaunchKernelGGL(dag_dense_kernel<1>, dim3(B, 1, NS), dim3(DP_THREADS), lds3, st, match, links, in, out_len, tgt_len,
+                               alpha, (float*)nullptr, trace, B, T, L, TR, cnt, gran, tag_base);
             int rc2 = check_launch("dag_best_alignment(dense)");
             if (rc2) return rc2;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
