@@ -39,12 +39,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tr", type=int, default=32, help="transition window (32 = tuner default, 4095 = README flag)")
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 64 for s2tt, BASELINE configs[2])")
     ap.add_argument("--graph-len", type=int, default=4096)
     ap.add_argument("--tgt-len", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=8192)
-    ap.add_argument("--workload", default="dag", choices=["dag", "s2st", "train"],
-                    help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2st = C4 full fbank->waveform pipeline; "
+    ap.add_argument("--workload", default="dag", choices=["dag", "s2tt", "s2st", "train"],
+                    help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2tt = C3 speech-to-text forward + graph decode; s2st = C4 full fbank->waveform pipeline; "
                          "train = C5 DASpeech training step (s2s_dag_fastspeech2_loss + flat-bucket gradient all-reduce)")
     ap.add_argument("--vocoder-backend", default="hip", choices=["torch", "hip"])
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
@@ -52,7 +52,10 @@ def parse():
                          "default fp32, the mode the mel parity (<= 1e-4) is stated for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.workload == "s2tt" else 32
+    return args
 
 
 def cpu_baseline(args):
@@ -84,11 +87,11 @@ def run_model_workload(args, torch, dist, dev, world, rank):
     from daspeech_amd.distributed import all_reduce_gradients
     from daspeech_amd.generator import S2SNATGenerator
     from daspeech_amd.models import HiFiGANGenerator
-    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model, S2TConformerDAGModel
     from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
     torch.manual_seed(1234)
     B = args.batch
-    model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev)
+    model = calibrate_synthetic_weights(S2TConformerDAGModel() if args.workload == "s2tt" else S2SConformerDAGFastSpeech2Model()).to(dev)
     batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
     args.warmup = max(args.warmup, 2 * len(batches))     # MIOpen/hipBLASLt pick algorithms per new shape: keep that out of the timing
 
@@ -98,13 +101,24 @@ def run_model_workload(args, torch, dist, dev, world, rank):
         torch.cuda.synchronize()
 
     extra = {}
-    if args.workload == "s2st":
+    amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
+    if args.workload == "s2tt":
+        model.eval()
+
+        @torch.no_grad()
+        def step(i):
+            ni = batches[i % len(batches)]["net_input"]
+            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                enc = model.forward_encoder(ni["src_tokens"], ni["src_lengths"])
+                prev = model.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
+                return model.forward_decoder(prev, enc)["output_tokens"]
+        wl = (f"C3 S2TT full forward (s2t_conformer_dag): Conformer(12L,256) -> DA-Transformer(4L,512) + fused links -> HIP lookahead "
+              f"graph decode to tokens, B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast"))
+    elif args.workload == "s2st":
         model.eval()
         voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
         gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev))
         frames = [0]
-
-        amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
 
         def step(i):
             with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
@@ -153,7 +167,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
     result = {
         "metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("f32" if args.amp == "none" else args.amp) if args.workload == "s2st" else ("bf16" if args.amp == "bf16" else "fp16"), "data": "synthetic",
+        "vs_baseline": None, "dtype": ("f32" if args.amp == "none" else args.amp) if args.workload in ("s2st", "s2tt") else ("bf16" if args.amp == "bf16" else "fp16"), "data": "synthetic",
         "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"dp{world}", **extra},
         "roofline": None, "cpu_baseline": None,
     }

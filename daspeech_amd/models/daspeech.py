@@ -299,17 +299,6 @@ class S2TConformerDAGModel(nn.Module):
                              "features": feats, "nll_loss": True},
                 "links": links, "prev_output_tokens": prev_output_tokens}
 
-
-class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
-    """registered name: s2s_conformer_dag_fastspeech2"""
-
-    def __init__(self, **kw):
-        tts_kw = kw.pop("tts", {})
-        super().__init__(**kw)
-        a = self.args
-        self.tts = FastSpeech2NoEmb(**tts_kw)
-        self.adaptor = FFNAdapter(a.decoder_embed_dim, a.adaptor_ffn_dim, self.tts.args.embed_dim)
-
     @torch.no_grad()
     def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]):
         """Graph decode on the GPU: lookahead / greedy (s2s_conformer_dag_fastspeech2.py:194-243) through the HIP decode ops, viterbi /
@@ -324,3 +313,14 @@ class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
         toks, ofeat, mask, lens = decode_ops.graph_decode(logits, links, feats, out_len, self.pad, self.args.decode_beta,
                                                           self.args.decode_strategy)
         return {"output_tokens": toks, "features": ofeat, "features_padding_mask": mask, "feature_lengths": lens}
+
+
+class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
+    """registered name: s2s_conformer_dag_fastspeech2"""
+
+    def __init__(self, **kw):
+        tts_kw = kw.pop("tts", {})
+        super().__init__(**kw)
+        a = self.args
+        self.tts = FastSpeech2NoEmb(**tts_kw)
+        self.adaptor = FFNAdapter(a.decoder_embed_dim, a.adaptor_ffn_dim, self.tts.args.embed_dim)

@@ -58,7 +58,8 @@ def calibrate_synthetic_weights(model, mean_jump: float = 6.5, frames_per_phonem
     model.synthetic_token_cycle = 97           # distinct neighbouring tokens: no repeat-collapse, no <pad> emissions
     d = torch.arange(1, model.args.max_target_positions + 1, dtype=torch.float)
     model.decoder.synthetic_link_bias = -4.0 * ((d - mean_jump) / 2.0) ** 2
-    dp = model.tts.var_adaptor.duration_predictor
-    dp.proj.weight.mul_(0.05)
-    dp.proj.bias.fill_(float(torch.log(torch.tensor(frames_per_phoneme + 1.0))))
+    if hasattr(model, "tts"):                  # the speech-to-text model has no TTS stage
+        dp = model.tts.var_adaptor.duration_predictor
+        dp.proj.weight.mul_(0.05)
+        dp.proj.bias.fill_(float(torch.log(torch.tensor(frames_per_phoneme + 1.0))))
     return model

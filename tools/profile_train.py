@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev).train()
 b = make_s2st_batch(32, dev, seed=0)
 def step():
-    with torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.autocast("cuda", dtype=torch.float16 if os.environ.get("AMP", "fp16") == "fp16" else torch.bfloat16):
         loss, log = s2s_dag_fastspeech2_loss(model, b)
     loss.backward()
     model.zero_grad(set_to_none=True)
@@ -16,4 +16,4 @@ step(); torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=18, max_name_column_width=70))
+print(prof.key_averages().table(sort_by=os.environ.get("SORT", "self_cuda_time_total"), row_limit=int(os.environ.get("ROWS", "40")), max_name_column_width=90))
