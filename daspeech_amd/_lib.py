@@ -49,6 +49,11 @@ SIGNATURES = {
     "dsp_hifigan_conv": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.c_float, ctypes.c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_conv_chain": (_c_int, [_c_p, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_resunit": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                                     ctypes.c_float, _c_int, _c_p]),
+    "dsp_hifigan_resunit_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "dsp_hifigan_packed_weight_elems": (ctypes.c_long, [_c_int, _c_int, _c_int]),
+    "dsp_hifigan_pack_weights": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_pack_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
     "dsp_dag_alignment_trace_optional": (_c_int, [_c_int, _c_int]),

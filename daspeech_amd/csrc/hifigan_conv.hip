@@ -84,13 +84,16 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     // L2 latency of the weight stream is covered by two steps of MFMAs
     constexpr int NC = CI / 32;
     const int nsteps = (p.dbg & 2) ? 0 : p.ntaps * NC;
+    // weights are in FRAGMENT ORDER (dsp_hifigan_pack_weights): [tap][32-channel chunk][16-row tile][lane][8 halves], so one A
+    // fragment is one contiguous 1 KB block — 8 full cache lines per load instead of 16 half-used ones (the vector L1's line rate,
+    // not MFMA issue, was pacing the loop: r01f PMC + tiling sweep)
+    const int Mt = (p.M + 15) >> 4;
     auto load_a = [&](int step, h8 (&a)[MI]) {
-        const int k = step / NC, c = step - k * NC;
-        const _Float16* Wk = p.w + (size_t)k * p.M * CI;
+        const _Float16* Ws = p.w + (size_t)step * Mt * 512 + lane * 8;          // step = tap * NC + chunk
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int co = co_base + i * 16 + lr;
-            a[i] = (co < p.M) ? *reinterpret_cast<const h8*>(Wk + (size_t)co * CI + c * 32 + lk * 8) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int tile = (co_base >> 4) + i;
+            a[i] = (tile < Mt) ? *reinterpret_cast<const h8*>(Ws + (size_t)tile * 512) : (h8){0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
     h8 a0[MI], a1[MI], a2[MI];
@@ -185,6 +188,187 @@ static int hg_launch(const HgParams& p, hipStream_t st)
     return check_launch("hifigan_conv");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One ResBlock1 unit (hifi-gan/models.py:38-42) in ONE launch:   out = scale * ( x + b2 + c2( lrelu( b1 + c1( lrelu(x) ) ) ) ) [+ out]
+// c1 = Conv1d(C, C, K, dilation d), c2 = Conv1d(C, C, K, dilation 1).  The layer-at-a-time chain moves 5 activation tensors per
+// unit through HBM (x in, h out, h in, x in again as the residual, out); here the intermediate h lives in LDS only: x tile
+// (with both halos) in, out tile out, the residual re-read hits L2.  h is rounded to fp16 exactly where the chain rounds it, the
+// MFMA step order is the chain's, so the result is bit-identical to the two-launch path (tests/test_gpu_hifigan.py).
+//   tile: NT output columns; intermediate columns m = 0..NTI-1 (NTI = NT+16) stand for times t0-8+m, so c2's halo (<= 8) is inside;
+//   x rows r = 0..NTI+2*h1-1 stand for times t0-8-h1+r.  c1 of column m reads rows m + k*d; c2 of column n reads mid rows
+//   n + 8 - h2 + k.  h outside [0,T) is ZERO (c2's zero padding), not c1 of zero-padded x.
+struct HgUnitParams {
+    const _Float16* x; const _Float16* w1; const float* b1; const _Float16* w2; const float* b2; _Float16* out;
+    int B, T, ntaps, dil, accumulate;
+    float slope, scale;
+};
+
+template <int C, int NT, int WM, int WN>
+__global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = C / 8, NC = C / 32;
+    constexpr int NTI = NT + 16;
+    constexpr int MI = C / WM / 16, NI = NTI / WN / 16;
+    constexpr int OPITCH = C + 8;
+    static_assert(WM * WN == 8 && MI >= 1 && NI >= 1 && NTI % (WN * 16) == 0, "8 waves, intermediate tile divisible");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z, t0 = blockIdx.x * NT;
+    const int h1 = p.dil * (p.ntaps - 1) / 2, h2 = (p.ntaps - 1) / 2;
+    const int R1 = NTI + 2 * h1;
+    const size_t xin_bytes = (size_t)R1 * C * 2, ot_bytes = (size_t)NT * OPITCH * 2;
+    char* xin = smem;
+    char* mid = smem + ((xin_bytes > ot_bytes ? xin_bytes : ot_bytes) + 255) / 256 * 256;
+    const _Float16* X = p.x + (size_t)b * p.T * C;
+    const _Float16 slope = (_Float16)p.slope;
+
+    for (int e = tid; e < R1 * CH; e += 512) {
+        const int row = e / CH, ch = e - row * CH;
+        const int tg = t0 - 8 - h1 + row;
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tg >= 0 && tg < p.T) {
+            v = *reinterpret_cast<const h8*>(X + (size_t)tg * C + ch * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = v[i] > (_Float16)0 ? v[i] : v[i] * slope;
+        }
+        *reinterpret_cast<h8*>(xin + ((size_t)row * CH + hg_swz<C>(row, ch)) * 16) = v;
+    }
+    __syncthreads();
+
+    f4 acc[MI][NI];
+    const int co_base = wm * (MI * 16);
+    const int nsteps = p.ntaps * NC;
+    // one convolution over an LDS tile: the flattened (tap, 32-channel chunk) loop of hifigan_conv_kernel, 3-deep weight ring
+    auto conv = [&](const _Float16* W, const char* tile, int row0, int rstep) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        auto load_a = [&](int step, h8 (&a)[MI]) {                    // fragment-order weights, see hifigan_conv_kernel
+            const _Float16* Ws = W + (size_t)step * (C / 16) * 512 + lane * 8;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const h8*>(Ws + (size_t)((co_base >> 4) + i) * 512);
+        };
+        auto do_step = [&](int step, const h8 (&a)[MI]) {
+            const int k = step / NC, c = step - k * NC;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                // straight-line: c2's 16 columns past NT (last wave, last j) read the 16 slack rows behind `mid`; never stored
+                const int row = (wn * NI + j) * 16 + lr + row0 + k * rstep;
+                const h8 bf = *reinterpret_cast<const h8*>(tile + ((size_t)row * CH + hg_swz<C>(row, c * 4 + lk)) * 16);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf, acc[i][j], 0, 0, 0);
+            }
+        };
+        h8 a0[MI], a1[MI], a2[MI];
+        load_a(0, a0);
+        if (nsteps > 1) load_a(1, a1);
+        for (int step = 0; step < nsteps; step += 3) {
+            if (step + 2 < nsteps) load_a(step + 2, a2);
+            do_step(step, a0);
+            if (step + 1 < nsteps) {
+                if (step + 3 < nsteps) load_a(step + 3, a0);
+                do_step(step + 1, a1);
+            }
+            if (step + 2 < nsteps) {
+                if (step + 4 < nsteps) load_a(step + 4, a1);
+                do_step(step + 2, a2);
+            }
+        }
+    };
+
+    // ---- c1 over the NTI intermediate columns -> mid = lrelu(fp16(acc + b1)), zero outside [0,T) ----
+    conv(p.w1, xin, 0, p.dil);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int co = co_base + i * 16 + lk * 4;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.b1 ? p.b1[co + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int m = (wn * NI + j) * 16 + lr;
+            const int tm = t0 - 8 + m;
+            _Float16 hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 h = (_Float16)(acc[i][j][e] + bv[e]);
+                h = h > (_Float16)0 ? h : h * slope;
+                hv[e] = (tm >= 0 && tm < p.T) ? h : (_Float16)0;
+            }
+            *reinterpret_cast<uint2*>(mid + ((size_t)m * CH + hg_swz<C>(m, co >> 3)) * 16 + (co & 4) * 2) = *reinterpret_cast<uint2*>(hv);
+        }
+    }
+    __syncthreads();                                  // mid complete; xin is dead from here on (its space becomes the output tile)
+
+    // ---- c2 over the NT output columns ----
+    conv(p.w2, mid, 8 - h2, 1);
+    _Float16* otile = reinterpret_cast<_Float16*>(xin);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = co_base + i * 16 + lk * 4;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.b2 ? p.b2[ml + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (wn * NI + j < NT / 16) {
+                const int tl = (wn * NI + j) * 16 + lr;
+                _Float16 hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(acc[i][j][e] + bv[e]);
+                *reinterpret_cast<uint2*>(otile + (size_t)tl * OPITCH + ml) = *reinterpret_cast<uint2*>(hv);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NT * CH; e += 512) {
+        const int tl = e / CH, ch = e - tl * CH;
+        const int q = t0 + tl;
+        if (q >= p.T) continue;
+        const size_t o = ((size_t)b * p.T + q) * C + ch * 8;
+        const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
+        const h8 r8 = *reinterpret_cast<const h8*>(p.x + o);                 // the unit's residual is its own input
+        h8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.accumulate) a8 = *reinterpret_cast<const h8*>(p.out + o);
+        h8 w8;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[x]) + (float)a8[x]);
+        *reinterpret_cast<h8*>(p.out + o) = w8;
+    }
+}
+
+template <int C, int NT, int WM, int WN>
+static int hg_unit_launch(const HgUnitParams& p, hipStream_t st)
+{
+    const int h1 = p.dil * (p.ntaps - 1) / 2;
+    const size_t xin = (size_t)(NT + 16 + 2 * h1) * C * 2, ot = (size_t)NT * (C + 8) * 2;
+    const size_t lds = ((xin > ot ? xin : ot) + 255) / 256 * 256 + (size_t)(NT + 32) * C * 2;      // + 16 slack rows, see conv()
+    if (lds > 160 * 1024) { set_error("hifigan_resunit: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
+    auto k = hifigan_resunit_kernel<C, NT, WM, WN>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, 1, p.B), dim3(512), lds, st, p);
+    return check_launch("hifigan_resunit");
+}
+
+// [ntaps][M][CI] (tap-major rows) -> fragment order [ntaps][CI/32][ceil(M/16)][64 lanes][8]: lane = lk*16 + lr holds row
+// tile*16 + lr, channels chunk*32 + lk*8 .. +7 (the A operand of mfma_f32_16x16x32_f16); rows >= M are zero
+__global__ void hg_pack_weights_kernel(const _Float16* __restrict__ w, _Float16* __restrict__ out, int ntaps, int M, int CI)
+{
+    const int Mt = (M + 15) >> 4, NC = CI / 32;
+    const long n = (long)ntaps * NC * Mt * 512;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e & 7), ln = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int tile = (int)(r % Mt); r /= Mt;
+        const int c = (int)(r % NC); const int k = (int)(r / NC);
+        const int co = tile * 16 + (ln & 15), ci = c * 32 + (ln >> 4) * 8 + h;
+        out[e] = (co < M) ? w[((size_t)k * M + co) * CI + ci] : (_Float16)0;
+    }
+}
+
 __global__ void hg_pack_kernel(const float* __restrict__ x, _Float16* __restrict__ out, long n_rows, int C, int Cpad)
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_rows * Cpad; e += (long)gridDim.x * blockDim.x) {
@@ -237,6 +421,8 @@ static int hg_conv_one(const void* x, const void* w, const float* bias, const vo
     { static int ablate = -1; if (ablate < 0) { const char* ab = getenv("HG_ABLATE"); ablate = ab ? atoi(ab) : 0; } p.dbg = ablate; }
     p.min_shift = p.max_shift = host_shifts[0];
     for (int k = 0; k < ntaps; ++k) { p.shifts[k] = host_shifts[k]; p.min_shift = min(p.min_shift, host_shifts[k]); p.max_shift = max(p.max_shift, host_shifts[k]); }
+    // tile / wave-grid choices: sweeps r01e (tap-major weights) and r01f (fragment-order weights; 512-column tiles and MI=4 wave tiles
+    // for C = 128 / 256 were 20-40 % slower: fewer, longer workgroups and a longer un-overlapped stage/epilogue per tile)
     switch (CI) {
         case 512: return hg_launch<512, 256, 128, 8, 1>(p, st);
         case 256: return hg_launch<256, 256, 128, 8, 1>(p, st);
@@ -258,6 +444,41 @@ extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias,
                        as_stream(stream));
 }
 
+static int hg_unit_one(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                       int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate, hipStream_t st)
+{
+    if (B < 0 || T < 1 || ntaps < 1 || ntaps > DSP_HG_MAX_TAPS || !(ntaps & 1) || dil < 1) { set_error("hifigan_resunit: bad sizes"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!x || !w1 || !w2 || !out || x == out) { set_error("hifigan_resunit: null or aliased pointer"); return DSP_EINVAL; }
+    HgUnitParams p;
+    p.x = (const _Float16*)x; p.w1 = (const _Float16*)w1; p.b1 = b1; p.w2 = (const _Float16*)w2; p.b2 = b2; p.out = (_Float16*)out;
+    p.B = B; p.T = T; p.ntaps = ntaps; p.dil = dil; p.accumulate = accumulate; p.slope = slope; p.scale = scale;
+    // C = 128 fits (142 KB of LDS, one workgroup per CU) but is slower than its two-launch chain (441 vs 2 x 200 us at B=32): the host
+    // only fuses C <= 64 (dsp_hifigan_resunit_supported)
+    switch (C) {
+        case 128: return hg_unit_launch<128, 240, 4, 2>(p, st);
+        case 64:  return hg_unit_launch<64, 240, 2, 4>(p, st);
+        case 32:  return hg_unit_launch<32, 496, 1, 8>(p, st);
+    }
+    set_error("hifigan_resunit: unsupported channel count %d (32, 64, 128)", C);
+    return DSP_EINVAL;
+}
+
+extern "C" int dsp_hifigan_resunit(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                                   int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate,
+                                   dsp_stream_t stream)
+{
+    return hg_unit_one(x, w1, b1, w2, b2, out, B, T, C, ntaps, dil, slope, scale, accumulate, as_stream(stream));
+}
+
+extern "C" int dsp_hifigan_resunit_supported(int C, int ntaps, int dil)
+{
+    if (!(C == 32 || C == 64) || ntaps < 1 || !(ntaps & 1) || ntaps > DSP_HG_MAX_TAPS || dil < 1) return 0;
+    const int h1 = dil * (ntaps - 1) / 2, NT = (C == 32) ? 496 : 240;
+    const size_t xin = (size_t)(NT + 16 + 2 * h1) * C * 2, ot = (size_t)NT * (C + 8) * 2;
+    return ((xin > ot ? xin : ot) + 255) / 256 * 256 + (size_t)(NT + 32) * C * 2 <= 160 * 1024;
+}
+
 // The generator is ~100 of these layers per call; driven one ctypes call at a time the host, not the GPU, sets the pace at
 // vocoder batch sizes.  One call walks a whole layer table.
 extern "C" int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream)
@@ -266,11 +487,33 @@ extern "C" int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, 
     hipStream_t st = as_stream(stream);
     for (int i = 0; i < n_layers; ++i) {
         const dsp_hg_layer& l = layers[i];
+        if (l.w2) {                                                        // fused ResBlock unit: x -> c1 -> c2 -> + x
+            const int dil = l.ntaps > 1 ? l.shifts[l.ntaps / 2 + 1] : 1;
+            int rc = hg_unit_one(l.x, l.w, l.bias, l.w2, l.bias2, l.out, B, l.T, l.CI, l.ntaps, dil, l.pre_slope, l.scale,
+                                 l.out_mode == DSP_HG_OUT_ACCUM, st);
+            if (rc) return rc;
+            continue;
+        }
         int rc = hg_conv_one(l.x, l.w, l.bias, l.res, l.out, B, l.T, l.CI, l.M, l.ntaps, l.shifts, l.pre_slope, l.scale,
                              l.out_mode, l.up_u, l.up_pad, l.Tout, l.Cout, st);
         if (rc) return rc;
     }
     return DSP_OK;
+}
+
+extern "C" long dsp_hifigan_packed_weight_elems(int ntaps, int M, int CI)
+{
+    if (ntaps < 1 || M < 1 || CI < 32 || (CI & 31)) return -1;
+    return (long)ntaps * (CI / 32) * ((M + 15) / 16) * 512;
+}
+
+extern "C" int dsp_hifigan_pack_weights(const void* w, void* out, int ntaps, int M, int CI, dsp_stream_t stream)
+{
+    const long n = dsp_hifigan_packed_weight_elems(ntaps, M, CI);
+    if (n < 0 || !w || !out || w == out) { set_error("hifigan_pack_weights: bad arguments"); return DSP_EINVAL; }
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(hg_pack_weights_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)w, (_Float16*)out, ntaps, M, CI);
+    return check_launch("hifigan_pack_weights");
 }
 
 extern "C" int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, int C, int Cpad, dsp_stream_t stream)

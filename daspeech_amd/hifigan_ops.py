@@ -26,19 +26,34 @@ class HgLayerDesc(ctypes.Structure):          # include/daspeech_hifigan.h: dsp_
                 ("shifts", ctypes.c_int * MAX_TAPS),
                 ("pre_slope", ctypes.c_float), ("scale", ctypes.c_float),
                 ("out_mode", ctypes.c_int), ("up_u", ctypes.c_int), ("up_pad", ctypes.c_int), ("Tout", ctypes.c_int),
-                ("Cout", ctypes.c_int)]
+                ("Cout", ctypes.c_int), ("w2", ctypes.c_void_p), ("bias2", ctypes.c_void_p)]
 
 
 class _Layer:
-    __slots__ = ("w", "bias", "shifts", "ntaps", "CI", "M", "Cout", "mode", "u", "pad")
+    __slots__ = ("w", "bias", "shifts", "ntaps", "CI", "M", "Cout", "mode", "u", "pad", "dil")
 
 
 def _shifts_array(sh: List[int]):
     return (ctypes.c_int * len(sh))(*sh)
 
 
+def pack_weights(w_tap_major: Tensor) -> Tensor:
+    """[ntaps][M][CI] fp16 -> the MFMA fragment order the kernels read (include/daspeech_hifigan.h: dsp_hifigan_pack_weights)."""
+    lib = _lib.load()
+    w = w_tap_major.contiguous()
+    K, M, CI = w.shape
+    assert w.dtype == torch.float16 and w.is_cuda
+    out = torch.empty((lib.dsp_hifigan_packed_weight_elems(K, M, CI),), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.dsp_hifigan_pack_weights(_lib.ptr(w), _lib.ptr(out), K, M, CI, _lib.current_stream_handle()), "dsp_hifigan_pack_weights")
+    return out
+
+
 class HiFiGANHipRunner:
-    def __init__(self, gen):
+    def __init__(self, gen, fuse_units: bool = True):
+        """fuse_units: run a ResBlock unit (conv, conv, residual) as ONE launch where dsp_hifigan_resunit supports its shape
+        (C <= 128); False keeps the layer-at-a-time chain (same bits, 2.5x the activation traffic) for comparison."""
+        self.fuse_units = fuse_units
         dev = next(gen.parameters()).device
         assert dev.type == "cuda", "HiFiGANHipRunner needs the generator on a GPU"
         self.dev = dev
@@ -64,11 +79,11 @@ class HiFiGANHipRunner:
         if ci_pad and ci_pad != Cin:
             w = torch.nn.functional.pad(w, (0, 0, 0, ci_pad - Cin))
             Cin = ci_pad
-        L.w = w.permute(2, 0, 1).contiguous().to(torch.float16)
+        L.w = pack_weights(w.permute(2, 0, 1).contiguous().to(torch.float16))
         L.bias = m.bias.detach().float().contiguous() if m.bias is not None else None
         d = m.dilation[0]
         L.shifts = [(k - (K - 1) // 2) * d for k in range(K)]
-        L.ntaps, L.CI, L.M, L.Cout, L.mode, L.u, L.pad = K, Cin, Cout, Cout, OUT_STORE, 1, 0
+        L.ntaps, L.CI, L.M, L.Cout, L.mode, L.u, L.pad, L.dil = K, Cin, Cout, Cout, OUT_STORE, 1, 0, d
         return L
 
     def _up_layer(self, m):
@@ -77,7 +92,7 @@ class HiFiGANHipRunner:
         Cin, Cout, K = w.shape
         u = m.stride[0]
         assert K == 2 * u and m.padding[0] == (K - u) // 2, "expects the HiFi-GAN upsampler geometry (kernel 2u, pad u/2)"
-        L.w = w.permute(2, 1, 0).reshape(2, u * Cout, Cin).contiguous().to(torch.float16)      # tap j, row (r, co): k = j*u + r
+        L.w = pack_weights(w.permute(2, 1, 0).reshape(2, u * Cout, Cin).contiguous().to(torch.float16))      # tap j, row (r, co): k = j*u + r
         L.bias = m.bias.detach().float().contiguous() if m.bias is not None else None
         L.shifts = [0, -1]
         L.ntaps, L.CI, L.M, L.Cout, L.mode, L.u, L.pad = 2, Cin, u * Cout, Cout, OUT_UPSAMPLE, u, (K - u) // 2
@@ -105,7 +120,12 @@ class HiFiGANHipRunner:
         hit = self._plans.get(key)
         if hit is not None:
             return hit
-        sizes, recs = [], []            # buffer sizes in halves; records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale)
+        sizes, recs = [], []            # buffer sizes in halves; records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale[, layer2])
+        lib = _lib.load()
+
+        def fusable(c1, c2):
+            return (self.fuse_units and c1.CI == c1.M == c2.CI == c2.M and c1.ntaps == c2.ntaps and c2.dil == 1
+                    and bool(lib.dsp_hifigan_resunit_supported(c1.CI, c1.ntaps, c1.dil)))
 
         def new_buf(t, c):
             sizes.append(B * t * c)
@@ -120,6 +140,14 @@ class HiFiGANHipRunner:
                 yb = x
                 units = self.blocks[i * self.nk + j]
                 for n, (c1, c2) in enumerate(units):
+                    if fusable(c1, c2):                       # x -> c1 -> c2 -> + x in one launch, no intermediate buffer
+                        if n + 1 < len(units):
+                            o = new_buf(t, c2.Cout); recs.append((c1, yb, None, o, t, 0.1, OUT_STORE, 1.0, c2)); yb = o
+                        elif acc is None:
+                            acc = new_buf(t, c2.Cout); recs.append((c1, yb, None, acc, t, 0.1, OUT_STORE, 1.0 / self.nk, c2))
+                        else:
+                            recs.append((c1, yb, None, acc, t, 0.1, OUT_ACCUM, 1.0 / self.nk, c2))
+                        continue
                     h = new_buf(t, c1.Cout); recs.append((c1, yb, None, h, t, 0.1, None, 1.0))
                     if n + 1 < len(units):
                         o = new_buf(t, c2.Cout); recs.append((c2, h, yb, o, t, 0.1, None, 1.0)); yb = o
@@ -134,7 +162,11 @@ class HiFiGANHipRunner:
         ws = torch.empty((tot,), dtype=torch.float16, device=dev)
         base = ws.data_ptr()
         table = (HgLayerDesc * len(recs))()
-        for d, (L, xb, rb, ob, tt, slope, mode, scale) in zip(table, recs):
+        for d, rec in zip(table, recs):
+            L, xb, rb, ob, tt, slope, mode, scale = rec[:8]
+            L2 = rec[8] if len(rec) > 8 else None
+            d.w2 = L2.w.data_ptr() if L2 is not None else None
+            d.bias2 = L2.bias.data_ptr() if (L2 is not None and L2.bias is not None) else None
             d.x = base + 2 * offs[xb]; d.res = (base + 2 * offs[rb]) if rb is not None else None; d.out = base + 2 * offs[ob]
             d.w = L.w.data_ptr(); d.bias = L.bias.data_ptr() if L.bias is not None else None
             d.T, d.CI, d.M, d.ntaps = tt, L.CI, L.M, L.ntaps

@@ -93,19 +93,13 @@ class HiFiGANGenerator(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _conv(self, x: Tensor, m: nn.Conv1d, pre_slope: float = None, residual: Tensor = None) -> Tensor:
-        """[residual +] conv(leaky_relu(x)) — the fusion unit of the HIP path."""
-        if self.conv_backend == "hip" and x.is_cuda:
-            from .. import hifigan_ops
-            return hifigan_ops.lrelu_conv1d(x, m.weight, m.bias, m.dilation[0], m.padding[0], pre_slope, residual)
+        """[residual +] conv(leaky_relu(x)) — torch backend (the HIP backend runs the whole stack in HiFiGANHipRunner)."""
         if pre_slope is not None:
             x = F.leaky_relu(x, pre_slope)
         y = F.conv1d(x, m.weight, m.bias, dilation=m.dilation, padding=m.padding)
         return y if residual is None else y + residual
 
     def _up(self, x: Tensor, m: nn.ConvTranspose1d, pre_slope: float) -> Tensor:
-        if self.conv_backend == "hip" and x.is_cuda:
-            from .. import hifigan_ops
-            return hifigan_ops.lrelu_conv_transpose1d(x, m.weight, m.bias, m.stride[0], m.padding[0], pre_slope)
         return F.conv_transpose1d(F.leaky_relu(x, pre_slope), m.weight, m.bias, stride=m.stride, padding=m.padding)
 
     def forward(self, mel: Tensor) -> Tensor:

@@ -25,7 +25,13 @@ extern "C" {
 #define DSP_HG_OUT_UPSAMPLE 2   /* out[q*u + r - pad][co] = v, M = u*Cout */
 #define DSP_HG_MAX_TAPS 16
 
-/* x [B,T,CI] fp16 (CI multiple of 32 in {32,64,96,128,256,512}); w [ntaps,M,CI] fp16; bias [Cout] fp32 or NULL;
+/* Weights are consumed in MFMA FRAGMENT ORDER: dsp_hifigan_pack_weights turns the tap-major [ntaps][M][CI] fp16 slab into
+ * [ntaps][CI/32][ceil(M/16)][64][8] (dsp_hifigan_packed_weight_elems halves; rows >= M zero), so that one A fragment is one
+ * contiguous 1 KB block.  Every `w` / `w1` / `w2` below is such a packed buffer. */
+long dsp_hifigan_packed_weight_elems(int ntaps, int M, int CI);
+int dsp_hifigan_pack_weights(const void* w_tap_major, void* out, int ntaps, int M, int CI, dsp_stream_t stream);
+
+/* x [B,T,CI] fp16 (CI multiple of 32 in {32,64,96,128,256,512}); w packed from [ntaps,M,CI] fp16; bias [Cout] fp32 or NULL;
  * res [B,Tout,Cout] fp16 or NULL (added before `scale`); out [B,Tout,Cout] fp16; v = scale * (acc + bias + res).
  * pre_slope: leaky_relu slope applied to x while staging (1.0 = none).  For STORE/ACCUM Tout == T and Cout == M. */
 int dsp_hifigan_conv(const void* x, const void* w, const float* bias, const void* res, void* out,
@@ -40,8 +46,19 @@ typedef struct dsp_hg_layer {
     int shifts[DSP_HG_MAX_TAPS];
     float pre_slope, scale;
     int out_mode, up_u, up_pad, Tout, Cout;
+    const void* w2; const float* bias2;   /* non-NULL: the record is a fused ResBlock unit (dsp_hifigan_resunit) whose first conv is
+                                             (w, bias, shifts) and whose residual is x; `res` is ignored, out_mode STORE or ACCUM */
 } dsp_hg_layer;
 int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream);
+
+/* One ResBlock1 unit (hifi-gan/models.py:38-42: xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x) in one launch, the
+ * intermediate kept in LDS:  out = scale * (x + b2 + c2(lrelu(b1 + c1(lrelu(x))))) [+ out if accumulate].
+ * c1 = Conv1d(C, C, ntaps, dilation dil), c2 = Conv1d(C, C, ntaps, dilation 1), "same" padding; w1, w2 packed from [ntaps][C][C] fp16;
+ * x, out [B,T,C] fp16, out != x.  Bit-identical to the two dsp_hifigan_conv launches it replaces.  C in {32, 64, 128}, ntaps odd.
+ * dsp_hifigan_resunit_supported() says whether fusing a (C, ntaps, dil) unit fits the LDS tiling AND pays (C <= 64). */
+int dsp_hifigan_resunit(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                        int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate, dsp_stream_t stream);
+int dsp_hifigan_resunit_supported(int C, int ntaps, int dil);
 
 /* fp32 [B,T,C] -> fp16 [B,T,Cpad] zero padded channels (mel input) */
 int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, int C, int Cpad, dsp_stream_t stream);

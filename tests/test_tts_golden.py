@@ -120,3 +120,43 @@ def test_hifigan_hip_matches_torch_fp32():
     with torch.no_grad():
         out2 = g(mel2); g.conv_backend = "torch"; ref2 = g(mel2)
     assert (out2 - ref2).abs().max().item() < 2e-2
+
+
+@pytest.mark.gpu
+def test_hifigan_fused_resblock_unit_bit_identical_to_layer_chain():
+    """dsp_hifigan_resunit (conv, conv, residual in one launch, intermediate in LDS) against the two dsp_hifigan_conv launches it
+    replaces: same rounding points and MFMA step order, so the fp16 outputs must be equal bit for bit — whole generator and
+    single units at tile edges (T not a multiple of the 240/496-column tiles, T smaller than a halo)."""
+    from daspeech_amd import _lib
+    from daspeech_amd.hifigan_ops import HiFiGANHipRunner
+    from daspeech_amd.models import HiFiGANGenerator
+    torch.manual_seed(11)
+    g = HiFiGANGenerator().cuda().eval()
+    with torch.no_grad():
+        for p in g.parameters():
+            p.copy_(torch.randn_like(p) / (p.shape[1] * p.shape[2]) ** 0.5 if p.dim() > 1 else torch.randn_like(p) * 0.05)
+    fused, chain = HiFiGANHipRunner(g, fuse_units=True), HiFiGANHipRunner(g, fuse_units=False)
+    for B, T in ((2, 37), (1, 5), (3, 64)):
+        mel = torch.randn(B, 80, T, device="cuda")
+        a, b = fused(mel), chain(mel)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (B, T, (a - b).abs().max().item())
+    lib = _lib.load()
+    st = _lib.current_stream_handle()
+    for C, K, dil, T in ((32, 11, 5, 1000), (32, 3, 1, 497), (64, 7, 3, 481), (64, 11, 5, 7), (128, 11, 5, 250), (128, 3, 1, 239)):
+        assert bool(lib.dsp_hifigan_resunit_supported(C, K, dil)) == (C <= 64)
+        x = (torch.randn(2, T, C, device="cuda") * 1.5).half()
+        from daspeech_amd.hifigan_ops import pack_weights
+        w1 = pack_weights((torch.randn(K, C, C, device="cuda") / (C * K) ** 0.5).half()); w2 = pack_weights((torch.randn(K, C, C, device="cuda") / (C * K) ** 0.5).half())
+        b1 = torch.randn(C, device="cuda") * 0.1; b2 = torch.randn(C, device="cuda") * 0.1
+        import ctypes
+        sh1 = (ctypes.c_int * K)(*[(k - (K - 1) // 2) * dil for k in range(K)]); sh2 = (ctypes.c_int * K)(*[k - (K - 1) // 2 for k in range(K)])
+        for accumulate in (0, 1):
+            base = (torch.randn(2, T, C, device="cuda")).half()
+            o1, o2, h = base.clone(), base.clone(), torch.empty_like(x)
+            _lib.check(lib.dsp_hifigan_resunit(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(o1), 2, T, C, K, dil,
+                                               0.1, 1.0 / 3, accumulate, st), "resunit")
+            _lib.check(lib.dsp_hifigan_conv(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), None, _lib.ptr(h), 2, T, C, C, K, sh1, 0.1, 1.0, 0, 1, 0, T, C, st), "conv")
+            _lib.check(lib.dsp_hifigan_conv(_lib.ptr(h), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(x), _lib.ptr(o2), 2, T, C, C, K, sh2, 0.1, 1.0 / 3,
+                                            1 if accumulate else 0, 1, 0, T, C, st), "conv")
+            assert torch.equal(o1, o2), (C, K, dil, T, accumulate, (o1.float() - o2.float()).abs().max().item())
+    assert not lib.dsp_hifigan_resunit_supported(256, 3, 1) and not lib.dsp_hifigan_resunit_supported(64, 4, 1)

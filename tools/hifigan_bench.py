@@ -6,8 +6,10 @@ B, T = int(sys.argv[1]), int(sys.argv[2])
 g = HiFiGANGenerator().cuda().eval()
 mel = torch.randn(B, 80, T, device="cuda")
 flops = 0.614e9 * B * T
-for backend in ("torch", "hip"):
-    g.conv_backend = backend
+from daspeech_amd.hifigan_ops import HiFiGANHipRunner
+for backend in (("torch",) if os.environ.get("HG_TORCH") else ()) + ("hip-chain", "hip"):
+    g.conv_backend = backend.split("-")[0]
+    g._hip_runner = HiFiGANHipRunner(g, fuse_units=(backend == "hip")) if backend != "torch" else None
     with torch.no_grad():
         for _ in range(2): g(mel)
         torch.cuda.synchronize(); t0 = time.perf_counter()
