@@ -39,6 +39,41 @@ __device__ __forceinline__ int hg_swz(int row, int chunk) {
     else return chunk ^ ((row / RPB) & MASK);
 }
 
+// Stage rows [t_first, t_first + R) of channels-last x (zero outside [0,T)) into the swizzled LDS tile, leaky_relu applied once
+// per element.  U requests per thread are in flight before the first is consumed: the one-load-one-wait loop this replaces paid
+// ~10 dependent HBM round trips per tile (r01f ISA reading: global_load / s_waitcnt vmcnt(0) / ds_write per iteration).
+template <int CI, int U>
+__device__ __forceinline__ void hg_stage_tile(char* tile, const _Float16* __restrict__ X, int T, int t_first, int R, float pre_slope,
+                                              bool skip_loads, int tid)
+{
+    constexpr int CH = CI / 8;
+    const _Float16 slope = (_Float16)pre_slope;
+    const int n = R * CH;
+    for (int e0 = tid; e0 < n; e0 += 512 * U) {
+        h8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 512;
+            const int row = e / CH, ch = e - row * CH;
+            const int tg = t_first + row;
+            v[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (e < n && tg >= 0 && tg < T && !skip_loads) v[u] = *reinterpret_cast<const h8*>(X + (size_t)tg * CI + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 512;
+            if (e < n) {
+                const int row = e / CH, ch = e - row * CH;
+                if (pre_slope != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[u][i] = v[u][i] > (_Float16)0 ? v[u][i] : v[u][i] * slope;
+                }
+                *reinterpret_cast<h8*>(tile + ((size_t)row * CH + hg_swz<CI>(row, ch)) * 16) = v[u];
+            }
+        }
+    }
+}
+
 template <int CI, int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
 {
@@ -55,20 +90,7 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     const _Float16* X = p.x + (size_t)b * p.T * CI;
 
     // ---- stage lrelu(x) tile: rows t0+min_shift .. t0+NT-1+max_shift, zero outside [0,T) ----
-    const _Float16 slope = (_Float16)p.pre_slope;
-    for (int e = tid; e < R * CH; e += 512) {
-        const int row = e / CH, ch = e - row * CH;
-        const int tg = t0 + p.min_shift + row;
-        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (tg >= 0 && tg < p.T && !(p.dbg & 1)) {
-            v = *reinterpret_cast<const h8*>(X + (size_t)tg * CI + ch * 8);
-            if (p.pre_slope != 1.0f) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = v[i] > (_Float16)0 ? v[i] : v[i] * slope;
-            }
-        }
-        *reinterpret_cast<h8*>(smem + ((size_t)row * CH + hg_swz<CI>(row, ch)) * 16) = v;
-    }
+    hg_stage_tile<CI, 6>(smem, X, p.T, t0 + p.min_shift, R, p.pre_slope, (p.dbg & 1) != 0, tid);
     __syncthreads();
 
     f4 acc[MI][NI];
@@ -151,23 +173,37 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     }
     __syncthreads();
     constexpr int CPR = MT / 8;                       // 16-byte chunks per tile row
-    for (int e = tid; e < NT * CPR; e += 512) {
-        const int tl = e / CPR, ch = e - tl * CPR;
-        const int mrow = m0 + ch * 8;
-        if (mrow >= p.M) continue;
-        const int q = t0 + tl;
-        int tout = q, co = mrow;
-        if (p.out_mode == DSP_HG_OUT_UPSAMPLE) { const int r = mrow / p.Cout; co = mrow - r * p.Cout; tout = q * p.up_u + r - p.up_pad; }
-        if (tout < 0 || tout >= p.Tout) continue;
-        const size_t o = ((size_t)b * p.Tout + tout) * p.Cout + co;
-        const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
-        h8 r8 = {0, 0, 0, 0, 0, 0, 0, 0}, a8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.res) r8 = *reinterpret_cast<const h8*>(p.res + o);
-        if (p.out_mode == DSP_HG_OUT_ACCUM) a8 = *reinterpret_cast<const h8*>(p.out + o);
-        h8 w8;
+    constexpr int EU = 4;                             // residual / accumulate loads of EU chunks in flight together
+    static_assert((NT * CPR) % (512 * EU) == 0, "tile chunks divide evenly");
+    for (int e0 = tid; e0 < NT * CPR; e0 += 512 * EU) {
+        h8 r8[EU], a8[EU];
+        size_t off[EU];
+        bool live[EU];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[x]) + (float)a8[x]);
-        *reinterpret_cast<h8*>(p.out + o) = w8;
+        for (int u = 0; u < EU; ++u) {
+            const int e = e0 + u * 512;
+            const int tl = e / CPR, ch = e - tl * CPR;
+            const int mrow = m0 + ch * 8;
+            const int q = t0 + tl;
+            int tout = q, co = mrow;
+            if (p.out_mode == DSP_HG_OUT_UPSAMPLE) { const int r = mrow / p.Cout; co = mrow - r * p.Cout; tout = q * p.up_u + r - p.up_pad; }
+            live[u] = mrow < p.M && tout >= 0 && tout < p.Tout;
+            off[u] = ((size_t)b * p.Tout + tout) * p.Cout + co;
+            r8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0}; a8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (live[u] && p.res) r8[u] = *reinterpret_cast<const h8*>(p.res + off[u]);
+            if (live[u] && p.out_mode == DSP_HG_OUT_ACCUM) a8[u] = *reinterpret_cast<const h8*>(p.out + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            if (!live[u]) continue;
+            const int e = e0 + u * 512;
+            const int tl = e / CPR, ch = e - tl * CPR;
+            const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
+            h8 w8;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[u][x]) + (float)a8[u][x]);
+            *reinterpret_cast<h8*>(p.out + off[u]) = w8;
+        }
     }
 }
 
@@ -224,17 +260,7 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
     const _Float16* X = p.x + (size_t)b * p.T * C;
     const _Float16 slope = (_Float16)p.slope;
 
-    for (int e = tid; e < R1 * CH; e += 512) {
-        const int row = e / CH, ch = e - row * CH;
-        const int tg = t0 - 8 - h1 + row;
-        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (tg >= 0 && tg < p.T) {
-            v = *reinterpret_cast<const h8*>(X + (size_t)tg * C + ch * 8);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = v[i] > (_Float16)0 ? v[i] : v[i] * slope;
-        }
-        *reinterpret_cast<h8*>(xin + ((size_t)row * CH + hg_swz<C>(row, ch)) * 16) = v;
-    }
+    hg_stage_tile<C, 6>(xin, X, p.T, t0 - 8 - h1, R1, p.slope, false, tid);
     __syncthreads();
 
     f4 acc[MI][NI];
@@ -324,19 +350,32 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
         }
     }
     __syncthreads();
-    for (int e = tid; e < NT * CH; e += 512) {
-        const int tl = e / CH, ch = e - tl * CH;
-        const int q = t0 + tl;
-        if (q >= p.T) continue;
-        const size_t o = ((size_t)b * p.T + q) * C + ch * 8;
-        const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
-        const h8 r8 = *reinterpret_cast<const h8*>(p.x + o);                 // the unit's residual is its own input
-        h8 a8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.accumulate) a8 = *reinterpret_cast<const h8*>(p.out + o);
-        h8 w8;
+    constexpr int EU = 4;
+    for (int e0 = tid; e0 < NT * CH; e0 += 512 * EU) {
+        h8 r8[EU], a8[EU];
+        bool live[EU];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[x]) + (float)a8[x]);
-        *reinterpret_cast<h8*>(p.out + o) = w8;
+        for (int u = 0; u < EU; ++u) {
+            const int e = e0 + u * 512;
+            const int tl = e / CH, ch = e - tl * CH;
+            live[u] = e < NT * CH && t0 + tl < p.T;
+            const size_t o = ((size_t)b * p.T + t0 + tl) * C + ch * 8;
+            r8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0}; a8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (live[u]) r8[u] = *reinterpret_cast<const h8*>(p.x + o);              // the unit's residual is its own input
+            if (live[u] && p.accumulate) a8[u] = *reinterpret_cast<const h8*>(p.out + o);
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            if (!live[u]) continue;
+            const int e = e0 + u * 512;
+            const int tl = e / CH, ch = e - tl * CH;
+            const size_t o = ((size_t)b * p.T + t0 + tl) * C + ch * 8;
+            const h8 v = *reinterpret_cast<const h8*>(otile + (size_t)tl * OPITCH + ch * 8);
+            h8 w8;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) w8[x] = (_Float16)(p.scale * ((float)v[x] + (float)r8[u][x]) + (float)a8[u][x]);
+            *reinterpret_cast<h8*>(p.out + o) = w8;
+        }
     }
 }
 
