@@ -108,6 +108,7 @@ SHAPES = [
     (2, 70, 2048, 32),     # strip boundary exactly at L
     (3, 30, 300, 299),     # dense window TR = L-1 at a realistic graph size (wave-per-column kernels)
     (2, 17, 200, 130),     # dense window, TR < L-1
+    (2, 24, 1024, 1023),   # dense window shared by 16 workgroups per (sample, direction): tagged-granule row hand-off
 ]
 
 
