@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     __syncthreads();
     constexpr int CPR = MT / 8;                       // 16-byte chunks per tile row
     constexpr int EU = 4;                             // residual / accumulate loads of EU chunks in flight together
-    static_assert((NT * CPR) % (512 * EU) == 0, "tile chunks divide evenly");
+    static_assert((NT * CPR) % 512 == 0, "tile chunks divide evenly");
     for (int e0 = tid; e0 < NT * CPR; e0 += 512 * EU) {
         h8 r8[EU], a8[EU];
         size_t off[EU];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
             const int q = t0 + tl;
             int tout = q, co = mrow;
             if (p.out_mode == DSP_HG_OUT_UPSAMPLE) { const int r = mrow / p.Cout; co = mrow - r * p.Cout; tout = q * p.up_u + r - p.up_pad; }
-            live[u] = mrow < p.M && tout >= 0 && tout < p.Tout;
+            live[u] = e < NT * CPR && mrow < p.M && tout >= 0 && tout < p.Tout;
             off[u] = ((size_t)b * p.Tout + tout) * p.Cout + co;
             r8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0}; a8[u] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
             if (live[u] && p.res) r8[u] = *reinterpret_cast<const h8*>(p.res + off[u]);
@@ -465,7 +465,7 @@ static int hg_conv_one(const void* x, const void* w, const float* bias, const vo
     switch (CI) {
         case 512: return hg_launch<512, 256, 128, 8, 1>(p, st);
         case 256: return hg_launch<256, 256, 128, 8, 1>(p, st);
-        case 128: return hg_launch<128, 128, 256, 4, 2>(p, st);
+        case 128: return hg_launch<128, 128, 256, 4, 2>(p, st);       // half-size tiles (2-3 workgroups per CU) are 7-10 % slower too
         case 96:  return hg_launch<96, 256, 128, 8, 1>(p, st);
         case 64:  return hg_launch<64, 64, 512, 2, 4>(p, st);      // 512-column tiles: 12.1 vs 13.0 ms per B=32 pass (sweep r01e;
                                                                     // 64x64 wave tiles, and larger tiles for C = 32 / 128 / 256, were slower or equal)
