@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                     help="s2st only: autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (the reference runs --fp16); "
                          "default fp32, the mode the mel parity (<= 1e-4) is stated for")
+    ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"],
+                    help="s2tt / s2st: graph decode mode (the reference's test_scripts run lookahead and jointviterbi)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     args = ap.parse_args()
@@ -92,6 +94,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
     torch.manual_seed(1234)
     B = args.batch
     model = calibrate_synthetic_weights(S2TConformerDAGModel() if args.workload == "s2tt" else S2SConformerDAGFastSpeech2Model()).to(dev)
+    model.args.decode_strategy = args.decode_strategy
     batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
     args.warmup = max(args.warmup, 2 * len(batches))     # MIOpen/hipBLASLt pick algorithms per new shape: keep that out of the timing
 
@@ -112,7 +115,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
                 enc = model.forward_encoder(ni["src_tokens"], ni["src_lengths"])
                 prev = model.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
                 return model.forward_decoder(prev, enc)["output_tokens"]
-        wl = (f"C3 S2TT full forward (s2t_conformer_dag): Conformer(12L,256) -> DA-Transformer(4L,512) + fused links -> HIP lookahead "
+        wl = (f"C3 S2TT full forward (s2t_conformer_dag): Conformer(12L,256) -> DA-Transformer(4L,512) + fused links -> {args.decode_strategy} "
               f"graph decode to tokens, B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast"))
     elif args.workload == "s2st":
         model.eval()
@@ -125,7 +128,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
                 out = gen.generate(model, batches[i % len(batches)])
             frames[0] += sum(o["feature"].shape[0] for o in out)
             return out
-        wl = (f"C4 full S2ST pipeline, lookahead decode: Conformer(12L,256) -> DA-Transformer(4L,512) + links -> HIP graph decode -> "
+        wl = (f"C4 full S2ST pipeline, {args.decode_strategy} decode: Conformer(12L,256) -> DA-Transformer(4L,512) + links -> HIP graph decode -> "
               f"FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) -> HiFi-GAN V1 ({args.vocoder_backend} convs), "
               f"B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"))
     else:

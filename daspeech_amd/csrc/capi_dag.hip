@@ -14,6 +14,8 @@ void set_k5_path(int v);
 int k5_diag(unsigned int* out);
 int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 int banded_last_error_word(hipStream_t st, unsigned int* word);
+int launch_max_alpha_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                             float* alpha, int32_t* trace, int B, int T, int L, int TR, hipStream_t st);
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
 
 bool strip4_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
@@ -125,6 +127,25 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
         }
     }
     return launch_best_alignment_generic(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, st);
+}
+
+extern "C" int dsp_dag_max_alpha(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                 float* alpha_max, int32_t* trace, int B, int T, int L, int TR, dsp_stream_t stream)
+{
+    int rc = check_dims("dag_max_alpha", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace) { set_error("dag_max_alpha: null pointer"); return DSP_EINVAL; }
+    return launch_max_alpha_generic(match, links, out_len, tgt_len, alpha_max, trace, B, T, L, TR, as_stream(stream));
+}
+
+extern "C" int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L,
+                                 dsp_stream_t stream)
+{
+    if (B < 0 || T < 1 || L < 1) { set_error("dag_backtrace: bad sizes"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!trace || !out_len || !tgt_len || !path) { set_error("dag_backtrace: null pointer"); return DSP_EINVAL; }
+    return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, as_stream(stream));
 }
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)

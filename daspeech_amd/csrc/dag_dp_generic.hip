@@ -493,8 +493,10 @@ int launch_pick_loss(const float* alpha, const float* beta, const int64_t* out_l
     return check_launch("dag_pick_loss");
 }
 
-int launch_best_alignment_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                                  float* alpha, int32_t* trace, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+// max-DP + trace only (every cell (t, j >= t) of rows < T_b, no end-reach mask): the forward half of the alignment and the DP of
+// the Viterbi graph decode (dsp_dag_max_alpha)
+int launch_max_alpha_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                             float* alpha, int32_t* trace, int B, int T, int L, int TR, hipStream_t st)
 {
     const size_t lds = 2 * (size_t)L * sizeof(float);
     if (lds > 160 * 1024) { set_error("dag_best_alignment: graph size L=%d too large (max 20480)", L); return DSP_EINVAL; }
@@ -510,16 +512,20 @@ int launch_best_alignment_generic(const float* match, const float* links, const 
             if (rcw) return rcw;
             hipLaunchKernelGGL(dag_dense_kernel<1>, dim3(B, 1, NS), dim3(DP_THREADS), lds3, st, match, links, in, out_len, tgt_len,
                                alpha, (float*)nullptr, trace, B, T, L, TR, cnt, gran, tag_base);
-            int rc2 = check_launch("dag_best_alignment(dense)");
-            if (rc2) return rc2;
-            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
+            return check_launch("dag_best_alignment(dense)");
         }
     }
     long sR, sD, sB;
     const float* lk = transposed_links(links, B, L, TR, st, &sR, &sD, &sB);
     hipLaunchKernelGGL(dag_maxalpha_generic_kernel, dim3(B), dim3(DP_THREADS), lds, st, match, lk, out_len, tgt_len,
                        alpha, trace, B, T, L, TR, sR, sD, sB);
-    int rc = check_launch("dag_best_alignment(max-alpha)");
+    return check_launch("dag_best_alignment(max-alpha)");
+}
+
+int launch_best_alignment_generic(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                  float* alpha, int32_t* trace, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+{
+    int rc = launch_max_alpha_generic(match, links, out_len, tgt_len, alpha, trace, B, T, L, TR, st);
     if (rc) return rc;
     return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
 }

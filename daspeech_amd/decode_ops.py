@@ -195,7 +195,75 @@ def restore_valid_links(links: Tensor) -> Tensor:
 @torch.no_grad()
 def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_length: Tensor, pad: int, decode_beta: float = 1.0,
                    decode_viterbibeta: float = 1.0, joint: bool = True, src_upsample_scale: float = 0.5):
-    """`viterbi` / `jointviterbi` strategies of forward_decoder (s2s_conformer_dag_fastspeech2.py:244-304), batched on the GPU:
+    """`viterbi` / `jointviterbi` strategies of forward_decoder (s2s_conformer_dag_fastspeech2.py:244-304) on the HIP max-DP.
+
+    The reference's loop `alpha, index = max(alpha[:, :, None] + dense_links, dim=1) [+ score * beta]` (:258-262) is the alignment
+    DP K6 with an emission row that does not depend on the step: row 0 of the DP is the start vertex alone (emission
+    `score[0]*beta` for jointviterbi, 0 otherwise), rows 1.. carry `score[j]*beta` (every row for jointviterbi, row 1 only for
+    viterbi, :252), and the emission of each sample's FINAL vertex is 0, so that `alpha_max[m+2, L_b-1]` is exactly the
+    reference's `max_j(scores[m][j] + links[j, L_b-1])` (:267-269) and `trace[m+2, L_b-1]` its arg-max (:278).  Same float
+    operations in the same order (one add per transition, max, one add per cell) and the same tie rule (smallest index), so
+    tokens and lengths are those of `viterbi_decode_torch`, which restates the reference loop.  The DP runs on the compact
+    links — the dense `[B, L, L]` restore and the L/4 torch launches per batch are gone."""
+    B, L, V = logits.shape
+    TR = links.shape[2]
+    dev = logits.device
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    sc, tok = logp.max(dim=-1)                                           # unreduced_logits / unreduced_tokens (:207-208)
+    max_length = max(1, int(L / 8 / src_upsample_scale))                 # (:256)
+    T = max_length + 2
+    olen = output_length.to(torch.int64).contiguous()
+    scb = (sc * decode_beta).contiguous()
+    match = (scb if joint else torch.zeros_like(scb)).unsqueeze(1).repeat(1, T, 1)
+    match[:, 1] = scb
+    if not joint:
+        match[:, 0] = 0
+    ar = torch.arange(B, device=dev)
+    match[ar, :, (olen - 1).clamp(min=0)] = 0
+    links_c = links.float().contiguous()
+    rows = torch.full((B,), T, dtype=torch.int64, device=dev)
+    amax = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+    trace = torch.empty((B, T, L), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_handle()
+        _lib.check(lib.dsp_dag_max_alpha(_lib.ptr(match), _lib.ptr(links_c), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(amax), _lib.ptr(trace),
+                                         B, T, L, TR, st), "dsp_dag_max_alpha")
+        best = amax[ar, 2:, (olen - 1).clamp(min=0)]                     # [B, M]: best score of every length (:267-269)
+        lengths = (torch.arange(max_length, device=dev) + 1).unsqueeze(0).float()
+        _, pred_length = torch.max(best / lengths ** decode_viterbibeta, dim=1)
+        pred_length = pred_length + 1                                    # (:275-276)
+        path = torch.empty((B, L), dtype=torch.int64, device=dev)
+        _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr((pred_length + 2).contiguous()), _lib.ptr(path), B, T, L, st),
+                   "dsp_dag_backtrace")
+    # vertices visited at DP rows 1 .. pred_length, in graph order (= the reference's reversed back-trace, :283-290)
+    on = (path >= 1) & (path <= pred_length.unsqueeze(1))
+    prev_tok = torch.full((B,), -12345, dtype=tok.dtype, device=dev)
+    # token kept if it is the LAST visited vertex, or (not pad and differs from the next visited token)   (:291-299, backward order)
+    vis_idx = torch.argsort((~on).to(torch.int8), dim=1, stable=True)   # visited vertices first, ascending
+    n_vis = on.sum(1)
+    Pm = int(n_vis.max().item()) if B else 0
+    vpath = vis_idx[:, :Pm]
+    vvalid = torch.arange(Pm, device=dev).unsqueeze(0) < n_vis.unsqueeze(1)
+    ptok = tok.gather(1, vpath)
+    nxt = torch.cat([ptok[:, 1:], prev_tok.unsqueeze(1)], dim=1)
+    nxt_valid = torch.cat([vvalid[:, 1:], torch.zeros((B, 1), dtype=torch.bool, device=dev)], dim=1)
+    is_last = vvalid & ~nxt_valid
+    keep = vvalid & (is_last | ((ptok != pad) & (ptok != nxt)))
+    n_keep = keep.sum(1)
+    fmax = int(n_keep.max().item()) if B else 0
+    order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+    fwd_path = vpath.gather(1, order)[:, :fmax]
+    fwd_tok = ptok.gather(1, order)[:, :fmax]
+    mask = torch.arange(fmax, device=dev).unsqueeze(0) >= n_keep.unsqueeze(1)
+    out_tok = fwd_tok.masked_fill(mask, pad)
+    out_feat = features.gather(1, fwd_path.unsqueeze(-1).expand(-1, -1, features.shape[-1])).masked_fill(mask.unsqueeze(-1), 0)
+    return out_tok, out_feat, mask, n_keep
+
+
+def viterbi_decode_torch(logits: Tensor, links: Tensor, features: Tensor, output_length: Tensor, pad: int, decode_beta: float = 1.0,
+                         decode_viterbibeta: float = 1.0, joint: bool = True, src_upsample_scale: float = 0.5):
+    """The same decode as a restatement of the reference loop in torch (device-agnostic; the checker of `viterbi_decode`):
     max_length = int(L / 8 / scale) max-product steps over the dense links, length-normalised best end, back-trace by batched
     gathers (the reference back-traces per sample on the host).  Returns like graph_decode."""
     B, L, V = logits.shape

@@ -108,6 +108,19 @@ int dsp_dag_best_alignment(const float* match, const float* links, const int64_t
                            float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                            dsp_stream_t stream);
 
+/* The two halves of the alignment, separately — what the Viterbi graph decode needs
+ * (s2s_conformer_dag_fastspeech2.py:244-304: max-product steps over the links, THEN the length is chosen, THEN the back-trace):
+ *   dsp_dag_max_alpha   alpha_max[b,t,j] = match[b,t,j] + max_d(alpha_max[b,t-1,j-d] + links[b,j-d,d-1]) and its arg-max
+ *                       trace[b,t,j] = j-d (smallest index among equal maxima, -1 if none) for EVERY cell j >= t of rows
+ *                       t < tgt_len[b] — no pruning of cells that cannot reach (tgt_len-1, out_len-1), unlike the fused op;
+ *   dsp_dag_backtrace   path[b,j] = t for the vertices on the chain trace[...] from (tgt_len[b]-1, out_len[b]-1), else -1;
+ *                       tgt_len may differ from the one the DP ran with (any row it filled).
+ */
+int dsp_dag_max_alpha(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                      float* alpha_max, int32_t* trace, int B, int T, int L, int TR, dsp_stream_t stream);
+int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L,
+                      dsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family: 0 = auto, 1 = generic row-sequential, 2 = banded

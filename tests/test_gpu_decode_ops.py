@@ -182,3 +182,32 @@ def test_fused_extract_links_matches_torch_formulation(TRmax):
     # every row with a successor is a distribution over its valid transitions
     rows = fin.any(-1)
     torch.testing.assert_close(torch.logsumexp(got[rows], -1), torch.zeros_like(got[rows][:, 0]), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("joint", [True, False])
+@pytest.mark.parametrize("shape", [(3, 40, 6), (4, 96, 95), (2, 260, 259), (5, 128, 32), (2, 1000, 999)])
+def test_viterbi_decode_hip_matches_reference_loop_restatement(shape, joint):
+    """viterbi / jointviterbi decode on the HIP max-DP (dsp_dag_max_alpha + dsp_dag_backtrace) vs the torch restatement of the
+    reference loop (s2s_conformer_dag_fastspeech2.py:244-304; itself pinned to the per-sample Python loop in
+    tests/test_torch_variants.py): identical tokens, lengths, masks and gathered features, with <pad> emissions, repeated
+    tokens, ragged graph sizes, banded and full transition windows, and quantised scores that force ties."""
+    from daspeech_amd import decode_ops
+    B, L, TR = shape
+    V, D, pad = 13, 8, 1
+    g = torch.Generator().manual_seed(17 + L + TR)
+    logits = torch.randn(B, L, V, generator=g) * 2
+    logits[:, ::4, pad] += 6
+    logits[:, 1::5] = logits[:, 2::5][:, : logits[:, 1::5].shape[1]] if L >= 10 else logits[:, 1::5]     # repeated argmax tokens
+    raw = torch.round(torch.randn(B, L, TR, generator=g) * 4) / 4                                        # ties
+    out_len = torch.randint(max(3, L - 9), L + 1, (B,), generator=g); out_len[0] = L
+    i = torch.arange(L).view(1, L, 1); d = torch.arange(TR).view(1, 1, TR)
+    valid = (i + d + 1) < out_len.view(B, 1, 1)
+    links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1)
+    links = links.masked_fill(~valid, float("-inf"))
+    feats = torch.randn(B, L, D, generator=g)
+    dev = "cuda"
+    for beta, vb in ((1.0, 1.0), (0.5, 1.3)):
+        got = decode_ops.viterbi_decode(logits.to(dev), links.to(dev), feats.to(dev), out_len.to(dev), pad, beta, vb, joint, 0.5)
+        ref = decode_ops.viterbi_decode_torch(logits.to(dev), links.to(dev), feats.to(dev), out_len.to(dev), pad, beta, vb, joint, 0.5)
+        assert torch.equal(got[3], ref[3]), (got[3], ref[3])
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[1], ref[1])

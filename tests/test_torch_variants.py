@@ -115,7 +115,7 @@ def test_viterbi_decode_matches_loop_restatement(joint):
     links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1)
     links = links.masked_fill(~valid, float("-inf"))
     feats = torch.randn(B, L, D)
-    toks, of, mask, n = decode_ops.viterbi_decode(logits, links, feats, out_len, pad, 1.0, 1.0, joint, 0.5)
+    toks, of, mask, n = decode_ops.viterbi_decode_torch(logits, links, feats, out_len, pad, 1.0, 1.0, joint, 0.5)
     ref = _viterbi_reference_loop(logits, decode_ops.restore_valid_links(links), feats, out_len.tolist(), pad, 1.0, 1.0, joint, 0.5)
     for b, (res, fl) in enumerate(ref):
         assert n[b].item() == len(res)
