@@ -59,3 +59,31 @@ class S2SNATGenerator:
                 item["waveform"] = wavs[b]
             res.append(item)
         return res
+
+
+MAX_WAV_VALUE = 32768.0          # hifi-gan/meldataset.py:13, inference_e2e.py:52
+
+
+def dump_results(results_path, sample_ids, results, sampling_rate: int = 22050, write_features: bool = True, write_waveforms: bool = True):
+    """Optional file sinks in the reference's formats, for its downstream ASR-BLEU scripts:
+      feat/<id>.npy                 float32 [80, T]   (generate_features.py:87-91 — the feature transposed)
+      wav/<id>_generated_e2e.wav    int16 mono        (hifi-gan/inference_e2e.py:50-56 — audio * 32768 cast to int16)
+    `results` is the list `S2SNATGenerator.generate` returns.  Returns the written paths."""
+    import os
+    import numpy as np
+    from scipy.io.wavfile import write as wav_write
+    written = []
+    feat_dir, wav_dir = os.path.join(results_path, "feat"), os.path.join(results_path, "wav")
+    for sid, item in zip(sample_ids, results):
+        if write_features and item.get("feature") is not None:
+            os.makedirs(feat_dir, exist_ok=True)
+            path = os.path.join(feat_dir, f"{sid}.npy")
+            np.save(path, item["feature"].detach().float().cpu().numpy().transpose(1, 0))
+            written.append(path)
+        if write_waveforms and item.get("waveform") is not None:
+            os.makedirs(wav_dir, exist_ok=True)
+            path = os.path.join(wav_dir, f"{sid}_generated_e2e.wav")
+            audio = (item["waveform"].detach().float().cpu().reshape(-1) * MAX_WAV_VALUE).numpy().astype("int16")
+            wav_write(path, sampling_rate, audio)
+            written.append(path)
+    return written

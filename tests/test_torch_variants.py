@@ -122,3 +122,20 @@ def test_viterbi_decode_matches_loop_restatement(joint):
         assert toks[b, : len(res)].tolist() == res and (toks[b, len(res):] == pad).all()
         torch.testing.assert_close(of[b, : len(res)], fl)
         assert (of[b, len(res):] == 0).all() and mask[b].tolist() == [False] * len(res) + [True] * (toks.shape[1] - len(res))
+
+
+def test_generator_file_sinks_use_the_reference_formats(tmp_path):
+    """feat/<id>.npy is [80, T] float32 (generate_features.py:87-91), wav/<id>_generated_e2e.wav is int16 = audio * 32768
+    (inference_e2e.py:50-56)."""
+    import numpy as np
+    from scipy.io.wavfile import read as wav_read
+    from daspeech_amd.generator import dump_results
+    feat = torch.randn(7, 80)
+    wav = torch.tensor([0.0, 0.5, -0.5, 0.999, -1.0])
+    out = dump_results(str(tmp_path), ["utt_3", "utt_4"], [{"feature": feat, "waveform": wav}, {"feature": feat[:2]}])
+    assert len(out) == 3
+    f = np.load(tmp_path / "feat" / "utt_3.npy")
+    assert f.shape == (80, 7) and f.dtype == np.float32 and np.array_equal(f, feat.numpy().T)
+    sr, a = wav_read(tmp_path / "wav" / "utt_3_generated_e2e.wav")
+    assert sr == 22050 and a.dtype == np.int16 and a.tolist() == [0, 16384, -16384, 32735, -32768]
+    assert not (tmp_path / "wav" / "utt_4_generated_e2e.wav").exists()
