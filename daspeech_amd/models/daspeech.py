@@ -259,6 +259,32 @@ class S2TConformerDAGModel(nn.Module):
         self.decoder = DAGDecoder(self.args)
         self.synthetic_token_cycle = 0
 
+    # ---- reference checkpoints ----------------------------------------------------------------------
+    # fairseq saves {"model": state_dict, "cfg": ..., ...} (checkpoint_utils.py:288).  Parameter names here follow the reference
+    # modules, so the state dict loads key for key once the entries that are not parameters of this implementation are set
+    # aside: the tied output projection (a second name for decoder.embed_tokens.weight, s2t_conformer_dag.py:96-97), the length
+    # predictor embedding of the NAT base decoder (unused by the DAG decode), fairseq's `version` buffers and the
+    # `_float_tensor` placeholders of sinusoidal position tables.  UNVERIFIED against a released checkpoint (none is available
+    # offline): `strict=True` therefore reports every missing / unexpected key instead of guessing.
+    _IGNORED_CKPT_SUFFIXES = (".version", "._float_tensor", "decoder.embed_length.weight")
+
+    def load_reference_state_dict(self, ckpt: Dict, strict: bool = True):
+        sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and isinstance(ckpt["model"], dict) else ckpt
+        sd = {k: v for k, v in sd.items() if not k.endswith(self._IGNORED_CKPT_SUFFIXES)}
+        tied = sd.pop("decoder.output_projection.weight", None)
+        if tied is not None and "decoder.embed_tokens.weight" in sd and not torch.equal(tied, sd["decoder.embed_tokens.weight"]):
+            raise ValueError("checkpoint has an UNTIED decoder.output_projection (trained without --share-decoder-input-output-embed): "
+                             "not supported")
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in own]
+        bad_shape = [k for k in sd if k in own and tuple(sd[k].shape) != tuple(own[k].shape)]
+        if strict and (missing or unexpected or bad_shape):
+            raise KeyError(f"reference checkpoint does not match: missing={missing[:8]} unexpected={unexpected[:8]} shape={bad_shape[:8]} "
+                           f"({len(missing)}/{len(unexpected)}/{len(bad_shape)} keys)")
+        self.load_state_dict({k: v for k, v in sd.items() if k in own and k not in bad_shape}, strict=False)
+        return missing, unexpected
+
     # graph size: L = clamp(src_upsample_scale * src_frames, 2, max_target_positions)   (s2t_conformer_dag.py:281-283)
     def initialize_output_tokens_by_src(self, src_lengths: Tensor, max_src_len: int = None) -> Tensor:
         """`max_src_len` (the padded frame count of the batch, a host integer) spares the device->host sync on `L.max()`; the

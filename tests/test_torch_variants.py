@@ -139,3 +139,28 @@ def test_generator_file_sinks_use_the_reference_formats(tmp_path):
     sr, a = wav_read(tmp_path / "wav" / "utt_3_generated_e2e.wav")
     assert sr == 22050 and a.dtype == np.int16 and a.tolist() == [0, 16384, -16384, 32735, -32768]
     assert not (tmp_path / "wav" / "utt_4_generated_e2e.wav").exists()
+
+
+def test_model_loads_a_fairseq_style_checkpoint_dict():
+    """checkpoint["model"] with the extra fairseq entries (tied output projection, version buffers, sinusoidal placeholders) loads
+    key for key; a renamed or missing parameter is reported, not guessed."""
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model
+    kw = dict(encoder_layers=1, decoder_layers=1, vocab_size=32, tts=dict(enc_layers=1, dec_layers=1))
+    torch.manual_seed(0)
+    src = S2SConformerDAGFastSpeech2Model(**kw)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    sd["decoder.output_projection.weight"] = sd["decoder.embed_tokens.weight"].clone()
+    sd["decoder.version"] = torch.tensor([3.0]); sd["encoder.version"] = torch.tensor([1.0])
+    sd["encoder.embed_positions._float_tensor"] = torch.zeros(1)
+    torch.manual_seed(1)
+    dst = S2SConformerDAGFastSpeech2Model(**kw)
+    missing, unexpected = dst.load_reference_state_dict({"model": sd, "cfg": None})
+    assert not missing and not unexpected
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    bad = dict(sd); bad["decoder.layers.0.fc3.weight"] = torch.zeros(2); del bad["adaptor.fc1.bias"]
+    with pytest.raises(KeyError, match="fc3"):
+        dst.load_reference_state_dict({"model": bad})
+    untied = dict(sd); untied["decoder.output_projection.weight"] = untied["decoder.output_projection.weight"] + 1
+    with pytest.raises(ValueError):
+        dst.load_reference_state_dict({"model": untied})
