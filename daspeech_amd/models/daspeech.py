@@ -118,9 +118,11 @@ class ConformerLayer(nn.Module):
         x = x + 0.5 * self._ffn(self.ffn1, x)
         x = x + self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask)
         c = self.conv_module
-        y = c["layer_norm"](x).transpose(1, 2)
-        y = F.glu(c["pointwise_conv1"](y), dim=1)
-        y = c["pointwise_conv2"](F.silu(c["batch_norm"](c["depthwise_conv"](y)))).transpose(1, 2)
+        # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
+        # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
+        y = F.glu(F.linear(c["layer_norm"](x), c["pointwise_conv1"].weight.squeeze(-1)), dim=-1)
+        y = F.silu(c["batch_norm"](c["depthwise_conv"](y.transpose(1, 2))))
+        y = F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1))
         x = x + y
         x = x + 0.5 * self._ffn(self.ffn2, x)
         return self.final_layer_norm(x)
