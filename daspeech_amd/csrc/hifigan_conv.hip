@@ -255,8 +255,12 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
     const int h1 = p.dil * (p.ntaps - 1) / 2, h2 = (p.ntaps - 1) / 2;
     const int R1 = NTI + 2 * h1;
     const size_t xin_bytes = (size_t)R1 * C * 2, ot_bytes = (size_t)NT * OPITCH * 2;
+    // ONE LDS region, three tenants in turn: the x tile, then the intermediate (written from the accumulators only after every wave
+    // has finished c1 — the whole intermediate tile sits in registers across that barrier), then the output tile.  Half the LDS of
+    // separate regions: C = 128 fits twice per CU, C = 64 four times.
+    (void)xin_bytes; (void)ot_bytes;
     char* xin = smem;
-    char* mid = smem + ((xin_bytes > ot_bytes ? xin_bytes : ot_bytes) + 255) / 256 * 256;
+    char* mid = smem;
     const _Float16* X = p.x + (size_t)b * p.T * C;
     const _Float16 slope = (_Float16)p.slope;
 
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
 
     // ---- c1 over the NTI intermediate columns -> mid = lrelu(fp16(acc + b1)), zero outside [0,T) ----
     conv(p.w1, xin, 0, p.dil);
+    __syncthreads();                                  // every wave is done reading the x tile: its space becomes the intermediate
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int co = co_base + i * 16 + lk * 4;
@@ -327,11 +332,12 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
             *reinterpret_cast<uint2*>(mid + ((size_t)m * CH + hg_swz<C>(m, co >> 3)) * 16 + (co & 4) * 2) = *reinterpret_cast<uint2*>(hv);
         }
     }
-    __syncthreads();                                  // mid complete; xin is dead from here on (its space becomes the output tile)
+    __syncthreads();                                  // intermediate complete
 
     // ---- c2 over the NT output columns ----
     conv(p.w2, mid, 8 - h2, 1);
-    _Float16* otile = reinterpret_cast<_Float16*>(xin);
+    __syncthreads();                                  // every wave is done reading the intermediate: its space becomes the output tile
+    _Float16* otile = reinterpret_cast<_Float16*>(smem);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = co_base + i * 16 + lk * 4;
@@ -379,12 +385,19 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
     }
 }
 
+// the three tenants of the unit's LDS region: x tile, intermediate (+ 16 slack rows, see conv()), output tile
+static size_t hg_unit_lds(int C, int NT, int h1)
+{
+    const size_t xin = (size_t)(NT + 16 + 2 * h1) * C * 2, mid = (size_t)(NT + 32) * C * 2, ot = (size_t)NT * (C + 8) * 2;
+    const size_t m = xin > mid ? xin : mid;
+    return ((m > ot ? m : ot) + 255) / 256 * 256;
+}
+
 template <int C, int NT, int WM, int WN>
 static int hg_unit_launch(const HgUnitParams& p, hipStream_t st)
 {
     const int h1 = p.dil * (p.ntaps - 1) / 2;
-    const size_t xin = (size_t)(NT + 16 + 2 * h1) * C * 2, ot = (size_t)NT * (C + 8) * 2;
-    const size_t lds = ((xin > ot ? xin : ot) + 255) / 256 * 256 + (size_t)(NT + 32) * C * 2;      // + 16 slack rows, see conv()
+    const size_t lds = hg_unit_lds(C, NT, h1);
     if (lds > 160 * 1024) { set_error("hifigan_resunit: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = hifigan_resunit_kernel<C, NT, WM, WN>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -496,8 +509,9 @@ static int hg_unit_one(const void* x, const void* w1, const float* b1, const voi
     // only fuses C <= 64 (dsp_hifigan_resunit_supported)
     switch (C) {
         case 128: return hg_unit_launch<128, 240, 4, 2>(p, st);
-        case 64:  return hg_unit_launch<64, 240, 2, 4>(p, st);
-        case 32:  return hg_unit_launch<32, 496, 1, 8>(p, st);
+        // the wider tile (half the weight-fragment loads per MFMA, 6 % faster at B=32) only when it still gives two workgroups per CU
+        case 64:  return (long)((T + 495) / 496) * B >= 512 ? hg_unit_launch<64, 496, 2, 4>(p, st) : hg_unit_launch<64, 240, 2, 4>(p, st);
+        case 32:  return (long)((T + 1007) / 1008) * B >= 512 ? hg_unit_launch<32, 1008, 1, 8>(p, st) : hg_unit_launch<32, 496, 1, 8>(p, st);
     }
     set_error("hifigan_resunit: unsupported channel count %d (32, 64, 128)", C);
     return DSP_EINVAL;
@@ -512,10 +526,9 @@ extern "C" int dsp_hifigan_resunit(const void* x, const void* w1, const float* b
 
 extern "C" int dsp_hifigan_resunit_supported(int C, int ntaps, int dil)
 {
-    if (!(C == 32 || C == 64) || ntaps < 1 || !(ntaps & 1) || ntaps > DSP_HG_MAX_TAPS || dil < 1) return 0;
-    const int h1 = dil * (ntaps - 1) / 2, NT = (C == 32) ? 496 : 240;
-    const size_t xin = (size_t)(NT + 16 + 2 * h1) * C * 2, ot = (size_t)NT * (C + 8) * 2;
-    return ((xin > ot ? xin : ot) + 255) / 256 * 256 + (size_t)(NT + 32) * C * 2 <= 160 * 1024;
+    if (!(C == 32 || C == 64 || C == 128) || ntaps < 1 || !(ntaps & 1) || ntaps > DSP_HG_MAX_TAPS || dil < 1) return 0;
+    const int h1 = dil * (ntaps - 1) / 2, NT = (C == 32) ? 1008 : (C == 64) ? 496 : 240;        // the largest tile the launcher may pick
+    return hg_unit_lds(C, NT, h1) <= 160 * 1024;
 }
 
 // The generator is ~100 of these layers per call; driven one ctypes call at a time the host, not the GPU, sets the pace at
