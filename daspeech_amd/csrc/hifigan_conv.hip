@@ -505,8 +505,7 @@ static int hg_unit_one(const void* x, const void* w1, const float* b1, const voi
     HgUnitParams p;
     p.x = (const _Float16*)x; p.w1 = (const _Float16*)w1; p.b1 = b1; p.w2 = (const _Float16*)w2; p.b2 = b2; p.out = (_Float16*)out;
     p.B = B; p.T = T; p.ntaps = ntaps; p.dil = dil; p.accumulate = accumulate; p.slope = slope; p.scale = scale;
-    // C = 128 fits (142 KB of LDS, one workgroup per CU) but is slower than its two-launch chain (441 vs 2 x 200 us at B=32): the host
-    // only fuses C <= 64 (dsp_hifigan_resunit_supported)
+    // C = 128: 78 KB per workgroup, two per CU (353 us per unit vs 2 x 200 us for its two-launch chain at B=32)
     switch (C) {
         case 128: return hg_unit_launch<128, 240, 4, 2>(p, st);
         // the wider tile (half the weight-fragment loads per MFMA, 6 % faster at B=32) only when it still gives two workgroups per CU
