@@ -507,6 +507,7 @@ static int hg_unit_one(const void* x, const void* w1, const float* b1, const voi
     p.B = B; p.T = T; p.ntaps = ntaps; p.dil = dil; p.accumulate = accumulate; p.slope = slope; p.scale = scale;
     // C = 128: 78 KB per workgroup, two per CU (353 us per unit vs 2 x 200 us for its two-launch chain at B=32)
     switch (C) {
+        case 256: return hg_unit_launch<256, 112, 8, 1>(p, st);
         case 128: return hg_unit_launch<128, 240, 4, 2>(p, st);
         // the wider tile (half the weight-fragment loads per MFMA, 6 % faster at B=32) only when it still gives two workgroups per CU
         case 64:  return (long)((T + 495) / 496) * B >= 512 ? hg_unit_launch<64, 496, 2, 4>(p, st) : hg_unit_launch<64, 240, 2, 4>(p, st);
@@ -525,8 +526,8 @@ extern "C" int dsp_hifigan_resunit(const void* x, const void* w1, const float* b
 
 extern "C" int dsp_hifigan_resunit_supported(int C, int ntaps, int dil)
 {
-    if (!(C == 32 || C == 64 || C == 128) || ntaps < 1 || !(ntaps & 1) || ntaps > DSP_HG_MAX_TAPS || dil < 1) return 0;
-    const int h1 = dil * (ntaps - 1) / 2, NT = (C == 32) ? 1008 : (C == 64) ? 496 : 240;        // the largest tile the launcher may pick
+    if (!(C == 32 || C == 64 || C == 128 || C == 256) || ntaps < 1 || !(ntaps & 1) || ntaps > DSP_HG_MAX_TAPS || dil < 1) return 0;
+    const int h1 = dil * (ntaps - 1) / 2, NT = (C == 32) ? 1008 : (C == 64) ? 496 : (C == 128) ? 240 : 112;        // the largest tile the launcher may pick
     return hg_unit_lds(C, NT, h1) <= 160 * 1024;
 }
 

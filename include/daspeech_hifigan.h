@@ -54,7 +54,7 @@ int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_
 /* One ResBlock1 unit (hifi-gan/models.py:38-42: xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x) in one launch, the
  * intermediate kept in LDS:  out = scale * (x + b2 + c2(lrelu(b1 + c1(lrelu(x))))) [+ out if accumulate].
  * c1 = Conv1d(C, C, ntaps, dilation dil), c2 = Conv1d(C, C, ntaps, dilation 1), "same" padding; w1, w2 packed from [ntaps][C][C] fp16;
- * x, out [B,T,C] fp16, out != x.  Bit-identical to the two dsp_hifigan_conv launches it replaces.  C in {32, 64, 128}, ntaps odd.
+ * x, out [B,T,C] fp16, out != x.  Bit-identical to the two dsp_hifigan_conv launches it replaces.  C in {32, 64, 128, 256}, ntaps odd.
  * dsp_hifigan_resunit_supported() says whether a (C, ntaps, dil) unit fits the LDS tiling. */
 int dsp_hifigan_resunit(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
                         int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate, dsp_stream_t stream);

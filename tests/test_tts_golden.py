@@ -144,7 +144,7 @@ def test_hifigan_fused_resblock_unit_bit_identical_to_layer_chain():
     st = _lib.current_stream_handle()
     # T * B large enough selects the wide tiles (C=64: 496 columns, C=32: 1008), small T the narrow ones
     for C, K, dil, T in ((32, 11, 5, 1000), (32, 3, 1, 497), (64, 7, 3, 481), (64, 11, 5, 7), (128, 11, 5, 250), (128, 3, 1, 239),
-                         (32, 7, 3, 258111), (64, 11, 5, 127003), (64, 3, 1, 126976)):
+                         (32, 7, 3, 258111), (64, 11, 5, 127003), (64, 3, 1, 126976), (256, 11, 5, 300), (256, 3, 1, 111), (256, 7, 3, 113)):
         assert lib.dsp_hifigan_resunit_supported(C, K, dil)
         x = (torch.randn(2, T, C, device="cuda") * 1.5).half()
         from daspeech_amd.hifigan_ops import pack_weights
@@ -161,4 +161,4 @@ def test_hifigan_fused_resblock_unit_bit_identical_to_layer_chain():
             _lib.check(lib.dsp_hifigan_conv(_lib.ptr(h), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(x), _lib.ptr(o2), 2, T, C, C, K, sh2, 0.1, 1.0 / 3,
                                             1 if accumulate else 0, 1, 0, T, C, st), "conv")
             assert torch.equal(o1, o2), (C, K, dil, T, accumulate, (o1.float() - o2.float()).abs().max().item())
-    assert not lib.dsp_hifigan_resunit_supported(256, 3, 1) and not lib.dsp_hifigan_resunit_supported(64, 4, 1)
+    assert not lib.dsp_hifigan_resunit_supported(512, 3, 1) and not lib.dsp_hifigan_resunit_supported(64, 4, 1)
