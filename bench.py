@@ -52,6 +52,7 @@ def parse():
                          "default fp32, the mode the mel parity (<= 1e-4) is stated for")
     ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"],
                     help="s2tt / s2st: graph decode mode (the reference's test_scripts run lookahead and jointviterbi)")
+    ap.add_argument("--vocoder-group", type=int, default=8, help="s2st: utterances per vocoder call (length-sorted groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
     elif args.workload == "s2st":
         model.eval()
         voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
-        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev))
+        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=args.vocoder_group)
         frames = [0]
 
         def step(i):
