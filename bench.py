@@ -105,6 +105,7 @@ def run_model_workload(args, torch, dist, dev, world, rank):
         torch.cuda.synchronize()
 
     extra = {}
+    roof = None
     amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
     if args.workload == "s2tt":
         model.eval()
@@ -168,12 +169,30 @@ def run_model_workload(args, torch, dist, dev, world, rank):
         elapsed = float(tt.item())
     if args.workload == "s2st":
         extra["mel_frames_per_utt"] = frames[0] / max(1, (args.steps + args.warmup) * B)
+        # roofline of the pipeline's dominant hand-written kernel family, the HiFi-GAN conv stack (MFMA bound, 0.614 GFLOP per mel
+        # frame): one vocoder call of the pipeline's group shape, timed with events on the launch stream
+        if rank == 0 and args.vocoder_backend == "hip":
+            Tm = max(8, int(round(extra["mel_frames_per_utt"])))
+            mel = torch.randn(args.vocoder_group, 80, Tm, device=dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    voc(mel)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    voc(mel)
+                e1.record(); torch.cuda.synchronize()
+            v_ms = e0.elapsed_time(e1) / 5
+            tf = 0.614e9 * args.vocoder_group * Tm / (v_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "HiFi-GAN V1 generator conv stack (hifigan_conv / hifigan_resunit kernels), one call of "
+                                               f"{args.vocoder_group} x {Tm} frames", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": tf / 2500.0, "traffic": None, "avg_call_ms": v_ms}
     result = {
         "metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ("f32" if args.amp == "none" else args.amp) if args.workload in ("s2st", "s2tt") else ("bf16" if args.amp == "bf16" else "fp16"), "data": "synthetic",
         "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"dp{world}", **extra},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roof, "cpu_baseline": None,
     }
     if rank == 0:
         print(json.dumps(result))
