@@ -17,6 +17,31 @@
 
 namespace dsp {
 
+// streaming accesses of the row kernels.  NT = non-temporal.  The in-place BACKWARD reads a row and overwrites it: with both the loads
+// and the stores non-temporal it runs 1.70 -> 1.59 ms at C2 fp32 (either alone: no change; r01f sweep, same box, same run).
+typedef unsigned int lsg_u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 lsg_ld16(const void* p)
+{
+    if constexpr (NT) {
+        const lsg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const lsg_u4*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void lsg_st16(void* p, const uint4& o)
+{
+    if constexpr (NT) {
+        lsg_u4 v; v.x = o.x; v.y = o.y; v.z = o.z; v.w = o.w;
+        __builtin_nontemporal_store(v, reinterpret_cast<lsg_u4*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = o;
+    }
+}
+
+
 template <typename T> struct Vec;                 // 16-byte vector of T
 template <> struct Vec<float> { static constexpr int N = 4; };
 template <> struct Vec<__half> { static constexpr int N = 8; };
@@ -175,7 +200,7 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int v = (k * 256 + tid) * N;
-                if (v < V) dst[k] = *reinterpret_cast<const uint4*>(row + v);
+                if (v < V) dst[k] = lsg_ld16<false>(row + v);
             }
         };
         // The S gathered logits of a row are requested TOGETHER WITH the row itself (one iteration before they are used): the
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
                         T* e = reinterpret_cast<T*>(&o);
 #pragma unroll
                         for (int i = 0; i < N; ++i) e[i] = from_f<T>(__expf(f[k][i] - m) * inv);
-                        *reinterpret_cast<uint4*>(row + v) = o;
+                        lsg_st16<false>(row + v, o);
                     }
                 }
             }
@@ -261,6 +286,133 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
             for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { graw[u] = gnx[u]; gnx[u] = gn2[u]; }
+        }
+        __syncthreads();
+        const int tot = S * nr;
+        if (osj == 1 || oss != 1) {
+            for (int e = tid; e < tot; e += 256) {
+                int k = e / nr, r = e - k * nr;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        } else {
+            for (int e = tid; e < tot; e += 256) {
+                int r = e / S, k = e - r * S;
+                out[b * osb + (int64_t)(j0 + r) * osj + k * oss] = stage[k * RT + r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Register-resident forward, gathers from LDS.  lsg_fwd_reg_kernel takes the S gathered logits of a row from global memory and
+// therefore needs the row's lines to stay in L2 (temporal loads).  Here the raw row is also parked in LDS (V * sizeof(T) bytes) and
+// the gathers read it there, so the row stream can be non-temporal both ways like the backward's (C2 fp32: 1.75 -> 1.62 ms with the softmax store, 1.13 -> 1.02 ms
+// without; bf16 1.19 -> 1.05 ms), the
+// gather costs no L2 traffic at all, and the two-rows-ahead gather registers are gone.  Two workgroup barriers per row: the row
+// image is single (a second 32 KB image would halve the occupancy).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void lsg_fwd_regl_kernel(
+    T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
+    float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
+    int B, int L, int V, int S, int RT, int write_softmax, float* __restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                // 2 x 16 floats (alternating per row)
+    float* stage = smem + 32;         // [S][RT]
+    T* rowbuf = reinterpret_cast<T*>(stage + (size_t)S * RT);     // [V] raw logits of the current row
+    constexpr int N = Vec<T>::N;
+    const int tid = threadIdx.x;
+    const int tiles_per_b = (L + RT - 1) / RT;
+    const long ntiles = (long)B * tiles_per_b;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_b);
+        const int j0 = (int)(tile % tiles_per_b) * RT;
+        const int nr = min(RT, L - j0);
+        uint4 cur[NV], nxt[NV], nx2[NV];
+        auto load_row = [&](int r, uint4 (&dst)[NV]) {
+            const T* row = x + ((size_t)b * L + (j0 + r)) * V;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                if (v < V) dst[k] = lsg_ld16<true>(row + v);
+            }
+        };
+        int tk[8], tkn[8];
+        auto load_tok = [&](int r, int (&dst)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = tid + u * 256;
+                dst[u] = 0;
+                if (k < S) {
+                    const int64_t t = idx[b * isb + (int64_t)(j0 + r) * isj + k * iss];
+                    dst[u] = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
+                }
+            }
+        };
+        load_row(0, cur); load_tok(0, tk);
+        if (nr > 1) { load_row(1, nxt); load_tok(1, tkn); }
+        for (int r = 0; r < nr; ++r) {
+            T* row = x + ((size_t)b * L + (j0 + r)) * V;
+            if (r + 2 < nr) load_row(r + 2, nx2);
+            float f[NV][N];
+            float m = NEG_INF;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                const T* e = reinterpret_cast<const T*>(&cur[k]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { f[k][i] = (v < V) ? to_f(e[i]) : NEG_INF; m = fmaxf(m, f[k][i]); }
+            }
+            float s = 0.f;
+            if (m != NEG_INF) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s += __expf(f[k][i] - m);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+                online_merge(m, s, m2, s2);
+            }
+            __syncthreads();                                       // every wave has finished gathering the previous row from rowbuf
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int v = (k * 256 + tid) * N;
+                if (v < V) *reinterpret_cast<uint4*>(rowbuf + v) = cur[k];
+            }
+            float* rs = red + ((r & 1) << 4);
+            if ((tid & 63) == 0) { rs[tid >> 6] = m; rs[8 + (tid >> 6)] = s; }
+            __syncthreads();
+            m = rs[0]; s = rs[8];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) online_merge(m, s, rs[w], rs[8 + w]);
+            const float ls = __logf(s);
+            if (stats && tid == 0) { float* st2 = stats + 2 * ((size_t)b * L + (j0 + r)); st2[0] = m; st2[1] = 1.f / s; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = tid + u * 256;
+                if (k < S) stage[k * RT + r] = (to_f(rowbuf[tk[u]]) - m) - ls;
+            }
+            if (write_softmax) {
+                const float inv = 1.f / s;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int v = (k * 256 + tid) * N;
+                    if (v < V) {
+                        uint4 o;
+                        T* e = reinterpret_cast<T*>(&o);
+#pragma unroll
+                        for (int i = 0; i < N; ++i) e[i] = from_f<T>(__expf(f[k][i] - m) * inv);
+                        lsg_st16<true>(row + v, o);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tk[u] = tkn[u];
+            if (r + 2 < nr) load_tok(r + 2, tkn);
         }
         __syncthreads();
         const int tot = S * nr;
@@ -343,7 +495,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_kernel(
 // different workgroups on 8 XCDs: 0.27 GB of gradients cost 1.2 GB of FETCH_SIZE at C2.  Here the [S][RT] gradient tile is
 // staged through LDS with 4*RT-byte runs along j, the softmax row is register-resident with the next row prefetched (as in
 // lsg_fwd_reg_kernel), and the per-row scatter image in LDS is unchanged.
-template <typename T, int NV, bool LAZY>
+template <typename T, int NV, bool LAZY, int NTM = 3>       // NTM: bit 0 non-temporal row loads, bit 1 non-temporal row stores
 __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
@@ -368,7 +520,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int v = (k * 256 + tid) * N;
-                if (v < V) dst[k] = *reinterpret_cast<const uint4*>(row + v);
+                if (v < V) dst[k] = lsg_ld16<(NTM & 1) != 0>(row + v);
             }
         };
         uint4 nx2[NV];
@@ -410,7 +562,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
 #pragma unroll
                     for (int i = 0; i < N; ++i)
                         eo[i] = from_f<T>((LAZY ? __expf(to_f(e[i]) - rm) * rinv : to_f(e[i])) * neg + delta[v + i]);     // dag_loss.py:293-295
-                    *reinterpret_cast<uint4*>(row + v) = o;
+                    lsg_st16<(NTM & 2) != 0>(row + v, o);
                 }
             }
             __syncthreads();
@@ -443,6 +595,24 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
     const int nvec = (V + 256 * N - 1) / (256 * N);
     if (vec && nvec <= 8 && S <= 8 * 256) {
         auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : lsg_fwd_reg_kernel<T, 8>);
+        {
+            // LDS-gather variant: row image V * sizeof(T) + stage [S][RTg] must leave two workgroups per CU
+            static int gl = -1;
+            if (gl < 0) { const char* e = getenv("DSP_K1_GL"); gl = e ? atoi(e) : 1; }          // DSP_K1_GL=0: the global-gather kernel
+            int RTg = 16;
+            while (RTg > 1 && (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4 > 78 * 1024) RTg >>= 1;
+            const size_t ldsg = (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4;
+            if (gl && ldsg <= 78 * 1024 && L >= RTg && (S * RTg) % 4 == 0) {
+                auto kg = nvec <= 2 ? lsg_fwd_regl_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_regl_kernel<T, 4> : lsg_fwd_regl_kernel<T, 8>);
+                const long nt = (long)B * ((L + RTg - 1) / RTg);
+                int gridg = (int)(nt < 4096 ? nt : 4096);
+                if (getenv("DSP_K1_GRID")) gridg = atoi(getenv("DSP_K1_GRID"));
+                if (ldsg > 48 * 1024) (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+                hipLaunchKernelGGL(kg, dim3(gridg), dim3(256), ldsg, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
+                                   B, L, V, S, RTg, ws, stats);
+                return check_launch("logsoftmax_gather(reg, LDS gather)");
+            }
+        }
         int RTr = RT, gridr = grid;
         // storing the softmax makes the launch a 1:1 read/write stream: two resident workgroups per CU (64 KB of stage per
         // workgroup at RT = 32) sustain 4.9 TB/s, four only 4.1 TB/s (sweep in tools/k1_bench.py, r01)
