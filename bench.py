@@ -135,7 +135,8 @@ def run_model_workload(args, torch, dist, dev, world, rank):
               f"B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"))
     else:
         model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01,
+                               fused=True)        # one multi-tensor kernel (fairseq uses its FusedAdam the same way); foreach: 73 ms, fused: 68.5 ms per step
         # the reference trains with fairseq's --fp16 (README.md:241,274: fp16 compute, dynamic loss scaling); --amp bf16 selects
         # bf16 autocast instead (no loss scaling; MIOpen falls back to a naive bf16 weight-gradient conv: 83 vs 72 ms per step)
         use_fp16 = args.amp != "bf16"
