@@ -310,15 +310,23 @@ __global__ __launch_bounds__(NT + 192) void dag_maxstrip_kernel(MStripParams p)
 // in bulk every few dozen hops.  Wave 0 then resolves the hops from LDS (lane d evaluates predecessor pos-1-d).
 constexpr int BT_HOPS = 10;
 constexpr int BT_LW = 768;                    // transition rows cached in LDS
-constexpr int BT_SEG = 64 * BT_HOPS;          // widest segment (frame one iteration old: up to 2*HOPS rows back)
-constexpr int BT_PER = (BT_HOPS * BT_SEG + 191) / 192;     // the three fetch waves (wave 0 resolves hops)
+constexpr int BT_SEG = 768;                   // segment pitch: >= 31 * 2 * HOPS + 1 (frame one iteration old: up to 2*HOPS rows back) and a
+                                              // multiple of the 192 fetch lanes, so that a lane's loads of a segment are base + q + 192 j
+constexpr int BT_PER = BT_HOPS * (BT_SEG / 192);           // loads per lane of the three fetch waves (wave 0 resolves hops)
+static_assert(BT_SEG % 192 == 0 && BT_SEG > 62 * BT_HOPS, "segment pitch");
 
-__device__ __forceinline__ float bt_row16_max(float v) {      // all-reduce max within each row of 16 lanes
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
-    return v;
+// Maximum of lanes 0..31 of a wave, as a wave-uniform value.  One DPP-modified v_max per step (the compiler's fmaxf + update_dpp
+// form is mov_dpp + two canonicalising v_max + v_max per step, and the hop is a chain of dependent instructions on ONE wave, so
+// instruction count is latency): four steps inside each row of 16, row_bcast:15 carries row 0's result into row 1, one readlane.
+// The inputs are never NaN.  s_nop 1: VALU write -> DPP read needs two wait states, which inline asm must provide itself.
+__device__ __forceinline__ float bt_max_lanes32(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 0" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
 }
 
 __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
@@ -342,37 +350,65 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
     // alpha_max[tF - HOPS - k][pF - 32(HOPS+k) .. pF - (HOPS+k)], a superset of what hop k of the next iteration can touch
     // (the path moves 1..32 vertices left per row), so the memory round trip overlaps the hop resolution of this iteration.
     float pre[BT_PER];
+    // (the per-element form of this loop — e / BT_SEG, e % BT_SEG, 64-bit address per load — spent ~1.4 us per iteration on
+    //  address arithmetic before the last load was even issued: r01g)
     auto fetch = [&](int tF, int pF) {
         if (tid < 64) return;
+        const int q0 = tid - 64;
 #pragma unroll
-        for (int u = 0; u < BT_PER; ++u) {
-            const int e = (tid - 64) + u * 192;
-            const int k = e / BT_SEG + 1, q = e % BT_SEG;
-            const int row = tF - BT_HOPS - k, col = pF - 32 * (BT_HOPS + k) + q;
-            float v = NEG_INF;
-            if (e < BT_HOPS * BT_SEG && q <= 31 * (BT_HOPS + k) && row >= 0 && col >= 0 && col < L) v = A[(size_t)row * L + col];
-            pre[u] = v;
+        for (int k = 1; k <= BT_HOPS; ++k) {
+            const int row = tF - BT_HOPS - k, col0 = pF - 32 * (BT_HOPS + k), qmax = 31 * (BT_HOPS + k);
+            const float* base = A + (long)(row < 0 ? 0 : row) * L + col0;       // wave-uniform
+#pragma unroll
+            for (int j = 0; j < BT_SEG / 192; ++j) {
+                const int q = q0 + 192 * j, col = col0 + q;
+                float v = NEG_INF;
+                if (row >= 0 && q <= qmax && col >= 0 && col < L) v = base[q];
+                pre[(k - 1) * (BT_SEG / 192) + j] = v;
+            }
         }
     };
     auto stash = [&]() {
         if (tid < 64) return;
+        const int q0 = tid - 64;
 #pragma unroll
-        for (int u = 0; u < BT_PER; ++u) { const int e = (tid - 64) + u * 192; if (e < BT_HOPS * BT_SEG) seg[e] = pre[u]; }
+        for (int k = 1; k <= BT_HOPS; ++k)
+#pragma unroll
+            for (int j = 0; j < BT_SEG / 192; ++j) seg[(k - 1) * BT_SEG + q0 + 192 * j] = pre[(k - 1) * (BT_SEG / 192) + j];
     };
     int tF = t + BT_HOPS, pF = pos + BT_HOPS;                            // pretend frame of the iteration before the first
     if (!done) { fetch(tF, pF); stash(); }
     __syncthreads();
     while (!done) {
         // (a) transition window: rows [pos - 32*HOPS, pos) must be cached
-        if (pos - 32 * BT_HOPS < lbase || pos > lbase + BT_LW) {
-            lbase = pos - BT_LW;
-            const long lo = (long)lbase * TR, n = (long)BT_LW * TR;
-            for (long e0 = tid; e0 < n; e0 += 8 * 256) {
-                float v[8];
+        if ((pos - 32 * BT_HOPS < lbase && lbase > 0) || pos > lbase + BT_LW) {
+            lbase = max(pos - BT_LW, 0);
+            const int nrow = min(BT_LW, L - lbase);                          // rows of the sample that exist
+            const long lo = (long)lbase * TR;
+            const int n = nrow * TR;
+            if ((TR & 3) == 0 && ((uintptr_t)(K + lo) & 15) == 0) {
+                // The window is 96 KB; the eight-loads-at-a-time loop this replaces took twelve dependent round trips (11 us per
+                // refill, 45 % of the kernel: r01g s_memtime accounting).  LDS-DMA: 24 requests per lane back to back, no registers —
+                // a register-staged version is re-serialised by the scheduler (load / s_waitcnt vmcnt(0) / ds_write per quad).
+                constexpr int NQ = BT_LW * 32 / 4 / 256;                     // 24 chunks of 64 quads per wave at TR = 32
+                const float4* src = reinterpret_cast<const float4*>(K + lo);
+                const int n4 = n >> 2, wave = tid >> 6;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const long e = e0 + u * 256; const long g = lo + e; v[u] = (e < n && g >= 0) ? K[g] : NEG_INF; }
+                for (int u = 0; u < NQ; ++u) {
+                    const int chunk = u * 4 + wave, e = chunk * 64 + lane;
+                    if (chunk * 64 < n4)                                    // wave-uniform; lanes past the end re-read quad 0 into rows nobody reads
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (e < n4 ? e : 0)),
+                                                         (__attribute__((address_space(3))) void*)(lk + chunk * 256), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                for (int e0 = tid; e0 < n; e0 += 8 * 256) {
+                    float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const long e = e0 + u * 256; if (e < n) lk[e] = v[u]; }
+                    for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; v[u] = (e < n) ? K[lo + e] : NEG_INF; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int e = e0 + u * 256; if (e < n) lk[e] = v[u]; }
+                }
             }
             __syncthreads();
         }
@@ -386,14 +422,12 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
                 if (t == 0 || pos < t) { done = true; break; }           // row 0 / under the diagonal: trace = -1
                 const int d = lane, i = pos - 1 - d;
                 float x = NEG_INF;
-                if (d < TR && i >= 0) x = seg[(h - 1) * BT_SEG + (i - (pF - 32 * (BT_HOPS + h)))] + lk[(size_t)(i - lbase) * TR + d];
-                const float r = bt_row16_max(x);                         // every lane: maximum of its row of 16
-                const float mx = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0)),
-                                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16)));
-                // the LARGEST d (smallest predecessor index) among the lanes that attain the maximum
-                const unsigned long long hit = __ballot(lane < 32 && x == mx && x != NEG_INF);
+                if (d < TR && i >= 0) x = seg[(h - 1) * BT_SEG + (i - (pF - 32 * (BT_HOPS + h)))] + lk[(i - lbase) * TR + d];
+                const float mx = bt_max_lanes32(x);                       // lanes >= TR (and so all of 32..63) hold -inf
                 --t;
-                if (hit == 0ull) { pos = -1; done = true; break; }
+                if (mx == NEG_INF) { pos = -1; done = true; break; }
+                // the LARGEST d (smallest predecessor index) among the lanes that attain the maximum: only candidates can equal a finite mx
+                const unsigned long long hit = __builtin_amdgcn_fcmp(x, mx, 1 /* FCMP_OEQ */);
                 pos = pos - 1 - (63 - __builtin_clzll(hit));
             }
             if (lane == 0) { s_state[0] = pos; s_state[1] = t; s_state[2] = done ? 1 : 0; }
