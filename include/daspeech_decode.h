@@ -39,7 +39,7 @@ int dsp_gather_rows(const void* features, int dtype, const int32_t* keep_idx, co
                     int B, int L, int D, int cap, int Fmax, dsp_stream_t stream);
 
 /* F0   transition log-probabilities of the graph, compact layout             (DAGDecoder.extract_links, s2t_conformer_dag.py:171-212)
- *   q, k [B,L,H,CK] fp32 (query_linear / key_linear of [features ; link positional embedding], H = 8 heads),
+ *   q, k [B,L,H,CK] fp32, CK = 32, 64 or 128 (query_linear / key_linear of [features ; link positional embedding], H = 8 heads),
  *   log_gates [B,L,H] fp32 (log_softmax of gate_linear), out_len [B] int64, dist_bias [TR] fp32 or NULL (benchmark calibration),
  *   scale = 1/sqrt(CK).  links[b,i,d] = logsumexp_h( log_softmax_d(q_i.k_{i+d+1} * scale, over valid successors) + log_gates[b,i,h] ),
  *   -inf where i+d+1 >= out_len[b] or >= L; rows without a successor are all -inf.  Only the band is computed — the reference's
