@@ -314,3 +314,21 @@ def viterbi_decode_torch(logits: Tensor, links: Tensor, features: Tensor, output
     out_tok = fwd_tok.masked_fill(mask, pad)
     out_feat = features.gather(1, fwd_path.clamp(min=0).unsqueeze(-1).expand(-1, -1, features.shape[-1])).masked_fill(mask.unsqueeze(-1), 0)
     return out_tok, out_feat, mask, n_keep
+
+
+def dwconv_bn_silu(x: Tensor, conv_weight: Tensor, bn: "torch.nn.BatchNorm1d") -> Tensor:
+    """SiLU(BatchNorm_eval(depthwise_conv1d(x))) on channels-last x [B,T,C] — the middle of the Conformer convolution module in
+    eval mode (include/daspeech_decode.h: dsp_dwconv_bn_silu).  conv_weight is the Conv1d(C, C, K, groups=C) weight [C,1,K]."""
+    _gpu("dwconv_bn_silu", x, conv_weight)
+    xf = x.detach().to(torch.float32).contiguous()
+    B, T, C = xf.shape
+    wt = conv_weight.detach().to(torch.float32).reshape(C, -1).contiguous()
+    K = wt.shape[1]
+    f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    bw, bb, bm, bv = f(bn.weight), f(bn.bias), f(bn.running_mean), f(bn.running_var)
+    lib = _lib.load()
+    with torch.cuda.device(xf.device):
+        y = torch.empty_like(xf)
+        _lib.check(lib.dsp_dwconv_bn_silu(_lib.ptr(xf), _lib.ptr(wt), _lib.ptr(bw), _lib.ptr(bb), _lib.ptr(bm), _lib.ptr(bv), float(bn.eps),
+                                          _lib.ptr(y), B, T, C, K, _lib.current_stream_handle()), "dsp_dwconv_bn_silu")
+    return y.to(x.dtype)

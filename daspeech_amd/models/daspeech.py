@@ -121,8 +121,13 @@ class ConformerLayer(nn.Module):
         # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
         # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
         y = F.glu(F.linear(c["layer_norm"](x), c["pointwise_conv1"].weight.squeeze(-1)), dim=-1)
-        y = F.silu(c["batch_norm"](c["depthwise_conv"](y.transpose(1, 2))))
-        y = F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1))
+        dw = c["depthwise_conv"]
+        if (not self.training and not torch.is_grad_enabled() and y.is_cuda and y.shape[-1] % 4 == 0
+                and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None):
+            y = decode_ops.dwconv_bn_silu(y, dw.weight, c["batch_norm"])       # one HIP pass on [B,T,C], no transposes
+        else:
+            y = F.silu(c["batch_norm"](dw(y.transpose(1, 2)))).transpose(1, 2)
+        y = F.linear(y, c["pointwise_conv2"].weight.squeeze(-1))
         x = x + y
         x = x + 0.5 * self._ffn(self.ffn2, x)
         return self.final_layer_norm(x)

@@ -69,6 +69,13 @@ int dsp_length_regulator_lens(const int64_t* dur, int64_t* cum, int64_t* out_len
 int dsp_length_regulator_expand(const void* x, int dtype, const int64_t* cum, void* out, int B, int N, int C, int maxlen,
                                 dsp_stream_t stream);
 
+/* Conformer convolution module, eval mode (fairseq conformer_layer.py ConvolutionModule: depthwise_conv -> batch_norm -> SiLU),
+ * on the channels-last tensor:   y[b,t,c] = SiLU( BN_eval( sum_k w[c,k] * x[b,t+k-(K-1)/2,c] ) ),  zero padding outside [0,T).
+ *   x, y [B,T,C] fp32 (16-byte aligned, C % 4 == 0, y != x); w [C,K] fp32 (the Conv1d(C,C,K,groups=C) weight [C,1,K]);
+ *   bn_w / bn_b may be NULL (affine off); K in {3, 7, 15, 31}. */
+int dsp_dwconv_bn_silu(const float* x, const float* w, const float* bn_w, const float* bn_b, const float* bn_mean,
+                       const float* bn_var, float eps, float* y, int B, int T, int C, int K, dsp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

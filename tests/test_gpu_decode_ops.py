@@ -211,3 +211,23 @@ def test_viterbi_decode_hip_matches_reference_loop_restatement(shape, joint):
         ref = decode_ops.viterbi_decode_torch(logits.to(dev), links.to(dev), feats.to(dev), out_len.to(dev), pad, beta, vb, joint, 0.5)
         assert torch.equal(got[3], ref[3]), (got[3], ref[3])
         assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("shape", [(3, 77, 64, 31), (2, 5, 256, 31), (1, 200, 8, 3), (4, 33, 128, 15), (2, 64, 32, 7)])
+def test_dwconv_bn_silu_matches_torch_module_chain(shape):
+    """dsp_dwconv_bn_silu (channels-last, one pass) vs the torch chain it replaces in the Conformer convolution module in eval mode:
+    transpose -> Conv1d(C, C, K, groups=C, bias=False) -> BatchNorm1d.eval() -> SiLU -> transpose; fp32, tolerance 1e-5 (different
+    summation order; MIOpen's naive kernel accumulates in double)."""
+    from daspeech_amd import decode_ops
+    B, T, C, K = shape
+    torch.manual_seed(5 + T)
+    dw = torch.nn.Conv1d(C, C, K, padding=(K - 1) // 2, groups=C, bias=False).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.3, 2.0)
+    x = torch.randn(B, T, C, device="cuda")
+    with torch.no_grad():
+        want = torch.nn.functional.silu(bn(dw(x.transpose(1, 2)))).transpose(1, 2)
+        got = decode_ops.dwconv_bn_silu(x, dw.weight, bn)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
