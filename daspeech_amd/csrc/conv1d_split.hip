@@ -1,0 +1,213 @@
+// conv1d_split.hip — fp32-accurate Conv1d on the fp16 matrix cores ("3 x fp16" split), for the FastSpeech2 FFT feed-forward
+// (fairseq/models/text_to_speech/fastspeech2.py:42-63 PositionwiseFeedForward: Conv1d(256,1024,9) - ReLU - Conv1d(1024,256,9)).
+//
+// MIOpen serves these fp32 convolutions at 60-70 TFLOP/s (1.0 / 1.2 ms each at B=32 x 483 frames: 9 of the 41 ms of the S2ST
+// pipeline).  The mel tolerance (1e-4) rules out plain fp16 operands, but not the matrix cores: with
+//     x = xh + xl * 2^-11,  w = wh + wl * 2^-11      (xh = fp16(x), xl = fp16((x - xh) * 2^11); same for w)
+// the three products  xh.wh,  xh.wl,  xl.wh  are EXACT in the fp32 accumulator (11 x 11 significant bits) and the dropped xl.wl term
+// is 2^-22 relative: fp32-GEMM accuracy at a third of the fp16 MFMA rate.  The lo parts carry their own 2^11 scale so that they live
+// in the normal fp16 range; their products go to a second accumulator that is folded in with 2^-11 at the end.
+//   x [B,T,CI] fp32 channels-last (row stride ldx), taps k with shift k - (K-1)/2 ("same" padding), weights pre-split and stored in
+//   MFMA fragment order (dsp_conv1d_split_pack), out [B,T,M] fp32 = [out +] bias + conv, optional ReLU.
+#include "common.h"
+#include "../../include/daspeech_decode.h"
+
+namespace dsp {
+
+typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+
+struct CsParams {
+    const float* x; const _Float16* wh; const _Float16* wl; const float* bias; float* out;
+    int B, T, M, ntaps; long ldx, ldo;
+    int relu, accumulate;
+};
+
+template <int CI>
+__device__ __forceinline__ int cs_swz(int row, int chunk) {
+    constexpr int CH = CI / 8;
+    constexpr int MASK = (CH < 16 ? CH : 16) - 1;
+    return chunk ^ (row & MASK);
+}
+
+template <int CI, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char cs_smem[];
+    constexpr int CH = CI / 8, NC = CI / 32;
+    constexpr int MI = MT / WM / 16, NI = NT / WN / 16;
+    static_assert(WM * WN == 8 && MI >= 1 && NI >= 1, "8 waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z, t0 = blockIdx.x * NT, m0 = blockIdx.y * MT;
+    const int P = (p.ntaps - 1) / 2;
+    const int R = NT + p.ntaps - 1;
+    char* th = cs_smem;                                   // hi tile  [R][CI] halves, 16-byte chunks XOR-swizzled
+    char* tl = cs_smem + (size_t)R * CI * 2;              // lo tile
+    const float* X = p.x + (size_t)b * p.T * p.ldx;
+
+    // ---- stage: rows t0-P .. t0+NT-1+P, zero outside [0,T); split into hi / lo*2^11 ----
+    for (int e = tid; e < R * CH; e += 512) {
+        const int row = e / CH, ch = e - row * CH;
+        const int tg = t0 - P + row;
+        cs_h8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tg >= 0 && tg < p.T) {
+            const float4 a = *reinterpret_cast<const float4*>(X + (size_t)tg * p.ldx + ch * 8);
+            const float4 c = *reinterpret_cast<const float4*>(X + (size_t)tg * p.ldx + ch * 8 + 4);
+            const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)f[i]; vl[i] = (_Float16)((f[i] - (float)vh[i]) * 2048.f); }
+        }
+        const size_t o = ((size_t)row * CH + cs_swz<CI>(row, ch)) * 16;
+        *reinterpret_cast<cs_h8*>(th + o) = vh;
+        *reinterpret_cast<cs_h8*>(tl + o) = vl;
+    }
+    __syncthreads();
+
+    cs_f4 acc0[MI][NI], acc1[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { acc0[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; }
+    const int co_base = m0 + wm * (MI * 16);
+    const int tl_base = wn * (NI * 16);
+    const int Mt = (p.M + 15) >> 4;
+    const int nsteps = p.ntaps * NC;
+    auto load_a = [&](int step, cs_h8 (&ah)[MI], cs_h8 (&al)[MI]) {
+        const size_t off = (size_t)step * Mt * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int tile = (co_base >> 4) + i;
+            const size_t o = off + (size_t)(tile < Mt ? tile : 0) * 512;
+            ah[i] = *reinterpret_cast<const cs_h8*>(p.wh + o);
+            al[i] = *reinterpret_cast<const cs_h8*>(p.wl + o);
+        }
+    };
+    auto do_step = [&](int step, const cs_h8 (&ah)[MI], const cs_h8 (&al)[MI]) {
+        const int k = step / NC, c = step - k * NC;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = tl_base + j * 16 + lr + k;
+            const size_t o = ((size_t)row * CH + cs_swz<CI>(row, c * 4 + lk)) * 16;
+            const cs_h8 bh = *reinterpret_cast<const cs_h8*>(th + o);
+            const cs_h8 bl = *reinterpret_cast<const cs_h8*>(tl + o);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc0[i][j], 0, 0, 0);
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc1[i][j], 0, 0, 0);
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc1[i][j], 0, 0, 0);
+            }
+        }
+    };
+    cs_h8 ah0[MI], al0[MI], ah1[MI], al1[MI];
+    load_a(0, ah0, al0);
+    for (int step = 0; step < nsteps; step += 2) {
+        if (step + 1 < nsteps) load_a(step + 1, ah1, al1);
+        do_step(step, ah0, al0);
+        if (step + 1 < nsteps) {
+            if (step + 2 < nsteps) load_a(step + 2, ah0, al0);
+            do_step(step + 1, ah1, al1);
+        }
+    }
+
+    // ---- epilogue: D fragment = 4 consecutive output channels of one frame per lane -> one 16-byte fp32 store ----
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int co = co_base + i * 16 + lk * 4;
+        if (co >= p.M) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = p.bias[co + e];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int t = t0 + tl_base + j * 16 + lr;
+            if (t >= p.T) continue;
+            float* O = p.out + ((size_t)b * p.T + t) * p.ldo + co;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc0[i][j][e] + acc1[i][j][e] * (1.f / 2048.f)) + bv[e];
+            if (p.accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(O);
+                v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<float4*>(O) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// fp32 weight [ntaps][M][CI] (tap-major) -> hi / lo fp16 in fragment order [ntaps][CI/32][ceil(M/16)][64][8] (see hifigan_conv.hip)
+__global__ void conv1d_split_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wh, _Float16* __restrict__ wl,
+                                         int ntaps, int M, int CI)
+{
+    const int Mt = (M + 15) >> 4, NC = CI / 32;
+    const long n = (long)ntaps * NC * Mt * 512;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e & 7), ln = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int tile = (int)(r % Mt); r /= Mt;
+        const int c = (int)(r % NC); const int k = (int)(r / NC);
+        const int co = tile * 16 + (ln & 15), ci = c * 32 + (ln >> 4) * 8 + h;
+        const float v = (co < M) ? w[((size_t)k * M + co) * CI + ci] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        wh[e] = hi;
+        wl[e] = (_Float16)((v - (float)hi) * 2048.f);
+    }
+}
+
+template <int CI, int MT, int NT, int WM, int WN>
+static int cs_launch(const CsParams& p, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * (NT + p.ntaps - 1) * CI * 2;
+    if (lds > 160 * 1024) { set_error("conv1d_split: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
+    auto k = conv1d_split_kernel<CI, MT, NT, WM, WN>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, (p.M + MT - 1) / MT, p.B), dim3(512), lds, st, p);
+    return check_launch("conv1d_split");
+}
+
+}  // namespace dsp
+
+using namespace dsp;
+
+extern "C" long dsp_conv1d_split_packed_elems(int ntaps, int M, int CI)
+{
+    if (ntaps < 1 || M < 1 || CI < 32 || (CI & 31)) return -1;
+    return (long)ntaps * (CI / 32) * ((M + 15) / 16) * 512;
+}
+
+extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream)
+{
+    const long n = dsp_conv1d_split_packed_elems(ntaps, M, CI);
+    if (n < 0 || !w_tap_major || !w_hi || !w_lo) { set_error("conv1d_split_pack: bad arguments"); return DSP_EINVAL; }
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(conv1d_split_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), w_tap_major, (_Float16*)w_hi, (_Float16*)w_lo, ntaps, M, CI);
+    return check_launch("conv1d_split_pack");
+}
+
+extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
+                                int B, int T, int CI, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream)
+{
+    if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || ldx < CI || ldo < M || (ldx & 3) || (ldo & 3)) {
+        set_error("conv1d_split: bad sizes B=%d T=%d CI=%d M=%d taps=%d", B, T, CI, M, ntaps); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!x || !w_hi || !w_lo || !out) { set_error("conv1d_split: null pointer"); return DSP_EINVAL; }
+    if ((((uintptr_t)x) | ((uintptr_t)out)) & 15) { set_error("conv1d_split: x / out must be 16-byte aligned"); return DSP_EINVAL; }
+    CsParams p;
+    p.x = x; p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.bias = bias; p.out = out;
+    p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
+    hipStream_t st = as_stream(stream);
+    switch (CI) {
+        case 256: return cs_launch<256, 256, 128, 8, 1>(p, st);
+        case 512: return cs_launch<512, 256, 64, 8, 1>(p, st);
+        case 128: return cs_launch<128, 128, 256, 4, 2>(p, st);
+    }
+    set_error("conv1d_split: unsupported input channel count %d (128, 256, 512; wider inputs: accumulate over 512-channel slices)", CI);
+    return DSP_EINVAL;
+}

@@ -6,6 +6,7 @@ Host-side mirror of the reference code these replace:
   predicted_durations / bucketize_embed_add / length_regulate   fairseq/fairseq/models/text_to_speech/fastspeech2.py:98-114,169-210
 No CPU fallback: GPU tensors only.
 """
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -332,3 +333,42 @@ def dwconv_bn_silu(x: Tensor, conv_weight: Tensor, bn: "torch.nn.BatchNorm1d") -
         _lib.check(lib.dsp_dwconv_bn_silu(_lib.ptr(xf), _lib.ptr(wt), _lib.ptr(bw), _lib.ptr(bb), _lib.ptr(bm), _lib.ptr(bv), float(bn.eps),
                                           _lib.ptr(y), B, T, C, K, _lib.current_stream_handle()), "dsp_dwconv_bn_silu")
     return y.to(x.dtype)
+
+
+class SplitConv1d:
+    """fp32-accurate Conv1d(Cin, Cout, K, padding=(K-1)//2) on the fp16 matrix cores (include/daspeech_decode.h: dsp_conv1d_split).
+    Packs the weight once (hi / lo fp16 in MFMA fragment order, per 512-channel input slice); call with channels-last x [B,T,Cin]."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor]):
+        _gpu("SplitConv1d", weight)
+        lib = _lib.load()
+        Cout, Cin, K = weight.shape
+        self.Cout, self.Cin, self.K = Cout, Cin, K
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        step = Cin if Cin <= 512 else 512
+        assert Cin % step == 0 and step in (128, 256, 512) and Cout % 4 == 0 and K % 2 == 1, (Cin, Cout, K)
+        self.slices = []
+        with torch.cuda.device(weight.device):
+            st = _lib.current_stream_handle()
+            for c0 in range(0, Cin, step):
+                wt = weight.detach().float()[:, c0:c0 + step, :].permute(2, 0, 1).contiguous()        # [K][Cout][step]
+                n = lib.dsp_conv1d_split_packed_elems(K, Cout, step)
+                hi = torch.empty((n,), dtype=torch.float16, device=weight.device); lo = torch.empty_like(hi)
+                _lib.check(lib.dsp_conv1d_split_pack(_lib.ptr(wt), _lib.ptr(hi), _lib.ptr(lo), K, Cout, step, st), "dsp_conv1d_split_pack")
+                self.slices.append((c0, step, hi, lo))
+
+    def __call__(self, x: Tensor, relu: bool = False) -> Tensor:
+        _gpu("SplitConv1d", x)
+        assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == self.Cin and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+        B, T, _ = x.shape
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            st = _lib.current_stream_handle()
+            out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
+            last = len(self.slices) - 1
+            for n, (c0, step, hi, lo) in enumerate(self.slices):
+                xs = x[:, :, c0:c0 + step]
+                _lib.check(lib.dsp_conv1d_split(ctypes.c_void_p(xs.data_ptr()), x.stride(1), _lib.ptr(hi), _lib.ptr(lo),
+                                                _lib.ptr(self.bias) if n == 0 else None, _lib.ptr(out), self.Cout, B, T, step, self.Cout, self.K,
+                                                1 if (relu and n == last) else 0, 1 if n > 0 else 0, st), "dsp_conv1d_split")
+        return out

@@ -65,6 +65,19 @@ class _ConvFFN(nn.Module):
         self.layer_norm = nn.LayerNorm(dim)
 
     def forward(self, x: Tensor) -> Tensor:
+        if (not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                and not torch.is_autocast_enabled() and self.ffn[0].weight.dtype == torch.float32 and x.is_contiguous()):
+            # eval, fp32: both convolutions on the matrix cores at fp32 accuracy (operand splitting), channels-last, no transposes
+            key = (self.ffn[0].weight.data_ptr(), self.ffn[0].weight._version, self.ffn[2].weight.data_ptr(), self.ffn[2].weight._version)
+            if getattr(self, "_split_key", None) != key:
+                from ..decode_ops import SplitConv1d
+                c1, c2 = self.ffn[0], self.ffn[2]
+                ok = all(c.stride == (1,) and c.dilation == (1,) and c.groups == 1 and c.padding == ((c.kernel_size[0] - 1) // 2,) for c in (c1, c2))
+                ok = ok and all(ci % 128 == 0 and (ci <= 512 and ci in (128, 256, 512) or ci % 512 == 0) for ci in (c1.in_channels, c2.in_channels))
+                self._split = (SplitConv1d(c1.weight, c1.bias), SplitConv1d(c2.weight, c2.bias)) if ok else None
+                self._split_key = key
+            if self._split is not None:
+                return self.layer_norm(self._split[1](self._split[0](x, relu=True)) + x)
         return self.layer_norm(self.ffn(x.transpose(1, 2)).transpose(1, 2) + x)
 
 

@@ -231,3 +231,36 @@ def test_dwconv_bn_silu_matches_torch_module_chain(shape):
         got = decode_ops.dwconv_bn_silu(x, dw.weight, bn)
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 77, 256, 1024, 9), (3, 130, 1024, 256, 9), (1, 5, 128, 64, 3), (2, 64, 512, 256, 1), (2, 200, 256, 256, 3)])
+def test_split_precision_conv1d_is_fp32_accurate(shape):
+    """dsp_conv1d_split (3 x fp16 MFMA, operand splitting) against an fp64 reference of the same Conv1d: its error must be of the order
+    of an fp32 convolution's own rounding error (measured beside it: torch's fp32 conv1d vs fp64), far inside the 1e-4 mel tolerance —
+    including values across 12 binades (the lo parts must not fall into the fp16 denormals), ReLU, bias, 512-channel input slices."""
+    from daspeech_amd.decode_ops import SplitConv1d
+    B, T, Cin, Cout, K = shape
+    torch.manual_seed(11 + T)
+    conv = torch.nn.Conv1d(Cin, Cout, K, padding=(K - 1) // 2).cuda()
+    x = torch.randn(B, T, Cin, device="cuda") * torch.exp2(torch.randint(-8, 5, (B, T, 1), device="cuda").float())
+    sc = SplitConv1d(conv.weight, conv.bias)
+    for relu in (False, True):
+        with torch.no_grad():
+            got = sc(x, relu=relu)
+            ref64 = torch.nn.functional.conv1d(x.double().transpose(1, 2), conv.weight.double(), conv.bias.double(), padding=(K - 1) // 2).transpose(1, 2)
+            ref32 = conv(x.transpose(1, 2)).transpose(1, 2)
+            if relu:
+                ref64 = ref64.clamp_min(0); ref32 = ref32.clamp_min(0)
+        scale = ref64.abs().max().item()
+        err = (got.double() - ref64).abs().max().item() / scale
+        err32 = (ref32.double() - ref64).abs().max().item() / scale
+        assert got.shape == (B, T, Cout) and torch.isfinite(got).all()
+        assert err < 4e-6 and err < 8 * err32 + 1e-6, (err, err32)
+    # a channel slice of a wider tensor as input (row stride > Cin)
+    if Cin <= 512:
+        wide = torch.randn(B, T, Cin + 64, device="cuda")
+        xs = wide[:, :, :Cin]
+        with torch.no_grad():
+            got = sc(xs)
+            ref = conv(xs.transpose(1, 2).contiguous()).transpose(1, 2)
+        torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
