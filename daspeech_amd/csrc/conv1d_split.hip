@@ -20,7 +20,7 @@ typedef float cs_f4 __attribute__((ext_vector_type(4)));
 struct CsParams {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; float* out;
     int B, T, M, ntaps; long ldx, ldo;
-    int relu, accumulate;
+    int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU
 };
 
 template <int CI>
@@ -133,9 +133,12 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
                 const float4 old = *reinterpret_cast<const float4*>(O);
                 v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
             }
-            if (p.relu) {
+            if (p.relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.relu == 2) {                  // SiLU
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
             }
             *reinterpret_cast<float4*>(O) = make_float4(v[0], v[1], v[2], v[3]);
         }

@@ -357,8 +357,11 @@ class SplitConv1d:
                 _lib.check(lib.dsp_conv1d_split_pack(_lib.ptr(wt), _lib.ptr(hi), _lib.ptr(lo), K, Cout, step, st), "dsp_conv1d_split_pack")
                 self.slices.append((c0, step, hi, lo))
 
-    def __call__(self, x: Tensor, relu: bool = False) -> Tensor:
+    ACT = {None: 0, "relu": 1, "silu": 2}
+
+    def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None) -> Tensor:
         _gpu("SplitConv1d", x)
+        code = 1 if relu else self.ACT[act]
         assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == self.Cin and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
         B, T, _ = x.shape
         lib = _lib.load()
@@ -370,5 +373,23 @@ class SplitConv1d:
                 xs = x[:, :, c0:c0 + step]
                 _lib.check(lib.dsp_conv1d_split(ctypes.c_void_p(xs.data_ptr()), x.stride(1), _lib.ptr(hi), _lib.ptr(lo),
                                                 _lib.ptr(self.bias) if n == 0 else None, _lib.ptr(out), self.Cout, B, T, step, self.Cout, self.K,
-                                                1 if (relu and n == last) else 0, 1 if n > 0 else 0, st), "dsp_conv1d_split")
+                                                code if n == last else 0, 1 if n > 0 else 0, st), "dsp_conv1d_split")
         return out
+
+
+def split_linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -> Optional[Tensor]:
+    """act(x @ W^T + b) at fp32 accuracy on the fp16 matrix cores (a SplitConv1d with one tap), or None when the shape / mode is not
+    served (caller falls back to F.linear): eval-mode inference in fp32 on the GPU, in_features 128 / 256 / 512 or a multiple of 512,
+    out_features % 4 == 0, at least 256 rows.  The packed weight is cached on the module."""
+    if (torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or lin.weight.dtype != torch.float32
+            or x.dim() != 3 or not x.is_contiguous() or x.shape[0] * x.shape[1] < 256):
+        return None
+    cin, cout = lin.in_features, lin.out_features
+    if not ((cin in (128, 256, 512) or (cin > 512 and cin % 512 == 0)) and cout % 4 == 0):
+        return None
+    key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version)
+    cache = getattr(lin, "_dsp_split", None)
+    if cache is None or cache[0] != key:
+        cache = (key, SplitConv1d(lin.weight.unsqueeze(-1), lin.bias))
+        lin._dsp_split = cache
+    return cache[1](x, act=act)

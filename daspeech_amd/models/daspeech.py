@@ -112,7 +112,14 @@ class ConformerLayer(nn.Module):
 
     @staticmethod
     def _ffn(m, x):
-        return m["w_2"](F.silu(m["w_1"](m["layer_norm"](x))))
+        h = m["layer_norm"](x)
+        if not m["w_1"].training:
+            y = decode_ops.split_linear(h, m["w_1"], act="silu")          # fp32-accurate GEMMs on the fp16 matrix cores (eval, fp32)
+            if y is not None:
+                z = decode_ops.split_linear(y, m["w_2"])
+                if z is not None:
+                    return z
+        return m["w_2"](F.silu(m["w_1"](h)))
 
     def forward(self, x, pos, pad_mask):
         x = x + 0.5 * self._ffn(self.ffn1, x)
