@@ -20,7 +20,7 @@ typedef float cs_f4 __attribute__((ext_vector_type(4)));
 struct CsParams {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; float* out;
     int B, T, M, ntaps; long ldx, ldo;
-    int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU
+    int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
 };
 
 template <int CI>
@@ -139,6 +139,9 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
             } else if (p.relu == 2) {                  // SiLU
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            } else if (p.relu == 3) {                  // GELU (erf form, torch's default)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
             *reinterpret_cast<float4*>(O) = make_float4(v[0], v[1], v[2], v[3]);
         }

@@ -357,7 +357,7 @@ class SplitConv1d:
                 _lib.check(lib.dsp_conv1d_split_pack(_lib.ptr(wt), _lib.ptr(hi), _lib.ptr(lo), K, Cout, step, st), "dsp_conv1d_split_pack")
                 self.slices.append((c0, step, hi, lo))
 
-    ACT = {None: 0, "relu": 1, "silu": 2}
+    ACT = {None: 0, "relu": 1, "silu": 2, "gelu": 3}
 
     def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None) -> Tensor:
         _gpu("SplitConv1d", x)
@@ -393,3 +393,15 @@ def split_linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -
         cache = (key, SplitConv1d(lin.weight.unsqueeze(-1), lin.bias))
         lin._dsp_split = cache
     return cache[1](x, act=act)
+
+
+def linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -> Tensor:
+    """act(lin(x)): through split_linear where it applies (eval-mode fp32 inference on the GPU), torch otherwise."""
+    if not lin.training:
+        y = split_linear(x, lin, act)
+        if y is not None:
+            return y
+    y = lin(x)
+    if act is None:
+        return y
+    return {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act](y)

@@ -83,9 +83,10 @@ class RelPosSelfAttention(nn.Module):
 
     def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
         B, T, C = x.shape
-        q = self.linear_q(x).view(B, T, self.h, self.dk)
-        k = self.linear_k(x).view(B, T, self.h, self.dk).transpose(1, 2)
-        v = self.linear_v(x).view(B, T, self.h, self.dk).transpose(1, 2)
+        L_ = decode_ops.linear
+        q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
+        k = L_(x, self.linear_k).view(B, T, self.h, self.dk).transpose(1, 2)
+        v = L_(x, self.linear_v).view(B, T, self.h, self.dk).transpose(1, 2)
         p = self.linear_pos(pos).view(1, -1, self.h, self.dk).transpose(1, 2)
         ac = torch.matmul((q + self.pos_bias_u).transpose(1, 2), k.transpose(-2, -1))
         bd = self.rel_shift(torch.matmul((q + self.pos_bias_v).transpose(1, 2), p.transpose(-2, -1)))
@@ -93,7 +94,7 @@ class RelPosSelfAttention(nn.Module):
         if pad_mask is not None:
             scores = scores.masked_fill(pad_mask.view(B, 1, 1, T), float("-inf"))
         att = torch.softmax(scores, dim=-1)
-        return self.linear_out(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C))
+        return decode_ops.linear(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C), self.linear_out)
 
 
 class ConformerLayer(nn.Module):
@@ -154,7 +155,7 @@ class ConformerEncoder(nn.Module):
         x, lens = self.subsample(src_tokens, src_lengths)
         T = x.shape[1]
         pad_mask = torch.arange(T, device=x.device).unsqueeze(0) >= lens.unsqueeze(1)
-        x = self.linear(self.embed_scale * x)
+        x = decode_ops.linear(self.embed_scale * x, self.linear)
         pos = rel_positional_encoding(T, x.shape[-1], x.device, x.dtype)
         for layer in self.conformer_layers:
             x = layer(x, pos, pad_mask)
@@ -173,14 +174,15 @@ class _MHA(nn.Module):
     def forward(self, x, mem, mem_pad):
         B, N, C = x.shape
         M = mem.shape[1]
-        q = self.q_proj(x).view(B, N, self.h, -1).transpose(1, 2)
-        k = self.k_proj(mem).view(B, M, self.h, -1).transpose(1, 2)
-        v = self.v_proj(mem).view(B, M, self.h, -1).transpose(1, 2)
+        L_ = decode_ops.linear
+        q = L_(x, self.q_proj).view(B, N, self.h, -1).transpose(1, 2)
+        k = L_(mem, self.k_proj).view(B, M, self.h, -1).transpose(1, 2)
+        v = L_(mem, self.v_proj).view(B, M, self.h, -1).transpose(1, 2)
         mask = None
         if mem_pad is not None:
             mask = torch.zeros(B, 1, 1, M, dtype=x.dtype, device=x.device).masked_fill(mem_pad.view(B, 1, 1, M), float("-inf"))
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+        return decode_ops.linear(o.transpose(1, 2).reshape(B, N, C), self.out_proj)
 
 
 class NATDecoderLayer(nn.Module):
@@ -195,7 +197,7 @@ class NATDecoderLayer(nn.Module):
     def forward(self, x, self_pad, enc, enc_pad):
         x = self.self_attn_layer_norm(x + self.self_attn(x, x, self_pad))
         x = self.encoder_attn_layer_norm(x + self.encoder_attn(x, enc, enc_pad))
-        return self.final_layer_norm(x + self.fc2(F.gelu(self.fc1(x))))
+        return self.final_layer_norm(x + decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2))
 
 
 class DAGDecoder(nn.Module):
@@ -236,8 +238,8 @@ class DAGDecoder(nn.Module):
         B, L, d = feats.shape
         h, ck = a.decoder_attention_heads, d // a.decoder_attention_heads
         fp = torch.cat([feats, self.link_positional(self.positions(prev_output_tokens))], dim=-1)
-        q = self.query_linear(fp).view(B, L, h, ck).float()
-        k = self.key_linear(fp).view(B, L, h, ck).float()
+        q = decode_ops.linear(fp, self.query_linear).view(B, L, h, ck).float()
+        k = decode_ops.linear(fp, self.key_linear).view(B, L, h, ck).float()
         log_gates = F.log_softmax(self.gate_linear(fp), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
         if feats.is_cuda and not torch.is_grad_enabled() and h == 8 and ck % 4 == 0 and ck <= 128 and TR >= 1 and self.fused_links:

@@ -33,7 +33,8 @@ class FFNAdapter(nn.Module):
         self.fc2 = nn.Linear(hidden_size, output_size)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.fc2(F.relu(self.fc1(x)))
+        from ..decode_ops import linear
+        return linear(linear(x, self.fc1, act="relu"), self.fc2)
 
 
 class _SelfAttention(nn.Module):
@@ -47,14 +48,15 @@ class _SelfAttention(nn.Module):
     def forward(self, x: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
         B, N, C = x.shape
         h = self.heads
-        q = self.q_proj(x).view(B, N, h, C // h).transpose(1, 2)
-        k = self.k_proj(x).view(B, N, h, C // h).transpose(1, 2)
-        v = self.v_proj(x).view(B, N, h, C // h).transpose(1, 2)
+        from ..decode_ops import linear as L_                 # fp32-accurate split GEMM in eval-mode fp32 inference, torch otherwise
+        q = L_(x, self.q_proj).view(B, N, h, C // h).transpose(1, 2)
+        k = L_(x, self.k_proj).view(B, N, h, C // h).transpose(1, 2)
+        v = L_(x, self.v_proj).view(B, N, h, C // h).transpose(1, 2)
         mask = None
         if padding_mask is not None:
             mask = torch.zeros(B, 1, 1, N, dtype=x.dtype, device=x.device).masked_fill(padding_mask.view(B, 1, 1, N), float("-inf"))
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+        return L_(o.transpose(1, 2).reshape(B, N, C), self.out_proj)
 
 
 class _ConvFFN(nn.Module):
