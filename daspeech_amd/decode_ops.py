@@ -377,12 +377,22 @@ class SplitConv1d:
         return out
 
 
+SPLIT_GEMM = True          # set_split_gemm(False): every Linear / FFT convolution goes back to torch (hipBLASLt / MIOpen fp32)
+
+
+def set_split_gemm(on: bool) -> bool:
+    """Switch the fp32-accurate matrix-core GEMM / conv path of eval-mode inference on or off; returns the previous setting."""
+    global SPLIT_GEMM
+    old, SPLIT_GEMM = SPLIT_GEMM, bool(on)
+    return old
+
+
 def split_linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -> Optional[Tensor]:
     """act(x @ W^T + b) at fp32 accuracy on the fp16 matrix cores (a SplitConv1d with one tap), or None when the shape / mode is not
     served (caller falls back to F.linear): eval-mode inference in fp32 on the GPU, in_features 128 / 256 / 512 or a multiple of 512,
-    out_features % 4 == 0, at least 256 rows.  The packed weight is cached on the module."""
-    if (torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or lin.weight.dtype != torch.float32
-            or x.dim() != 3 or not x.is_contiguous() or x.shape[0] * x.shape[1] < 256):
+    out_features % 4 == 0, at least 128 rows.  The packed weight is cached on the module."""
+    if (not SPLIT_GEMM or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or lin.weight.dtype != torch.float32
+            or x.dim() != 3 or not x.is_contiguous() or x.shape[0] * x.shape[1] < 128):
         return None
     cin, cout = lin.in_features, lin.out_features
     if not ((cin in (128, 256, 512) or (cin > 512 and cin % 512 == 0)) and cout % 4 == 0):

@@ -67,7 +67,8 @@ class _ConvFFN(nn.Module):
         self.layer_norm = nn.LayerNorm(dim)
 
     def forward(self, x: Tensor) -> Tensor:
-        if (not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+        from .. import decode_ops as _dops
+        if (_dops.SPLIT_GEMM and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
                 and not torch.is_autocast_enabled() and self.ffn[0].weight.dtype == torch.float32 and x.is_contiguous()):
             # eval, fp32: both convolutions on the matrix cores at fp32 accuracy (operand splitting), channels-last, no transposes
             key = (self.ffn[0].weight.data_ptr(), self.ffn[0].weight._version, self.ffn[2].weight.data_ptr(), self.ffn[2].weight._version)
