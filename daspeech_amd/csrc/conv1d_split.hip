@@ -21,6 +21,7 @@ struct CsParams {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; float* out;
     int B, T, M, ntaps; long ldx, ldo;
     int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
+    int nslices; long wslice;      // the input is nslices x CI channels wide; slice s uses weights + s * wslice (halves)
 };
 
 template <int CI>
@@ -47,14 +48,29 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     char* tl = cs_smem + (size_t)R * CI * 2;              // lo tile
     const float* X = p.x + (size_t)b * p.T * p.ldx;
 
+    cs_f4 acc0[MI][NI], acc1[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { acc0[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; }
+    const int co_base = m0 + wm * (MI * 16);
+    const int tl_base = wn * (NI * 16);
+    const int Mt = (p.M + 15) >> 4;
+    const int nsteps = p.ntaps * NC;
+    // input slices of CI channels one after the other through the same LDS tiles; the accumulators stay in registers
+    for (int sl = 0; sl < p.nslices; ++sl) {
+    const float* Xs = X + (size_t)sl * CI;
+    const _Float16* WH = p.wh + (size_t)sl * p.wslice;
+    const _Float16* WL = p.wl + (size_t)sl * p.wslice;
+    if (sl) __syncthreads();                              // every wave is done with the previous slice's tiles
     // ---- stage: rows t0-P .. t0+NT-1+P, zero outside [0,T); split into hi / lo*2^11 ----
     for (int e = tid; e < R * CH; e += 512) {
         const int row = e / CH, ch = e - row * CH;
         const int tg = t0 - P + row;
         cs_h8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
         if (tg >= 0 && tg < p.T) {
-            const float4 a = *reinterpret_cast<const float4*>(X + (size_t)tg * p.ldx + ch * 8);
-            const float4 c = *reinterpret_cast<const float4*>(X + (size_t)tg * p.ldx + ch * 8 + 4);
+            const float4 a = *reinterpret_cast<const float4*>(Xs + (size_t)tg * p.ldx + ch * 8);
+            const float4 c = *reinterpret_cast<const float4*>(Xs + (size_t)tg * p.ldx + ch * 8 + 4);
             const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)f[i]; vl[i] = (_Float16)((f[i] - (float)vh[i]) * 2048.f); }
@@ -65,23 +81,14 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     }
     __syncthreads();
 
-    cs_f4 acc0[MI][NI], acc1[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) { acc0[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (cs_f4){0.f, 0.f, 0.f, 0.f}; }
-    const int co_base = m0 + wm * (MI * 16);
-    const int tl_base = wn * (NI * 16);
-    const int Mt = (p.M + 15) >> 4;
-    const int nsteps = p.ntaps * NC;
     auto load_a = [&](int step, cs_h8 (&ah)[MI], cs_h8 (&al)[MI]) {
         const size_t off = (size_t)step * Mt * 512 + lane * 8;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int tile = (co_base >> 4) + i;
             const size_t o = off + (size_t)(tile < Mt ? tile : 0) * 512;
-            ah[i] = *reinterpret_cast<const cs_h8*>(p.wh + o);
-            al[i] = *reinterpret_cast<const cs_h8*>(p.wl + o);
+            ah[i] = *reinterpret_cast<const cs_h8*>(WH + o);
+            al[i] = *reinterpret_cast<const cs_h8*>(WL + o);
         }
     };
     auto do_step = [&](int step, const cs_h8 (&ah)[MI], const cs_h8 (&al)[MI]) {
@@ -109,6 +116,8 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
             if (step + 2 < nsteps) load_a(step + 2, ah0, al0);
             do_step(step + 1, ah1, al1);
         }
+    }
+
     }
 
     // ---- epilogue: D fragment = 4 consecutive output channels of one frame per lane -> one 16-byte fp32 store ----
@@ -198,9 +207,10 @@ extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void*
 }
 
 extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
-                                int B, int T, int CI, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream)
+                                int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream)
 {
-    if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || ldx < CI || ldo < M || (ldx & 3) || (ldo & 3)) {
+    if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || nslices < 1 || ldx < (long)CI * nslices || ldo < M ||
+        (ldx & 3) || (ldo & 3)) {
         set_error("conv1d_split: bad sizes B=%d T=%d CI=%d M=%d taps=%d", B, T, CI, M, ntaps); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
     if (!x || !w_hi || !w_lo || !out) { set_error("conv1d_split: null pointer"); return DSP_EINVAL; }
@@ -208,12 +218,13 @@ extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, cons
     CsParams p;
     p.x = x; p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.bias = bias; p.out = out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
+    p.nslices = nslices; p.wslice = dsp_conv1d_split_packed_elems(ntaps, M, CI);
     hipStream_t st = as_stream(stream);
     switch (CI) {
         case 256: return cs_launch<256, 256, 128, 8, 1>(p, st);
         case 512: return cs_launch<512, 256, 64, 8, 1>(p, st);
         case 128: return cs_launch<128, 128, 256, 4, 2>(p, st);
     }
-    set_error("conv1d_split: unsupported input channel count %d (128, 256, 512; wider inputs: accumulate over 512-channel slices)", CI);
+    set_error("conv1d_split: unsupported slice width %d (128, 256, 512; wider inputs are nslices slices)", CI);
     return DSP_EINVAL;
 }

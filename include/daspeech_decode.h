@@ -80,14 +80,15 @@ int dsp_dwconv_bn_silu(const float* x, const float* w, const float* bn_w, const 
  * the products xh.wh, xh.wl, xl.wh are exact in the fp32 accumulator, the dropped xl.wl term is 2^-22 relative) — for the
  * FastSpeech2 FFT feed-forward convolutions (fairseq fastspeech2.py:42-63), which MIOpen runs at 60-70 TFLOP/s in fp32.
  *   dsp_conv1d_split_pack   fp32 weight, tap-major [ntaps][M][CI] -> w_hi, w_lo (dsp_conv1d_split_packed_elems halves each)
- *   dsp_conv1d_split        x [B,T,CI] fp32, row stride ldx (a channel slice of a wider tensor is fine); out [B,T,M] fp32, row
- *                           stride ldo;  out = act([out +] bias + conv(x)), act = relu: 0 none, 1 ReLU, 2 SiLU, 3 GELU (erf).  ntaps = 1 is a
- *                           Linear layer.  CI in {128, 256, 512}: a wider input is summed
+ *   dsp_conv1d_split        x [B,T,nslices*CI] fp32, row stride ldx (a channel slice of a wider tensor is fine); out [B,T,M] fp32, row
+ *                           stride ldo;  out = act([out +] bias + conv(x)), act = relu: 0 none, 1 ReLU, 2 SiLU, 3 GELU (erf).   ntaps = 1 is a
+ *                           Linear layer.  CI in {128, 256, 512} is the SLICE width: wider inputs are nslices slices walked
+ *                           inside one launch (w_hi / w_lo: the slices' packed weights one after the other); a wider input is summed
  *                           over 512-channel slices with accumulate = 1.  ntaps odd, M % 4 == 0. */
 long dsp_conv1d_split_packed_elems(int ntaps, int M, int CI);
 int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream);
 int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
-                     int B, int T, int CI, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream);
+                     int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream);
 
 #ifdef __cplusplus
 }
