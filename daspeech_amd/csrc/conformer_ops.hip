@@ -29,6 +29,11 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
         float4 acc[DW_TT];
 #pragma unroll
         for (int u = 0; u < DW_TT; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wr[4][K];                                  // this lane's 4 x K taps, in registers (read per FMA they were ~1000 L1 loads per lane)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < K; ++k) wr[i][k] = w[(c + i) * K + k];
         constexpr int P = (K - 1) / 2;
         // input row t0 - P + s contributes to output t0 + u through tap k = s - u
 #pragma unroll
@@ -40,8 +45,8 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
             for (int u = 0; u < DW_TT; ++u) {
                 const int k = s - u;
                 if (k >= 0 && k < K) {
-                    acc[u].x = fmaf(v.x, w[(c + 0) * K + k], acc[u].x); acc[u].y = fmaf(v.y, w[(c + 1) * K + k], acc[u].y);
-                    acc[u].z = fmaf(v.z, w[(c + 2) * K + k], acc[u].z); acc[u].w = fmaf(v.w, w[(c + 3) * K + k], acc[u].w);
+                    acc[u].x = fmaf(v.x, wr[0][k], acc[u].x); acc[u].y = fmaf(v.y, wr[1][k], acc[u].y);
+                    acc[u].z = fmaf(v.z, wr[2][k], acc[u].z); acc[u].w = fmaf(v.w, wr[3][k], acc[u].w);
                 }
             }
         }
