@@ -22,6 +22,7 @@ struct CsParams {
     int B, T, M, ntaps; long ldx, ldo;
     int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
     int nslices; long wslice;      // the input is nslices x CI channels wide; slice s uses weights + s * wslice (halves)
+    const float* res; long ldr; float alpha;      // out = res + alpha * act(bias + conv)   (res may be NULL: out = alpha * act(...))
 };
 
 template <int CI>
@@ -152,6 +153,13 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
+            if (p.res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(p.res + ((size_t)b * p.T + t) * p.ldr + co);
+                v[0] = r4.x + p.alpha * v[0]; v[1] = r4.y + p.alpha * v[1]; v[2] = r4.z + p.alpha * v[2]; v[3] = r4.w + p.alpha * v[3];
+            } else if (p.alpha != 1.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+            }
             *reinterpret_cast<float4*>(O) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
@@ -206,8 +214,9 @@ extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void*
     return check_launch("conv1d_split_pack");
 }
 
-extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
-                                int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream)
+static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
+                  int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, const float* res, long ldr, float alpha,
+                  dsp_stream_t stream)
 {
     if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || nslices < 1 || ldx < (long)CI * nslices || ldo < M ||
         (ldx & 3) || (ldo & 3)) {
@@ -219,6 +228,8 @@ extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, cons
     p.x = x; p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.bias = bias; p.out = out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
     p.nslices = nslices; p.wslice = dsp_conv1d_split_packed_elems(ntaps, M, CI);
+    p.res = res; p.ldr = ldr; p.alpha = alpha;
+    if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     switch (CI) {
         case 256: return cs_launch<256, 256, 128, 8, 1>(p, st);
@@ -227,4 +238,17 @@ extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, cons
     }
     set_error("conv1d_split: unsupported slice width %d (128, 256, 512; wider inputs are nslices slices)", CI);
     return DSP_EINVAL;
+}
+
+extern "C" int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
+                                int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream)
+{
+    return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, CI, nslices, M, ntaps, relu, accumulate, nullptr, 0, 1.f, stream);
+}
+
+extern "C" int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res,
+                                         long ldr, float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps,
+                                         int relu, dsp_stream_t stream)
+{
+    return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, CI, nslices, M, ntaps, relu, 0, res, ldr, alpha, stream);
 }

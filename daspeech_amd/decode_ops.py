@@ -359,7 +359,8 @@ class SplitConv1d:
 
     ACT = {None: 0, "relu": 1, "silu": 2, "gelu": 3}
 
-    def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None) -> Tensor:
+    def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+        """act(conv(x) + bias), or residual + alpha * that when a residual [B,T,Cout] is given."""
         _gpu("SplitConv1d", x)
         code = 1 if relu else self.ACT[act]
         assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == self.Cin and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
@@ -368,8 +369,17 @@ class SplitConv1d:
         with torch.cuda.device(x.device):
             st = _lib.current_stream_handle()
             out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
-            _lib.check(lib.dsp_conv1d_split(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(out),
-                                            self.Cout, B, T, self.step, self.nslices, self.Cout, self.K, code, 0, st), "dsp_conv1d_split")
+            if residual is not None or alpha != 1.0:
+                r = None
+                if residual is not None:
+                    r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
+                    assert tuple(r.shape) == (B, T, self.Cout)
+                _lib.check(lib.dsp_conv1d_split_residual(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(r),
+                                                         self.Cout, float(alpha), _lib.ptr(out), self.Cout, B, T, self.step, self.nslices, self.Cout,
+                                                         self.K, code, st), "dsp_conv1d_split_residual")
+            else:
+                _lib.check(lib.dsp_conv1d_split(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(out),
+                                                self.Cout, B, T, self.step, self.nslices, self.Cout, self.K, code, 0, st), "dsp_conv1d_split")
         return out
 
 
@@ -383,31 +393,37 @@ def set_split_gemm(on: bool) -> bool:
     return old
 
 
-def split_linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -> Optional[Tensor]:
+def split_linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Optional[Tensor]:
     """act(x @ W^T + b) at fp32 accuracy on the fp16 matrix cores (a SplitConv1d with one tap), or None when the shape / mode is not
     served (caller falls back to F.linear): eval-mode inference in fp32 on the GPU, in_features 128 / 256 / 512 or a multiple of 512,
     out_features % 4 == 0, at least 128 rows.  The packed weight is cached on the module."""
     if (not SPLIT_GEMM or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or lin.weight.dtype != torch.float32
             or x.dim() != 3 or not x.is_contiguous() or x.shape[0] * x.shape[1] < 128):
         return None
-    cin, cout = lin.in_features, lin.out_features
+    wt = lin.weight                                                # nn.Linear [out,in] or a kernel-1 nn.Conv1d [out,in,1]
+    if wt.dim() == 3 and wt.shape[2] != 1:
+        return None
+    cout, cin = wt.shape[0], wt.shape[1]
     if not ((cin in (128, 256, 512) or (cin > 512 and cin % 512 == 0)) and cout % 4 == 0):
         return None
     key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version)
     cache = getattr(lin, "_dsp_split", None)
     if cache is None or cache[0] != key:
-        cache = (key, SplitConv1d(lin.weight.unsqueeze(-1), lin.bias))
+        cache = (key, SplitConv1d(wt if wt.dim() == 3 else wt.unsqueeze(-1), lin.bias))
         lin._dsp_split = cache
-    return cache[1](x, act=act)
+    return cache[1](x, act=act, residual=residual, alpha=alpha)
 
 
-def linear(x: Tensor, lin: "torch.nn.Linear", act: Optional[str] = None) -> Tensor:
-    """act(lin(x)): through split_linear where it applies (eval-mode fp32 inference on the GPU), torch otherwise."""
+def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """[residual + alpha *] act(lin(x)): through split_linear where it applies (eval-mode fp32 inference on the GPU), torch otherwise.
+    `lin` is an nn.Linear or a kernel-1 nn.Conv1d (applied on the channels-last x)."""
     if not lin.training:
-        y = split_linear(x, lin, act)
+        y = split_linear(x, lin, act, residual, alpha)
         if y is not None:
             return y
-    y = lin(x)
-    if act is None:
-        return y
-    return {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act](y)
+    y = torch.nn.functional.linear(x, lin.weight if lin.weight.dim() == 2 else lin.weight.squeeze(-1), lin.bias)
+    if act is not None:
+        y = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act](y)
+    if alpha != 1.0:
+        y = alpha * y
+    return y if residual is None else residual + y

@@ -81,7 +81,7 @@ class RelPosSelfAttention(nn.Module):
         x = F.pad(x, (1, 0)).view(B, h, P + 1, T)[:, :, 1:].reshape(B, h, T, P)
         return x[..., : P // 2 + 1]
 
-    def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
+    def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor], residual: Optional[Tensor] = None) -> Tensor:
         B, T, C = x.shape
         L_ = decode_ops.linear
         q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
@@ -94,7 +94,7 @@ class RelPosSelfAttention(nn.Module):
         if pad_mask is not None:
             scores = scores.masked_fill(pad_mask.view(B, 1, 1, T), float("-inf"))
         att = torch.softmax(scores, dim=-1)
-        return decode_ops.linear(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C), self.linear_out)
+        return decode_ops.linear(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C), self.linear_out, residual=residual)
 
 
 class ConformerLayer(nn.Module):
@@ -113,31 +113,25 @@ class ConformerLayer(nn.Module):
 
     @staticmethod
     def _ffn(m, x):
-        h = m["layer_norm"](x)
-        if not m["w_1"].training:
-            y = decode_ops.split_linear(h, m["w_1"], act="silu")          # fp32-accurate GEMMs on the fp16 matrix cores (eval, fp32)
-            if y is not None:
-                z = decode_ops.split_linear(y, m["w_2"])
-                if z is not None:
-                    return z
-        return m["w_2"](F.silu(m["w_1"](h)))
+        """x + 0.5 * w_2(silu(w_1(layer_norm(x))))  — the macaron half-step, residual included."""
+        L_ = decode_ops.linear                 # fp32-accurate split GEMMs (bias, SiLU, scale and residual in their epilogues) in eval-mode
+        return L_(L_(m["layer_norm"](x), m["w_1"], act="silu"), m["w_2"], residual=x, alpha=0.5)      # fp32 inference, torch otherwise
 
     def forward(self, x, pos, pad_mask):
-        x = x + 0.5 * self._ffn(self.ffn1, x)
-        x = x + self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask)
+        x = self._ffn(self.ffn1, x)
+        x = self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask, residual=x)
         c = self.conv_module
         # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
         # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
-        y = F.glu(F.linear(c["layer_norm"](x), c["pointwise_conv1"].weight.squeeze(-1)), dim=-1)
+        y = F.glu(decode_ops.linear(c["layer_norm"](x), c["pointwise_conv1"]), dim=-1)
         dw = c["depthwise_conv"]
         if (not self.training and not torch.is_grad_enabled() and y.is_cuda and y.shape[-1] % 4 == 0
                 and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None):
             y = decode_ops.dwconv_bn_silu(y, dw.weight, c["batch_norm"])       # one HIP pass on [B,T,C], no transposes
         else:
             y = F.silu(c["batch_norm"](dw(y.transpose(1, 2)))).transpose(1, 2)
-        y = F.linear(y, c["pointwise_conv2"].weight.squeeze(-1))
-        x = x + y
-        x = x + 0.5 * self._ffn(self.ffn2, x)
+        x = decode_ops.linear(y.contiguous(), c["pointwise_conv2"], residual=x)
+        x = self._ffn(self.ffn2, x)
         return self.final_layer_norm(x)
 
 
@@ -171,7 +165,7 @@ class _MHA(nn.Module):
         self.q_proj, self.out_proj = nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.k_proj, self.v_proj = nn.Linear(kdim, dim), nn.Linear(kdim, dim)
 
-    def forward(self, x, mem, mem_pad):
+    def forward(self, x, mem, mem_pad, residual=None):
         B, N, C = x.shape
         M = mem.shape[1]
         L_ = decode_ops.linear
@@ -182,7 +176,7 @@ class _MHA(nn.Module):
         if mem_pad is not None:
             mask = torch.zeros(B, 1, 1, M, dtype=x.dtype, device=x.device).masked_fill(mem_pad.view(B, 1, 1, M), float("-inf"))
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return decode_ops.linear(o.transpose(1, 2).reshape(B, N, C), self.out_proj)
+        return decode_ops.linear(o.transpose(1, 2).reshape(B, N, C), self.out_proj, residual=residual)
 
 
 class NATDecoderLayer(nn.Module):
@@ -195,9 +189,9 @@ class NATDecoderLayer(nn.Module):
         self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
 
     def forward(self, x, self_pad, enc, enc_pad):
-        x = self.self_attn_layer_norm(x + self.self_attn(x, x, self_pad))
-        x = self.encoder_attn_layer_norm(x + self.encoder_attn(x, enc, enc_pad))
-        return self.final_layer_norm(x + decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2))
+        x = self.self_attn_layer_norm(self.self_attn(x, x, self_pad, residual=x))
+        x = self.encoder_attn_layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x))
+        return self.final_layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x))
 
 
 class DAGDecoder(nn.Module):

@@ -89,6 +89,11 @@ long dsp_conv1d_split_packed_elems(int ntaps, int M, int CI);
 int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream);
 int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
                      int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, dsp_stream_t stream);
+/* same with the layer's residual connection in the epilogue:  out = res + alpha * act(bias + conv(x))   (res [B,T,M], row stride ldr;
+ * out may be res) — `x + 0.5 * ffn(x)`, `x + attn(x)` without separate scale / add launches */
+int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr,
+                              float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
+                              dsp_stream_t stream);
 
 #ifdef __cplusplus
 }
