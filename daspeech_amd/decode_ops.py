@@ -404,12 +404,13 @@ def split_linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[T
     if wt.dim() == 3 and wt.shape[2] != 1:
         return None
     cout, cin = wt.shape[0], wt.shape[1]
-    if not ((cin in (128, 256, 512) or (cin > 512 and cin % 512 == 0)) and cout % 4 == 0):
-        return None
-    key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version)
+    if not ((cin in (128, 256, 512) or (cin > 512 and cin % 512 == 0)) and cout % 4 == 0 and cout >= 128):
+        return None                                                # narrow outputs (gates, mel projection) waste the 256-row weight tile
+    bias = getattr(lin, "bias", None)                              # nn.Embedding used as a tied output projection has none
+    key = (lin.weight.data_ptr(), lin.weight._version, None if bias is None else bias._version)
     cache = getattr(lin, "_dsp_split", None)
     if cache is None or cache[0] != key:
-        cache = (key, SplitConv1d(wt if wt.dim() == 3 else wt.unsqueeze(-1), lin.bias))
+        cache = (key, SplitConv1d(wt if wt.dim() == 3 else wt.unsqueeze(-1), bias))
         lin._dsp_split = cache
     return cache[1](x, act=act, residual=residual, alpha=alpha)
 
@@ -421,7 +422,7 @@ def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor]
         y = split_linear(x, lin, act, residual, alpha)
         if y is not None:
             return y
-    y = torch.nn.functional.linear(x, lin.weight if lin.weight.dim() == 2 else lin.weight.squeeze(-1), lin.bias)
+    y = torch.nn.functional.linear(x, lin.weight if lin.weight.dim() == 2 else lin.weight.squeeze(-1), getattr(lin, "bias", None))
     if act is not None:
         y = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act](y)
     if alpha != 1.0:

@@ -87,7 +87,7 @@ class RelPosSelfAttention(nn.Module):
         q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
         k = L_(x, self.linear_k).view(B, T, self.h, self.dk).transpose(1, 2)
         v = L_(x, self.linear_v).view(B, T, self.h, self.dk).transpose(1, 2)
-        p = self.linear_pos(pos).view(1, -1, self.h, self.dk).transpose(1, 2)
+        p = L_(pos, self.linear_pos).view(1, -1, self.h, self.dk).transpose(1, 2)
         ac = torch.matmul((q + self.pos_bias_u).transpose(1, 2), k.transpose(-2, -1))
         bd = self.rel_shift(torch.matmul((q + self.pos_bias_v).transpose(1, 2), p.transpose(-2, -1)))
         scores = (ac + bd) / math.sqrt(self.dk)
@@ -224,7 +224,7 @@ class DAGDecoder(nn.Module):
         return x
 
     def output_layer(self, feats: Tensor) -> Tensor:
-        return F.linear(feats, self.embed_tokens.weight)          # --share-decoder-input-output-embed
+        return decode_ops.linear(feats, self.embed_tokens)        # --share-decoder-input-output-embed (weight [V, d], no bias)
 
     def extract_links(self, feats: Tensor, prev_output_tokens: Tensor) -> Tensor:
         """Compact transition log-probs [B, L, TR] fp32 (s2t_conformer_dag.py:171-212, banded branch :191-202)."""
@@ -234,7 +234,7 @@ class DAGDecoder(nn.Module):
         fp = torch.cat([feats, self.link_positional(self.positions(prev_output_tokens))], dim=-1)
         q = decode_ops.linear(fp, self.query_linear).view(B, L, h, ck).float()
         k = decode_ops.linear(fp, self.key_linear).view(B, L, h, ck).float()
-        log_gates = F.log_softmax(self.gate_linear(fp), dim=-1, dtype=torch.float)                   # [B,L,h]
+        log_gates = F.log_softmax(decode_ops.linear(fp, self.gate_linear), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
         if feats.is_cuda and not torch.is_grad_enabled() and h == 8 and ck % 4 == 0 and ck <= 128 and TR >= 1 and self.fused_links:
             # inference: the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather

@@ -199,4 +199,5 @@ class FastSpeech2NoEmb(nn.Module):
         x = x + self.dec_pos_emb_alpha * self._pos(dec_mask)
         for layer in self.decoder_fft_layers:
             x = layer(x, dec_mask)
-        return self.out_proj(x), out_lens, log_dur, pitch, energy
+        from ..decode_ops import linear as _lin
+        return _lin(x.contiguous(), self.out_proj), out_lens, log_dur, pitch, energy
