@@ -428,3 +428,17 @@ def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor]
     if alpha != 1.0:
         y = alpha * y
     return y if residual is None else residual + y
+
+
+def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
+    """ln(x): the one-wave-per-row HIP kernel (dsp_layer_norm) in eval-mode fp32 inference on the GPU, torch otherwise."""
+    C = x.shape[-1]
+    if (SPLIT_GEMM and not ln.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and x.is_contiguous() and len(ln.normalized_shape) == 1 and C % 4 == 0 and C <= 2048 and (ln.weight is None or ln.weight.dtype == torch.float32)):
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            _lib.check(lib.dsp_layer_norm(_lib.ptr(x), _lib.ptr(ln.weight), _lib.ptr(ln.bias), float(ln.eps), _lib.ptr(y), x.numel() // C, C,
+                                          _lib.current_stream_handle()), "dsp_layer_norm")
+        return y
+    return ln(x)

@@ -115,15 +115,15 @@ class ConformerLayer(nn.Module):
     def _ffn(m, x):
         """x + 0.5 * w_2(silu(w_1(layer_norm(x))))  — the macaron half-step, residual included."""
         L_ = decode_ops.linear                 # fp32-accurate split GEMMs (bias, SiLU, scale and residual in their epilogues) in eval-mode
-        return L_(L_(m["layer_norm"](x), m["w_1"], act="silu"), m["w_2"], residual=x, alpha=0.5)      # fp32 inference, torch otherwise
+        return L_(L_(decode_ops.layer_norm(x, m["layer_norm"]), m["w_1"], act="silu"), m["w_2"], residual=x, alpha=0.5)      # fp32 inference, torch otherwise
 
     def forward(self, x, pos, pad_mask):
         x = self._ffn(self.ffn1, x)
-        x = self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask, residual=x)
+        x = self.self_attn(decode_ops.layer_norm(x, self.self_attn_layer_norm), pos, pad_mask, residual=x)
         c = self.conv_module
         # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
         # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
-        y = F.glu(decode_ops.linear(c["layer_norm"](x), c["pointwise_conv1"]), dim=-1)
+        y = F.glu(decode_ops.linear(decode_ops.layer_norm(x, c["layer_norm"]), c["pointwise_conv1"]), dim=-1)
         dw = c["depthwise_conv"]
         if (not self.training and not torch.is_grad_enabled() and y.is_cuda and y.shape[-1] % 4 == 0
                 and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None):
@@ -132,7 +132,7 @@ class ConformerLayer(nn.Module):
             y = F.silu(c["batch_norm"](dw(y.transpose(1, 2)))).transpose(1, 2)
         x = decode_ops.linear(y.contiguous(), c["pointwise_conv2"], residual=x)
         x = self._ffn(self.ffn2, x)
-        return self.final_layer_norm(x)
+        return decode_ops.layer_norm(x, self.final_layer_norm)
 
 
 class ConformerEncoder(nn.Module):
@@ -189,9 +189,9 @@ class NATDecoderLayer(nn.Module):
         self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
 
     def forward(self, x, self_pad, enc, enc_pad):
-        x = self.self_attn_layer_norm(self.self_attn(x, x, self_pad, residual=x))
-        x = self.encoder_attn_layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x))
-        return self.final_layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x))
+        x = decode_ops.layer_norm(self.self_attn(x, x, self_pad, residual=x), self.self_attn_layer_norm)
+        x = decode_ops.layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x), self.encoder_attn_layer_norm)
+        return decode_ops.layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x), self.final_layer_norm)
 
 
 class DAGDecoder(nn.Module):

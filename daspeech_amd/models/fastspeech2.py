@@ -80,7 +80,7 @@ class _ConvFFN(nn.Module):
                 self._split = (SplitConv1d(c1.weight, c1.bias), SplitConv1d(c2.weight, c2.bias)) if ok else None
                 self._split_key = key
             if self._split is not None:
-                return self.layer_norm(self._split[1](self._split[0](x, relu=True)) + x)
+                return _dops.layer_norm(self._split[1](self._split[0](x, relu=True), residual=x), self.layer_norm)
         return self.layer_norm(self.ffn(x.transpose(1, 2)).transpose(1, 2) + x)
 
 
@@ -92,7 +92,8 @@ class FFTLayer(nn.Module):
         self.ffn = _ConvFFN(dim, hidden, kernel)
 
     def forward(self, x: Tensor, padding_mask: Optional[Tensor] = None) -> Tensor:
-        x = self.layer_norm(self.self_attn(x, padding_mask) + x)
+        from ..decode_ops import layer_norm as _ln
+        x = _ln(self.self_attn(x, padding_mask) + x, self.layer_norm)
         return self.ffn(x)
 
 

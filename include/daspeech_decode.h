@@ -95,6 +95,10 @@ int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const 
                               float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
                               dsp_stream_t stream);
 
+/* LayerNorm over the last dimension (torch.nn.LayerNorm semantics: biased variance, eps inside the square root), one wave per row:
+ * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */
+int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, float* y, long rows, int C, dsp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

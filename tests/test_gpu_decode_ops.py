@@ -264,3 +264,16 @@ def test_split_precision_conv1d_is_fp32_accurate(shape):
             got = sc(xs)
             ref = conv(xs.transpose(1, 2).contiguous()).transpose(1, 2)
         torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(5, 77, 256), (3, 1, 512), (2, 33, 1024), (7, 3, 80), (1, 130, 2048), (4, 9, 36)])
+def test_layer_norm_kernel_matches_torch(shape):
+    """dsp_layer_norm (one wave per row, values in registers) vs torch.nn.LayerNorm in eval-mode fp32."""
+    from daspeech_amd import decode_ops
+    torch.manual_seed(3)
+    ln = torch.nn.LayerNorm(shape[-1]).cuda().eval()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+        x = torch.randn(*shape, device="cuda") * 3 + 1.5
+        got = decode_ops.layer_norm(x, ln); want = ln(x)
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-6)
