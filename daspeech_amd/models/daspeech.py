@@ -118,15 +118,25 @@ class ConformerLayer(nn.Module):
         return L_(L_(decode_ops.layer_norm(x, m["layer_norm"]), m["w_1"], act="silu"), m["w_2"], residual=x, alpha=0.5)      # fp32 inference, torch otherwise
 
     def forward(self, x, pos, pad_mask):
+        c = self.conv_module
+        if self.training or torch.is_grad_enabled():
+            # training: plain torch ops only (the step is host-launch bound: every helper indirection and extra view costs)
+            def ffn(m, x):
+                return x + 0.5 * m["w_2"](F.silu(m["w_1"](m["layer_norm"](x))))
+            x = ffn(self.ffn1, x)
+            x = x + self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask)
+            # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
+            # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
+            y = F.glu(F.linear(c["layer_norm"](x), c["pointwise_conv1"].weight.squeeze(-1)), dim=-1)
+            y = F.silu(c["batch_norm"](c["depthwise_conv"](y.transpose(1, 2))))
+            x = x + F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1))
+            x = ffn(self.ffn2, x)
+            return self.final_layer_norm(x)
         x = self._ffn(self.ffn1, x)
         x = self.self_attn(decode_ops.layer_norm(x, self.self_attn_layer_norm), pos, pad_mask, residual=x)
-        c = self.conv_module
-        # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
-        # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
         y = F.glu(decode_ops.linear(decode_ops.layer_norm(x, c["layer_norm"]), c["pointwise_conv1"]), dim=-1)
         dw = c["depthwise_conv"]
-        if (not self.training and not torch.is_grad_enabled() and y.is_cuda and y.shape[-1] % 4 == 0
-                and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None):
+        if y.is_cuda and y.shape[-1] % 4 == 0 and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None:
             y = decode_ops.dwconv_bn_silu(y, dw.weight, c["batch_norm"])       # one HIP pass on [B,T,C], no transposes
         else:
             y = F.silu(c["batch_norm"](dw(y.transpose(1, 2)))).transpose(1, 2)
@@ -189,6 +199,10 @@ class NATDecoderLayer(nn.Module):
         self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
 
     def forward(self, x, self_pad, enc, enc_pad):
+        if self.training or torch.is_grad_enabled():
+            x = self.self_attn_layer_norm(x + self.self_attn(x, x, self_pad))
+            x = self.encoder_attn_layer_norm(x + self.encoder_attn(x, enc, enc_pad))
+            return self.final_layer_norm(x + self.fc2(F.gelu(self.fc1(x))))
         x = decode_ops.layer_norm(self.self_attn(x, x, self_pad, residual=x), self.self_attn_layer_norm)
         x = decode_ops.layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x), self.encoder_attn_layer_norm)
         return decode_ops.layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x), self.final_layer_norm)
