@@ -15,6 +15,17 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
+def _file_flags(src):
+    """Extra hipcc flags a source asks for in a `// HIPCC_FLAGS: ...` line of its header comment."""
+    out = []
+    with open(src) as f:
+        for _ in range(40):
+            line = f.readline()
+            if line.startswith("// HIPCC_FLAGS:"):
+                out += line.split(":", 1)[1].split()
+    return out
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -45,7 +56,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         hdr_t = max(os.path.getmtime(h) for h in _deps() if h.endswith(".h"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + _file_flags(src) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -442,3 +442,23 @@ def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
                                           _lib.current_stream_handle()), "dsp_layer_norm")
         return y
     return ln(x)
+
+
+def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor, bias_v: Tensor, pad_mask: Optional[Tensor], heads: int) -> Optional[Tensor]:
+    """Fused Conformer relative-position attention (dsp_relpos_attention): q, k, v [B,T,C] fp32 (C = heads * 64), p [1 or none, 2T-1, C],
+    bias_u / bias_v [heads, 64], pad_mask [B,T] bool.  Returns [B,T,C], or None when the shape / mode is not served."""
+    B, T, C = q.shape
+    if (not SPLIT_GEMM or torch.is_grad_enabled() or not q.is_cuda or q.dtype != torch.float32 or torch.is_autocast_enabled() or C != heads * 64 or T > 256
+            or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous())):
+        return None
+    pp = p.reshape(-1, C).contiguous()
+    if pp.shape[0] != 2 * T - 1:
+        return None
+    lib = _lib.load()
+    pm = None if pad_mask is None else pad_mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(q.device):
+        out = torch.empty_like(q)
+        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pp), _lib.ptr(bias_u.detach().float().contiguous()),
+                                            _lib.ptr(bias_v.detach().float().contiguous()), _lib.ptr(pm), _lib.ptr(out), B, T, heads, 64,
+                                            _lib.current_stream_handle()), "dsp_relpos_attention")
+    return out

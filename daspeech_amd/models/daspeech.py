@@ -84,6 +84,11 @@ class RelPosSelfAttention(nn.Module):
     def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor], residual: Optional[Tensor] = None) -> Tensor:
         B, T, C = x.shape
         L_ = decode_ops.linear
+        if not self.training and self.dk == 64:
+            qf, kf, vf = L_(x, self.linear_q), L_(x, self.linear_k), L_(x, self.linear_v)
+            o = decode_ops.relpos_attention(qf, kf, vf, L_(pos, self.linear_pos), self.pos_bias_u, self.pos_bias_v, pad_mask, self.h)
+            if o is not None:                                         # one fused HIP kernel for scores, shift, soft-max and the value product
+                return L_(o, self.linear_out, residual=residual)
         q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
         k = L_(x, self.linear_k).view(B, T, self.h, self.dk).transpose(1, 2)
         v = L_(x, self.linear_v).view(B, T, self.h, self.dk).transpose(1, 2)

@@ -99,6 +99,14 @@ int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const 
  * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */
 int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, float* y, long rows, int C, dsp_stream_t stream);
 
+/* Conformer relative-position self-attention (fairseq conformer_layer.py / espnet RelPositionMultiHeadedAttention), fused, fp32:
+ *   out[b,i,h,:] = sum_j softmax_j( ((q_i + u_h).k_j + (q_i + v_h).p_{(T-1)-i+j}) / sqrt(dk) ; keys with pad_mask[b,j] != 0 -> -inf ) v_j
+ * q, k, v, out [B,T,H,dk] fp32 (the linear_q / linear_k / linear_v outputs viewed per head, no transposes), p [2T-1,H,dk] (linear_pos of
+ * the relative positional encoding, rows for relative positions T-1 .. -(T-1)), bias_u / bias_v [H,dk], pad_mask [B,T] bytes or NULL.
+ * dk = 64, T <= 256 (longer sequences: the torch formulation). */
+int dsp_relpos_attention(const float* q, const float* k, const float* v, const float* p, const float* bias_u, const float* bias_v,
+                         const unsigned char* pad_mask, float* out, int B, int T, int H, int DK, dsp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,3 +277,29 @@ def test_layer_norm_kernel_matches_torch(shape):
         x = torch.randn(*shape, device="cuda") * 3 + 1.5
         got = decode_ops.layer_norm(x, ln); want = ln(x)
     torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 77, 4), (2, 200, 4), (1, 5, 2), (2, 256, 1), (4, 33, 8)])
+def test_fused_relpos_attention_matches_torch_formulation(shape):
+    """dsp_relpos_attention vs the torch formulation of the Conformer's relative-position attention (two batched GEMMs, rel_shift,
+    masked soft-max, value GEMM) on ragged batches: fp32, tolerance 2e-5 (different summation order)."""
+    from daspeech_amd import decode_ops
+    from daspeech_amd.models.daspeech import RelPosSelfAttention, rel_positional_encoding
+    B, T, H = shape
+    torch.manual_seed(9 + T)
+    att = RelPosSelfAttention(H * 64, H).cuda().eval()
+    with torch.no_grad():
+        att.pos_bias_u.normal_(0, 0.5); att.pos_bias_v.normal_(0, 0.5)
+    x = torch.randn(B, T, H * 64, device="cuda")
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), device="cuda"); lens[0] = T
+    pad = torch.arange(T, device="cuda").unsqueeze(0) >= lens.unsqueeze(1)
+    pos = rel_positional_encoding(T, H * 64, x.device, x.dtype)
+    with torch.no_grad():
+        old = decode_ops.set_split_gemm(True)
+        try:
+            got = att(x, pos, pad)
+            decode_ops.set_split_gemm(False)
+            want = att(x, pos, pad)
+        finally:
+            decode_ops.set_split_gemm(old)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
