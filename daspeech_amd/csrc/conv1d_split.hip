@@ -64,21 +64,43 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     const _Float16* WH = p.wh + (size_t)sl * p.wslice;
     const _Float16* WL = p.wl + (size_t)sl * p.wslice;
     if (sl) __syncthreads();                              // every wave is done with the previous slice's tiles
-    // ---- stage: rows t0-P .. t0+NT-1+P, zero outside [0,T); split into hi / lo*2^11 ----
-    for (int e = tid; e < R * CH; e += 512) {
-        const int row = e / CH, ch = e - row * CH;
-        const int tg = t0 - P + row;
-        cs_h8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (tg >= 0 && tg < p.T) {
-            const float4 a = *reinterpret_cast<const float4*>(Xs + (size_t)tg * p.ldx + ch * 8);
-            const float4 c = *reinterpret_cast<const float4*>(Xs + (size_t)tg * p.ldx + ch * 8 + 4);
-            const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    // ---- stage: rows t0-P .. t0+NT-1+P, zero outside [0,T); split into hi / lo*2^11.  All of a lane's row chunks (R*CH/512 <= 10) are
+    //      requested together, UNCONDITIONALLY from a clamped row: predicated loads wait for one another (r01h s_memtime accounting: 10 k
+    //      cycles of staging per slice, eight dependent round trips, against 17 k cycles of MFMA loop) ----
+    {
+        constexpr int CS_U = 4;                                // 8 sixteen-byte requests per lane in flight (more spills: 256 VGPRs)
+        const int n = R * CH;
+        for (int e0 = tid; e0 < n; e0 += 512 * CS_U) {
+            float4 va[CS_U], vc[CS_U];
+            bool ok[CS_U];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)f[i]; vl[i] = (_Float16)((f[i] - (float)vh[i]) * 2048.f); }
+            for (int u = 0; u < CS_U; ++u) {
+                const int e = e0 + u * 512, ec = e < n ? e : 0;
+                const int row = ec / CH, ch = ec - row * CH;
+                const int tg = t0 - P + row;
+                ok[u] = e < n && tg >= 0 && tg < p.T;
+                const float* src = Xs + (size_t)(ok[u] ? tg : 0) * p.ldx + ch * 8;
+                va[u] = *reinterpret_cast<const float4*>(src);
+                vc[u] = *reinterpret_cast<const float4*>(src + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < CS_U; ++u) {
+                const int e = e0 + u * 512;
+                if (e < n) {
+                    const int row = e / CH, ch = e - row * CH;
+                    const float f[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vc[u].x, vc[u].y, vc[u].z, vc[u].w};
+                    cs_h8 vh, vl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float x = ok[u] ? f[i] : 0.f;
+                        vh[i] = (_Float16)x; vl[i] = (_Float16)((x - (float)vh[i]) * 2048.f);
+                    }
+                    const size_t o = ((size_t)row * CH + cs_swz<CI>(row, ch)) * 16;
+                    *reinterpret_cast<cs_h8*>(th + o) = vh;
+                    *reinterpret_cast<cs_h8*>(tl + o) = vl;
+                }
+            }
         }
-        const size_t o = ((size_t)row * CH + cs_swz<CI>(row, ch)) * 16;
-        *reinterpret_cast<cs_h8*>(th + o) = vh;
-        *reinterpret_cast<cs_h8*>(tl + o) = vl;
     }
     __syncthreads();
 
@@ -108,14 +130,20 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
             }
         }
     };
-    cs_h8 ah0[MI], al0[MI], ah1[MI], al1[MI];
+    // 3-deep register ring of weight fragments: a request is two steps (>= 48 MFMAs per wave) ahead of its use
+    cs_h8 ah0[MI], al0[MI], ah1[MI], al1[MI], ah2[MI], al2[MI];
     load_a(0, ah0, al0);
-    for (int step = 0; step < nsteps; step += 2) {
-        if (step + 1 < nsteps) load_a(step + 1, ah1, al1);
+    if (nsteps > 1) load_a(1, ah1, al1);
+    for (int step = 0; step < nsteps; step += 3) {
+        if (step + 2 < nsteps) load_a(step + 2, ah2, al2);
         do_step(step, ah0, al0);
         if (step + 1 < nsteps) {
-            if (step + 2 < nsteps) load_a(step + 2, ah0, al0);
+            if (step + 3 < nsteps) load_a(step + 3, ah0, al0);
             do_step(step + 1, ah1, al1);
+        }
+        if (step + 2 < nsteps) {
+            if (step + 4 < nsteps) load_a(step + 4, ah1, al1);
+            do_step(step + 2, ah2, al2);
         }
     }
 
