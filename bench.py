@@ -168,6 +168,28 @@ def run_model_workload(args, torch, dist, dev, world, rank):
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if args.workload == "s2tt" and rank == 0 and amp_dtype is None:
+        # roofline of the workload's dominant kernel family, the fp32-accurate split GEMM on the fp16 matrix cores:
+        # the Conformer feed-forward's first GEMM at this batch's row count; 3 MFMAs per product, priced against the dense fp16 peak
+        from daspeech_amd import decode_ops
+        lin = model.encoder.conformer_layers[0].ffn1["w_1"]
+        ni = batches[0]["net_input"]
+        with torch.no_grad():
+            Tenc = int(model.forward_encoder(ni["src_tokens"], ni["src_lengths"])["encoder_out"].shape[1])
+            xg = torch.randn(B, Tenc, lin.in_features, device=dev)
+            if decode_ops.split_linear(xg, lin, act="silu") is not None:
+                for _ in range(3):
+                    decode_ops.split_linear(xg, lin, act="silu")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    decode_ops.split_linear(xg, lin, act="silu")
+                e1.record(); torch.cuda.synchronize()
+                g_ms = e0.elapsed_time(e1) / 20
+                mf = 3 * 2.0 * B * Tenc * lin.in_features * lin.out_features / (g_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": f"conv1d_split_kernel (Linear {lin.in_features}->{lin.out_features} + SiLU on {B * Tenc} rows, fp32-accurate: "
+                                                   "3 fp16 MFMAs per product)", "achieved": mf, "peak": 2500.0, "unit": "TFLOP/s", "frac": mf / 2500.0,
+                        "traffic": None, "avg_call_ms": g_ms, "effective_fp32_TFLOPs": mf / 3}
     if args.workload == "s2st":
         extra["mel_frames_per_utt"] = frames[0] / max(1, (args.steps + args.warmup) * B)
         # roofline of the pipeline's dominant hand-written kernel family, the HiFi-GAN conv stack (MFMA bound, 0.614 GFLOP per mel
