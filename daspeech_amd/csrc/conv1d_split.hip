@@ -10,6 +10,7 @@
 //   x [B,T,CI] fp32 channels-last (row stride ldx), taps k with shift k - (K-1)/2 ("same" padding), weights pre-split and stored in
 //   MFMA fragment order (dsp_conv1d_split_pack), out [B,T,M] fp32 = [out +] bias + conv, optional ReLU.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/daspeech_decode.h"
 
 namespace dsp {
@@ -260,7 +261,12 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
     if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     switch (CI) {
-        case 256: return cs_launch<256, 256, 128, 8, 1>(p, st);
+        case 256: {
+            // 128-row tiles (8 time sub-tiles per wave, one workgroup per CU) when they fill the chip, 64-row tiles (two per CU) for the
+            // narrow layers: 256 -> 256 projections on 12.6 k rows are 99 workgroups at 128 rows
+            const long wgs128 = (long)((T + 127) / 128) * ((M + 255) / 256) * B;
+            return wgs128 >= 256 ? cs_launch<256, 256, 128, 8, 1>(p, st) : cs_launch<256, 256, 64, 8, 1>(p, st);
+        }
         case 512: return cs_launch<512, 256, 64, 8, 1>(p, st);
         case 128: return cs_launch<128, 128, 256, 4, 2>(p, st);
     }
