@@ -79,6 +79,8 @@ int dsp_dwconv_bn_silu(const float* x, const float* w, const float* bn_w, const 
 /* fp32-accurate Conv1d ("same" padding, stride 1) on the fp16 matrix cores by operand splitting (x = xh + xl/2048, w = wh + wl/2048;
  * the products xh.wh, xh.wl, xl.wh are exact in the fp32 accumulator, the dropped xl.wl term is 2^-22 relative) — for the
  * FastSpeech2 FFT feed-forward convolutions (fairseq fastspeech2.py:42-63), which MIOpen runs at 60-70 TFLOP/s in fp32.
+ * Range: operands are split into fp16 hi / lo parts, so |x| and |w| must stay below the fp16 maximum (65504; larger values become
+ * inf) — true of layer-normalised activations and trained weights, not of arbitrary data; values under 6e-5 keep fewer than 22 bits.
  *   dsp_conv1d_split_pack   fp32 weight, tap-major [ntaps][M][CI] -> w_hi, w_lo (dsp_conv1d_split_packed_elems halves each)
  *   dsp_conv1d_split        x [B,T,nslices*CI] fp32, row stride ldx (a channel slice of a wider tensor is fine); out [B,T,M] fp32, row
  *                           stride ldo;  out = act([out +] bias + conv(x)), act = relu: 0 none, 1 ReLU, 2 SiLU, 3 GELU (erf).   ntaps = 1 is a
