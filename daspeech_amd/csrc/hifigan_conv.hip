@@ -507,7 +507,9 @@ static int hg_unit_one(const void* x, const void* w1, const float* b1, const voi
     p.B = B; p.T = T; p.ntaps = ntaps; p.dil = dil; p.accumulate = accumulate; p.slope = slope; p.scale = scale;
     // C = 128: 78 KB per workgroup, two per CU (353 us per unit vs 2 x 200 us for its two-launch chain at B=32)
     switch (C) {
-        case 256: return hg_unit_launch<256, 112, 8, 1>(p, st);
+        // 112-column tiles (91 KB, one workgroup per CU) when they fill the chip; 48-column tiles (58 KB, two per CU) for small batches:
+        // B=8 x 330 frames is 192 workgroups at 112 columns (70.6 -> 60.3 us per unit), B=32 prefers 112 (175 vs 208 us)
+        case 256: return (long)((T + 111) / 112) * B >= 384 ? hg_unit_launch<256, 112, 8, 1>(p, st) : hg_unit_launch<256, 48, 8, 1>(p, st);
         case 128: return hg_unit_launch<128, 240, 4, 2>(p, st);
         // the wider tile (half the weight-fragment loads per MFMA, 6 % faster at B=32) only when it still gives two workgroups per CU
         case 64:  return (long)((T + 495) / 496) * B >= 512 ? hg_unit_launch<64, 496, 2, 4>(p, st) : hg_unit_launch<64, 240, 2, 4>(p, st);

@@ -144,7 +144,8 @@ def test_hifigan_fused_resblock_unit_bit_identical_to_layer_chain():
     st = _lib.current_stream_handle()
     # T * B large enough selects the wide tiles (C=64: 496 columns, C=32: 1008), small T the narrow ones
     for C, K, dil, T in ((32, 11, 5, 1000), (32, 3, 1, 497), (64, 7, 3, 481), (64, 11, 5, 7), (128, 11, 5, 250), (128, 3, 1, 239),
-                         (32, 7, 3, 258111), (64, 11, 5, 127003), (64, 3, 1, 126976), (256, 11, 5, 300), (256, 3, 1, 111), (256, 7, 3, 113)):
+                         (32, 7, 3, 258111), (64, 11, 5, 127003), (64, 3, 1, 126976), (256, 11, 5, 300), (256, 3, 1, 111), (256, 7, 3, 113),
+                         (256, 7, 3, 22403)):        # C=256: 48-column tiles for few tiles, 112-column tiles from 384 workgroups on
         assert lib.dsp_hifigan_resunit_supported(C, K, dil)
         x = (torch.randn(2, T, C, device="cuda") * 1.5).half()
         from daspeech_amd.hifigan_ops import pack_weights
