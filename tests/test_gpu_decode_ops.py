@@ -31,7 +31,7 @@ def test_argmax_logp(dtype, V):
     assert tok[0, 0].item() == 5
 
 
-@pytest.mark.parametrize("shape", [(3, 60, 8), (2, 33, 32), (2, 20, 19)])
+@pytest.mark.parametrize("shape", [(3, 60, 8), (2, 33, 32), (2, 20, 19), (3, 200, 199), (2, 130, 100)])   # TR > 64: one wave per vertex
 @pytest.mark.parametrize("greedy", [False, True])
 def test_lookahead_next_bit_exact(shape, greedy):
     B, L, TR = shape
