@@ -1,0 +1,42 @@
+"""The bench line the driver parses (committed in profiles/ from the last GPU run of `python bench.py`) carries every field of the
+contract: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
+config{workload}, `roofline` of the dominant kernel and the `cpu_baseline` leg.  CPU-only: checks the committed line and the CLI."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    assert files, pattern
+    return files[-1]
+
+
+def test_committed_dag_bench_line_has_the_contract_fields():
+    d = json.loads(open(_latest("r01*_bench_dag_tr32.json")).read().strip().split("\n")[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes"]          # PMC bytes cannot be below the algorithmic ones
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_cli_accepts_the_driver_flags():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
