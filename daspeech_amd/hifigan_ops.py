@@ -120,46 +120,70 @@ class HiFiGANHipRunner:
         hit = self._plans.get(key)
         if hit is not None:
             return hit
-        sizes, recs = [], []            # buffer sizes in halves; records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale[, layer2])
-        lib = _lib.load()
+        sizes, recs, free = [], [], []      # physical buffers (capacity in halves), layer records, released buffer ids
+        lib = _lib.load()                   # records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale[, layer2])
 
         def fusable(c1, c2):
             return (self.fuse_units and c1.CI == c1.M == c2.CI == c2.M and c1.ntaps == c2.ntaps and c2.dil == 1
                     and bool(lib.dsp_hifigan_resunit_supported(c1.CI, c1.ntaps, c1.dil)))
 
+        # The launches run in order on one stream, so a buffer can be handed out again as soon as its last reader has been recorded:
+        # 5 live buffers per stage (stage input, running MRF sum, two ping-pong unit outputs, the unfused chain's intermediate) instead of
+        # one per layer — 1.4 GB instead of 5 GB of workspace at B=32 x 330 frames.
         def new_buf(t, c):
-            sizes.append(B * t * c)
+            n = B * t * c
+            best = None
+            for k in free:
+                if sizes[k] >= n and (best is None or sizes[k] < sizes[best]):
+                    best = k
+            if best is not None:
+                free.remove(best)
+                return best
+            sizes.append(n)
             return len(sizes) - 1
+
+        def release(k):
+            if k is not None and k not in free:
+                free.append(k)
         x = new_buf(T, self.in_pad)
+        x_first = x
         t = T
-        y = new_buf(t, self.pre.Cout); recs.append((self.pre, x, None, y, t, 1.0, None, 1.0)); x = y
+        y = new_buf(t, self.pre.Cout); recs.append((self.pre, x, None, y, t, 1.0, None, 1.0)); x = y      # (the packed input stays: x_in)
         for i, up in enumerate(self.ups):
-            y = new_buf(t * up.u, up.Cout); recs.append((up, x, None, y, t, 0.1, None, 1.0)); x = y; t = t * up.u
-            acc = None
+            y = new_buf(t * up.u, up.Cout); recs.append((up, x, None, y, t, 0.1, None, 1.0)); release(x); x = y; t = t * up.u
+            acc = new_buf(t, up.Cout)
+            first = True
             for j in range(self.nk):
-                yb = x
+                yb, cur = x, None
                 units = self.blocks[i * self.nk + j]
                 for n, (c1, c2) in enumerate(units):
+                    last = n + 1 == len(units)
                     if fusable(c1, c2):                       # x -> c1 -> c2 -> + x in one launch, no intermediate buffer
-                        if n + 1 < len(units):
-                            o = new_buf(t, c2.Cout); recs.append((c1, yb, None, o, t, 0.1, OUT_STORE, 1.0, c2)); yb = o
-                        elif acc is None:
-                            acc = new_buf(t, c2.Cout); recs.append((c1, yb, None, acc, t, 0.1, OUT_STORE, 1.0 / self.nk, c2))
+                        if not last:
+                            o = new_buf(t, c2.Cout); recs.append((c1, yb, None, o, t, 0.1, OUT_STORE, 1.0, c2))
+                            release(cur); cur = o; yb = o
                         else:
-                            recs.append((c1, yb, None, acc, t, 0.1, OUT_ACCUM, 1.0 / self.nk, c2))
+                            recs.append((c1, yb, None, acc, t, 0.1, OUT_STORE if first else OUT_ACCUM, 1.0 / self.nk, c2))
                         continue
                     h = new_buf(t, c1.Cout); recs.append((c1, yb, None, h, t, 0.1, None, 1.0))
-                    if n + 1 < len(units):
-                        o = new_buf(t, c2.Cout); recs.append((c2, h, yb, o, t, 0.1, None, 1.0)); yb = o
-                    elif acc is None:
-                        acc = new_buf(t, c2.Cout); recs.append((c2, h, yb, acc, t, 0.1, None, 1.0 / self.nk))
+                    if not last:
+                        o = new_buf(t, c2.Cout); recs.append((c2, h, yb, o, t, 0.1, None, 1.0))
+                        release(cur); cur = o; yb = o
                     else:
-                        recs.append((c2, h, yb, acc, t, 0.1, OUT_ACCUM, 1.0 / self.nk))
-            x = acc
+                        recs.append((c2, h, yb, acc, t, 0.1, None if first else OUT_ACCUM, 1.0 / self.nk))
+                    release(h)
+                release(cur)
+                first = False
+            release(x); x = acc
         offs, tot = [], 0
         for sz in sizes:
             offs.append(tot); tot += (sz + 63) // 64 * 64          # 128-byte aligned buffers
-        ws = torch.empty((tot,), dtype=torch.float16, device=dev)
+        # ONE grow-only workspace shared by all cached plans (a plan is offsets + a launch table); growing it invalidates the tables.
+        # Calls of one runner are therefore ordered on ONE stream at a time (use one runner per stream for concurrent vocoding).
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < tot or ws.device != dev:
+            self._plans.clear()
+            ws = self._ws = torch.empty((tot,), dtype=torch.float16, device=dev)
         base = ws.data_ptr()
         table = (HgLayerDesc * len(recs))()
         for d, rec in zip(table, recs):
@@ -175,7 +199,7 @@ class HiFiGANHipRunner:
             d.pre_slope, d.scale = slope, scale
             d.out_mode = L.mode if mode is None else mode
             d.up_u, d.up_pad, d.Tout, d.Cout = L.u, L.pad, (tt * L.u if L.mode == OUT_UPSAMPLE else tt), L.Cout
-        plan = (ws, table, base + 2 * offs[0], base + 2 * offs[x], t, sizes[x] // (B * t))
+        plan = (ws, table, base + 2 * offs[x_first], base + 2 * offs[x], t, self.ups[-1].Cout if self.ups else self.pre.Cout)
         if len(self._plans) >= 32:
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = plan
