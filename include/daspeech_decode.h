@@ -83,10 +83,10 @@ int dsp_dwconv_bn_silu(const float* x, const float* w, const float* bn_w, const 
  * inf) — true of layer-normalised activations and trained weights, not of arbitrary data; values under 6e-5 keep fewer than 22 bits.
  *   dsp_conv1d_split_pack   fp32 weight, tap-major [ntaps][M][CI] -> w_hi, w_lo (dsp_conv1d_split_packed_elems halves each)
  *   dsp_conv1d_split        x [B,T,nslices*CI] fp32, row stride ldx (a channel slice of a wider tensor is fine); out [B,T,M] fp32, row
- *                           stride ldo;  out = act([out +] bias + conv(x)), act = relu: 0 none, 1 ReLU, 2 SiLU, 3 GELU (erf).   ntaps = 1 is a
- *                           Linear layer.  CI in {128, 256, 512} is the SLICE width: wider inputs are nslices slices walked
- *                           inside one launch (w_hi / w_lo: the slices' packed weights one after the other); a wider input is summed
- *                           over 512-channel slices with accumulate = 1.  ntaps odd, M % 4 == 0. */
+ *                           stride ldo;  out = act([out +] bias + conv(x)), act = relu: 0 none, 1 ReLU, 2 SiLU, 3 GELU (erf).
+ *                           ntaps = 1 is a Linear layer.  CI in {128, 256, 512} is the SLICE width: a wider input is nslices slices
+ *                           walked inside one launch (w_hi / w_lo hold the slices' packed weights one after the other);
+ *                           accumulate = 1 adds to what `out` holds.  ntaps odd, M % 4 == 0. */
 long dsp_conv1d_split_packed_elems(int ntaps, int M, int CI);
 int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream);
 int dsp_conv1d_split(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
