@@ -59,6 +59,8 @@ SIGNATURES = {
     "dsp_hifigan_conv": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.c_float, ctypes.c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_conv_chain": (_c_int, [_c_p, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_conv_chain_lens": (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_int, _c_p]),
+    "dsp_hifigan_post_lens": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p, _c_int, _c_p]),
     "dsp_hifigan_resunit": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
                                      ctypes.c_float, _c_int, _c_p]),
     "dsp_hifigan_resunit_supported": (_c_int, [_c_int, _c_int, _c_int]),

@@ -1,10 +1,18 @@
-"""Criteria of the DASpeech hot path on top of the HIP ops — caller contract of SURVEY.md §8 a10/a11.
+"""Criteria of the DASpeech hot path on top of the HIP ops — caller contract of SURVEY.md §8 a10/a11, with the reference's
+criterion interface `forward(model, sample, reduce=True) -> (loss, sample_size, logging_output)`.
 
-  nat_dag_loss                 DASpeech/criterions/nat_dag_loss.py:45-366     (_compute_dag_loss :114-156, glat_function :202-264)
-  s2s_dag_fastspeech2_loss     DASpeech/criterions/s2s_dag_fastspeech2_loss.py:26-370 (_compute_dag_loss_with_alpha_beta :53-91,
-                               expect strategy :252-265, TTS losses :275-298)
+  NATDAGLoss                   DASpeech/criterions/nat_dag_loss.py:45-366     (_compute_dag_loss :114-156, set_update_num :161-162,
+                               forward :164-300, glat_function :202-264)
+  S2SDAGFastSpeech2Loss        DASpeech/criterions/s2s_dag_fastspeech2_loss.py:26-370 (_compute_dag_loss_with_alpha_beta :53-91,
+                               argmax strategy :213-251, expect strategy :252-265, TTS losses :267-298)
+  parse_anneal_argument / get_anneal_value      DASpeech/criterions/utilities.py:17-37
+
+fairseq is not a dependency: `cfg` is any attribute bag carrying the reference's argument names (`glat_p`, `glance_strategy`,
+`no_force_emit`, `torch_dag_loss`, `torch_dag_best_alignment`, `torch_dag_logsoftmax_gather`, `training_strategy`,
+`tts_loss_weight`, `dag_freezing_steps`); `task` only supplies `tgt_dict.pad()` and may be None (pad = model.pad).
 """
-from typing import Dict
+from types import SimpleNamespace
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
@@ -13,92 +21,298 @@ from torch import Tensor
 from . import custom_ops, decode_ops
 
 
-def compute_dag_loss(outputs: Tensor, output_masks: Tensor, targets: Tensor, target_masks: Tensor, links: Tensor,
-                     glat_keep_mask: Tensor = None, matchmask: Tensor = None, with_alpha_beta: bool = False):
-    """loss = -(dag_loss / T_b).mean(), non-finite samples zeroed and counted (nat_dag_loss.py:114-156)."""
-    B, L, _ = outputs.shape
-    out_len = output_masks.sum(-1)
-    tgt_len = target_masks.sum(-1)
-    # `outputs` is never read again (the reference forbids it, dag_loss.py:249-251): keep the gather's backward state as two
-    # floats per row instead of an in-place softmax — the forward's B*L*V store disappears, match and gradient are unchanged
-    prev_mode = custom_ops.set_lazy_softmax(True)
-    try:
-        _, match = custom_ops.dag_logsoftmax_gather_inplace(outputs, targets.unsqueeze(1).expand(-1, L, -1))
-    finally:
-        custom_ops.set_lazy_softmax(prev_mode)
-    match = match.transpose(1, 2)                                                     # [B,T,L], already contiguous
-    if glat_keep_mask is not None and matchmask is not None:                          # force-emit mask (:130-132)
-        gl = glat_keep_mask.unsqueeze(1)                                              # [B,1,L] glanced vertices
-        match = match.masked_fill(gl, 0) + match.masked_fill(~matchmask, float("-inf")).masked_fill(~gl, 0).detach()
-    if with_alpha_beta:
-        loss_b, (alpha, beta) = custom_ops.dag_loss_with_alpha_beta(match, links, out_len, tgt_len)
-    else:
-        loss_b, alpha, beta = custom_ops.dag_loss(match, links, out_len, tgt_len), None, None
-    bad = ~torch.isfinite(loss_b)
-    loss_b = loss_b.masked_fill(bad, 0)
-    loss = -(loss_b / tgt_len).mean()
-    return {"loss": loss, "invalid": bad.sum(), "alpha": alpha, "beta": beta, "match": match, "out_len": out_len, "tgt_len": tgt_len}
+# ------------------------------------------------------------------------------------------------ glat-p annealing (utilities.py)
+def parse_anneal_argument(anneal_str: str):
+    """"0.5:0.1@200k" -> [(0.5, 0.0), (0.1, 200000.0)]   (utilities.py:17-29)."""
+    res = []
+    for value_str in str(anneal_str).split(":"):
+        value, pos = value_str.split("@") if "@" in value_str else (value_str, "0")
+        res.append((float(value), float(pos.replace("k", "000"))))
+    return res
 
 
+def get_anneal_value(anneal_params, update_num):
+    """Piecewise-linear schedule, including the reference's `+ 1` in the slope denominator (utilities.py:31-37)."""
+    last_value, last_pos = anneal_params[0][0], 0
+    for value, pos in anneal_params:
+        if update_num < pos:
+            return last_value + (value - last_value) * (update_num - last_pos) / (pos - last_pos + 1)
+        last_value, last_pos = value, pos
+    return anneal_params[-1][0]
+
+
+# ------------------------------------------------------------------------------------------------ glancing (nat_dag_loss.py:202-264)
 @torch.no_grad()
-def glat_function(model, logits: Tensor, links: Tensor, prev_output_tokens: Tensor, tgt_tokens: Tensor, glat: Dict):
-    """Glancing with the Viterbi alignment, "number-random" strategy (nat_dag_loss.py:202-264)."""
-    B, L, _ = logits.shape
-    pad = model.pad
-    tgt_len = tgt_tokens.ne(pad).sum(-1)
-    out_len = prev_output_tokens.ne(pad).sum(-1)
-    # (no gradient here: the HIP operator then leaves the logits untouched, so the reference's defensive .clone() — a full
-    # B*L*V copy — is not needed)
-    _, match = custom_ops.dag_logsoftmax_gather_inplace(logits, tgt_tokens.unsqueeze(1).expand(-1, L, -1))
-    match = match.transpose(1, 2)
-    path = custom_ops.dag_best_alignment(match, links, out_len, tgt_len)              # [B,L], -1 off-path
+def glat_function(model, word_ins_out: Tensor, tgt_tokens: Tensor, prev_output_tokens: Tensor, glat: Dict, links: Tensor = None,
+                  glance_strategy: Optional[str] = None, torch_ops: bool = False, noise: Tensor = None, unif: Tensor = None):
+    """Glancing with the Viterbi alignment.  Same positional signature and return value as the reference's closure
+    (`glat_function(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=links)` -> (glat_prev_output_tokens,
+    glat_tgt_tokens, glat_info)).  `glance_strategy`: None (independent draw per aligned vertex with probability
+    (T - same)/T * p, :229-230) or "number-random" (exactly round((T - same) * p) aligned vertices, chosen by random scores,
+    :232-242 — the released recipe, README.md:240,305).  `noise` / `unif` replay the two random draws (randn :236, rand :251);
+    drawn on the device when None.  `torch_ops` selects the torch_* DAG ops (the reference's --torch-dag-* flags)."""
+    batch_size, prelen, _ = links.shape
+    tarlen = tgt_tokens.shape[1]
+    target_length = tgt_tokens.ne(model.pad).sum(1)
+    output_length = prev_output_tokens.ne(model.pad).sum(1)
+    pred_tokens = word_ins_out.argmax(-1)
+    idx = tgt_tokens.unsqueeze(1).expand(-1, prelen, -1)
+    if torch_ops:
+        _, match = custom_ops.torch_dag_logsoftmax_gather_inplace(word_ins_out, idx)
+        match = match.transpose(1, 2)
+        dense = decode_ops.restore_valid_links(links)
+        path = custom_ops.torch_dag_best_alignment(match.detach().clone(), dense, output_length, target_length)
+    else:
+        # (no gradient here: the HIP operator then leaves the logits untouched, so a defensive clone of B*L*V is not needed)
+        _, match = custom_ops.dag_logsoftmax_gather_inplace(word_ins_out, idx)
+        match = match.transpose(1, 2)
+        path = custom_ops.dag_best_alignment(match, links, output_length, target_length)          # [B,L], -1 off the path
     predict_align_mask = path >= 0
-    matchmask = torch.zeros(B, tgt_tokens.shape[1] + 1, L, device=logits.device, dtype=torch.bool) \
-        .scatter_(1, path.unsqueeze(1) + 1, 1)[:, 1:]                                 # (:225)
-    oracle = tgt_tokens.gather(-1, path.clip(min=0))
-    same = ((logits.argmax(-1) == oracle) & predict_align_mask).sum(1)
-    keep_prob = ((tgt_len - same) / tgt_len.clamp(min=1) * glat["context_p"]).unsqueeze(-1) * predict_align_mask.float()
-    keep_mask = (torch.rand_like(keep_prob) < keep_prob) & predict_align_mask
-    glat_prev = prev_output_tokens.masked_fill(keep_mask, 0) + oracle.masked_fill(~keep_mask, 0)
-    return glat_prev, tgt_tokens, {"glat_keep": keep_mask, "matchmask": matchmask,
-                                   "glat_acc": (same.sum() / tgt_len.sum().clamp(min=1)), "path": path}
+    matchmask = torch.zeros(batch_size, tarlen + 1, prelen, device=path.device, dtype=torch.bool) \
+        .scatter_(1, path.unsqueeze(1) + 1, 1)[:, 1:]                                              # (:225)
+    oracle = tgt_tokens.gather(-1, path.clip(min=0))                                              # (:226)
+    same_num = ((pred_tokens == oracle) & predict_align_mask).sum(1)                              # (:227)
+    if glance_strategy is None:
+        keep_prob = ((target_length - same_num) / target_length * glat["context_p"]).unsqueeze(-1) * predict_align_mask.float()
+    elif glance_strategy == "number-random":
+        prob = torch.randn(oracle.shape, device=tgt_tokens.device, dtype=torch.float) if noise is None else noise.to(tgt_tokens.device, torch.float).clone()
+        prob.masked_fill_(~predict_align_mask, -100)
+        glance_nums = ((target_length - same_num) * glat["context_p"] + 0.5).to(torch.long)
+        prob_thresh = prob.sort(descending=True)[0].gather(-1, (glance_nums - 1).clip(min=0).unsqueeze(-1)).squeeze(-1)
+        prob_thresh.masked_fill_(glance_nums == 0, 100)
+        keep_prob = (prob >= prob_thresh.unsqueeze(-1)).to(prob.dtype)
+    else:
+        raise ValueError(f"glance strategy {glance_strategy!r} (supported: None, 'number-random')")
+    u = torch.rand(prev_output_tokens.shape, device=prev_output_tokens.device) if unif is None else unif.to(prev_output_tokens.device)
+    keep_word_mask = (u < keep_prob).bool()
+    glat_prev_output_tokens = prev_output_tokens.masked_fill(keep_word_mask, 0) + oracle.masked_fill(~keep_word_mask, 0)
+    glat_info = {
+        "glat_accu": (same_num.sum() / target_length.sum()).detach(),
+        "glat_context_p": glat["context_p"],
+        "glat_keep": keep_prob.mean().detach(),
+        "matchmask": matchmask,
+        "keep_word_mask": keep_word_mask,
+        "glat_prev_output_tokens": glat_prev_output_tokens,
+        # extras (not in the reference's dict): the RNG-free intermediates the parity tests compare
+        "path": path, "oracle": oracle, "same_num": same_num,
+    }
+    return glat_prev_output_tokens, tgt_tokens, glat_info
 
 
-def s2s_dag_fastspeech2_loss(model, sample: Dict[str, Tensor], glat_p: float = 0.1, tts_loss_weight: float = 5.0):
-    """One training objective evaluation: DAG loss + 5.0 x FastSpeech2 losses with the "expect" TTS input
-    (s2s_dag_fastspeech2_loss.py:93-306)."""
-    net = sample["net_input"]
-    tgt = sample["target_text"]
-    prev = model.initialize_output_tokens_by_src(net["src_lengths"])
-    glat_state = {}
+DEFAULT_CFG = dict(label_smoothing=0, glat_p="0", glance_strategy=None, no_force_emit=False, torch_dag_logsoftmax_gather=False,
+                   torch_dag_best_alignment=False, torch_dag_loss=False, training_strategy="expect", tts_loss_weight=1.0,
+                   dag_freezing_steps=-1)
 
-    def _glat(m, logits, links, p, t, g):
-        out = glat_function(m, logits, links, p, t, g)
-        glat_state.update(out[2])
-        return out
-    out = model(net["src_tokens"], net["src_lengths"], prev, tgt, glat={"context_p": glat_p}, glat_function=_glat)
-    logits, links, feats = out["word_ins"]["out"], out["links"], out["word_ins"]["features"]
-    prev = out["prev_output_tokens"]
-    dag = compute_dag_loss(logits, prev.ne(model.pad), tgt, tgt.ne(model.pad), links, glat_state.get("glat_keep"),
-                           glat_state.get("matchmask"), with_alpha_beta=True)
-    # expect strategy: z_i = sum_j P(a_i = j | x, y) v_j   (:252-265)
-    expect = decode_ops.posterior(dag["alpha"], dag["beta"]).to(feats.dtype)
-    tts_in = model.adaptor(torch.matmul(expect, feats)[:, 1:, :])
-    tlen = sample["target_text_lengths"] - 1
-    pmask = torch.arange(tts_in.shape[1], device=tts_in.device).unsqueeze(0) >= tlen.unsqueeze(1)
-    mel, out_lens, log_dur, pitch, energy = model.tts(tts_in, pmask, durations=sample["durations"], pitches=sample["pitches"],
-                                                      energies=sample["energies"])
-    # TTS losses (:275-298): L1 on mel frames, MSE on log-duration / pitch / energy over non-pad phonemes
-    tgt_mel, tgt_mel_len = sample["target_audio"], sample["target_audio_lengths"]
-    F_ = min(mel.shape[1], tgt_mel.shape[1])
-    fmask = (torch.arange(F_, device=mel.device).unsqueeze(0) < tgt_mel_len.unsqueeze(1)).unsqueeze(-1)
-    l1 = (F.l1_loss(mel[:, :F_], tgt_mel[:, :F_], reduction="none") * fmask).sum() / fmask.sum().clamp(min=1) / mel.shape[-1]
-    nonpad = ~pmask
-    log_dur_tgt = torch.log(sample["durations"].float() + 1)
-    dur_l = F.mse_loss(log_dur[nonpad], log_dur_tgt[nonpad])
-    pit_l = F.mse_loss(pitch[nonpad], sample["pitches"][nonpad])
-    ene_l = F.mse_loss(energy[nonpad], sample["energies"][nonpad])
-    tts = l1 + dur_l + pit_l + ene_l
-    loss = dag["loss"] + tts_loss_weight * tts
-    return loss, {"loss": loss.detach(), "dag": dag["loss"].detach(), "tts": tts.detach(), "l1": l1.detach(), "dur": dur_l.detach(),
-                  "pitch": pit_l.detach(), "energy": ene_l.detach(), "invalid": dag["invalid"], "glat_acc": glat_state.get("glat_acc")}
+
+class NATDAGLoss:
+    """registered name: nat_dag_loss (nat_dag_loss.py:45)."""
+
+    def __init__(self, cfg=None, task=None, **overrides):
+        base = dict(DEFAULT_CFG)
+        if cfg is not None:
+            base.update(vars(cfg) if not isinstance(cfg, dict) else cfg)
+        base.update(overrides)
+        self.cfg = SimpleNamespace(**base)
+        self.task = task
+        assert self.cfg.label_smoothing == 0, "DAG does not support label smoothing"
+        self.glance_strategy = self.cfg.glance_strategy
+        self._glat_p_anneal_params = parse_anneal_argument(self.cfg.glat_p)
+        self.training = True
+        self.set_update_num(0)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def set_update_num(self, update_num):
+        self.glat_p = get_anneal_value(self._glat_p_anneal_params, update_num)
+
+    def _pad(self, model):
+        return self.task.tgt_dict.pad() if self.task is not None and hasattr(self.task, "tgt_dict") else model.pad
+
+    # ---- nat_dag_loss.py:114-156 / s2s_dag_fastspeech2_loss.py:53-91
+    def _dag_loss_core(self, outputs, output_masks, targets, target_masks, links, name, factor, matchmask, keep_word_mask, model,
+                       with_alpha_beta: bool):
+        prelen = outputs.shape[1]
+        output_length = output_masks.sum(dim=-1)
+        target_length = target_masks.sum(dim=-1)
+        idx = targets.unsqueeze(1).expand(-1, prelen, -1)
+        if self.cfg.torch_dag_logsoftmax_gather:
+            outputs, match_all = custom_ops.torch_dag_logsoftmax_gather_inplace(outputs, idx)
+        else:
+            # `outputs` is never read again (the reference forbids it, dag_loss.py:249-251): keep the gather's backward state as
+            # two floats per row instead of an in-place softmax — the forward's B*L*V store disappears, match and gradient unchanged
+            prev_mode = custom_ops.set_lazy_softmax(True)
+            try:
+                outputs, match_all = custom_ops.dag_logsoftmax_gather_inplace(outputs, idx)
+            finally:
+                custom_ops.set_lazy_softmax(prev_mode)
+        match_all = match_all.transpose(1, 2)                                                   # [B,T,L], already contiguous
+        if matchmask is not None and not self.cfg.no_force_emit:                                # force-emit (:130-132)
+            glat_prev_mask = keep_word_mask.unsqueeze(1)
+            match_all = match_all.masked_fill(glat_prev_mask, 0) + \
+                match_all.masked_fill(~matchmask, float("-inf")).masked_fill(~glat_prev_mask, 0).detach()
+        nvalidtokens = output_masks.sum()
+        alpha = beta = None
+        if with_alpha_beta:
+            assert not self.cfg.torch_dag_loss, "must use the HIP dag loss to obtain alpha and beta"
+            loss_result, (alpha, beta) = custom_ops.dag_loss_with_alpha_beta(match_all, links, output_length, target_length)
+        elif self.cfg.torch_dag_loss:
+            loss_result = custom_ops.torch_dag_loss(match_all, decode_ops.restore_valid_links(links), output_length, target_length)
+        else:
+            loss_result = custom_ops.dag_loss(match_all, links, output_length, target_length)
+        invalid_masks = loss_result.isinf().logical_or(loss_result.isnan())
+        loss_result = loss_result.masked_fill(invalid_masks, 0)
+        invalid_nsentences = invalid_masks.sum().detach()
+        loss = -(loss_result / target_length).mean()
+        nll_loss = loss.detach()
+        nsentences, ntokens = targets.shape[0], targets.ne(self._pad(model)).sum()
+        res = {"name": name, "loss": loss * factor, "nll_loss": nll_loss, "factor": factor, "ntokens": ntokens,
+               "nvalidtokens": nvalidtokens, "nsentences": nsentences, "loss_nofactor": loss, "invalid_nsentences": invalid_nsentences}
+        return res, alpha, beta
+
+    def _compute_dag_loss(self, outputs, output_masks, targets, target_masks, links, label_smoothing=0.0, name="loss", factor=1.0,
+                          matchmask=None, keep_word_mask=None, model=None):
+        return self._dag_loss_core(outputs, output_masks, targets, target_masks, links, name, factor, matchmask, keep_word_mask, model, False)[0]
+
+    def _glat_args(self):
+        if self.glat_p == 0:
+            return None
+        return {"context_p": max(self.glat_p, 0), "require_glance_grad": False}
+
+    def _glat_function(self):
+        torch_ops = bool(self.cfg.torch_dag_best_alignment and self.cfg.torch_dag_logsoftmax_gather)
+
+        def fn(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=None):
+            return glat_function(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=links,
+                                 glance_strategy=self.glance_strategy, torch_ops=torch_ops)
+        return fn
+
+    # ---- nat_dag_loss.py:164-300
+    def forward(self, model, sample, reduce=True):
+        src_tokens, src_lengths = sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"]
+        tgt_tokens = sample["target"]
+        if sample.get("update_num", None) is not None:           # in training
+            self.set_update_num(sample["update_num"])
+        prev_output_tokens = model.initialize_output_tokens_by_tokens(src_tokens, src_lengths)
+        outputs = model(src_tokens, src_lengths, prev_output_tokens, tgt_tokens, self._glat_args(), self._glat_function())
+        _losses = self._compute_dag_loss(
+            outputs["word_ins"].get("out"), prev_output_tokens.ne(self._pad(model)), outputs["word_ins"].get("tgt"),
+            outputs["word_ins"].get("mask", None), outputs["links"], name="dag-loss", factor=1,
+            matchmask=outputs.get("matchmask", None), keep_word_mask=outputs.get("keep_word_mask", None), model=model)
+        loss = _losses["loss"]
+        sample_size = 1
+        logging_output = {
+            "loss": loss.data, "dag_nll-loss": _losses["nll_loss"].data, "ntokens": _losses["ntokens"],
+            "nvalidtokens": _losses["nvalidtokens"], "nsentences": _losses["nsentences"],
+            "invalid_nsentences": _losses["invalid_nsentences"], "sample_size": sample_size,
+            "glat_acc": outputs.get("glat_accu", 0), "glat_keep": outputs.get("glat_keep", 0),
+            "dag-loss": _losses["loss_nofactor"].item() if reduce else _losses["loss_nofactor"],
+        }
+        return loss, sample_size, logging_output
+
+    __call__ = forward
+
+    @staticmethod
+    def logging_outputs_can_be_summed() -> bool:
+        return True
+
+
+def _lengths_to_mask(lens: Tensor, n: int = None) -> Tensor:
+    n = int(lens.max()) if n is None else n
+    return torch.arange(n, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
+
+
+class S2SDAGFastSpeech2Loss(NATDAGLoss):
+    """registered name: s2s_dag_fastspeech2_loss (s2s_dag_fastspeech2_loss.py:26)."""
+
+    def _compute_dag_loss_with_alpha_beta(self, outputs, output_masks, targets, target_masks, links, label_smoothing=0.0, name="loss",
+                                          factor=1.0, matchmask=None, keep_word_mask=None, model=None):
+        return self._dag_loss_core(outputs, output_masks, targets, target_masks, links, name, factor, matchmask, keep_word_mask, model, True)
+
+    def forward(self, model, sample, reduce=True):
+        src_tokens, src_lengths = sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"]
+        tgt_tokens = sample["target_text"]
+        if sample.get("update_num", None) is not None:
+            self.set_update_num(sample["update_num"])
+        prev_output_tokens = model.initialize_output_tokens_by_tokens(src_tokens, src_lengths)
+        train_dag = self.training and sample.get("update_num", 0) > self.cfg.dag_freezing_steps             # (:191)
+        with torch.set_grad_enabled(train_dag and torch.is_grad_enabled()):
+            outputs = model(src_tokens, src_lengths, prev_output_tokens, tgt_tokens, self._glat_args(), self._glat_function())
+        dag_loss, alpha, beta = self._compute_dag_loss_with_alpha_beta(
+            outputs["word_ins"].get("out"), prev_output_tokens.ne(self._pad(model)), outputs["word_ins"].get("tgt"),
+            outputs["word_ins"].get("mask", None), outputs["links"], name="dag-loss", factor=1,
+            matchmask=outputs.get("matchmask", None), keep_word_mask=outputs.get("keep_word_mask", None), model=model)
+        features = outputs["word_ins"]["features"]                                                           # B x L x D
+        if self.cfg.training_strategy == "argmax":
+            # z_i = v_{a*_i}, a* = the Viterbi alignment of (y, x)   (:213-251)
+            with torch.no_grad():
+                links_d = outputs["links"].detach()
+                prelen = links_d.shape[1]
+                target_length = tgt_tokens.ne(model.pad).sum(1)
+                output_length = prev_output_tokens.ne(model.pad).sum(1)
+                idx = tgt_tokens.unsqueeze(1).expand(-1, prelen, -1)
+                # the alignment is taken on the LOGITS: the loss above keeps its backward state as row statistics (lazy mode) or, with
+                # --torch-dag-logsoftmax-gather, does not touch the buffer at all.  (The reference's CUDA path has already overwritten
+                # the buffer with its softmax at this point, :215, so it aligns on log_softmax(softmax(x)); its torch path does not.
+                # The torch path's behaviour is the one reproduced.)
+                logits_d = outputs["word_ins"]["out"].detach()
+                if self.cfg.torch_dag_best_alignment:
+                    _, match = custom_ops.torch_dag_logsoftmax_gather_inplace(logits_d, idx)
+                    path = custom_ops.torch_dag_best_alignment(match.transpose(1, 2).clone(), decode_ops.restore_valid_links(links_d),
+                                                               output_length, target_length)
+                else:
+                    _, match = custom_ops.dag_logsoftmax_gather_inplace(logits_d, idx)
+                    path = custom_ops.dag_best_alignment(match.transpose(1, 2), links_d, output_length, target_length)
+                path = path.clone()
+                path[:, 0] = -1                                                                              # mask <bos>  (:241)
+                features_mask = path >= 0
+                n_on = features_mask.sum(-1)
+                order = torch.argsort((~features_mask).to(torch.int8), dim=1, stable=True)[:, : int(n_on.max())]
+                features_padding_mask = ~_lengths_to_mask(n_on, order.shape[1])
+            features_on_path = features.gather(1, order.unsqueeze(-1).expand(-1, -1, features.shape[-1])) \
+                .masked_fill(features_padding_mask.unsqueeze(-1), 0)                                         # _collate_frames (:244-246)
+            input_to_tts = model.adaptor(features_on_path)
+        else:
+            # expect: z_i = sum_j P(a_i = j | x, y) v_j   (:252-265)
+            score = decode_ops.posterior(alpha, beta).to(features.dtype)
+            input_to_tts = model.adaptor(torch.matmul(score, features)[:, 1:, :])
+            features_padding_mask = ~_lengths_to_mask(sample["target_text_lengths"] - 1, input_to_tts.shape[1])
+        _feat_out, _, log_dur_out, pitch_out, energy_out = model.tts(
+            input_to_tts, features_padding_mask, durations=sample["durations"], pitches=sample["pitches"], energies=sample["energies"])
+        src_mask = _lengths_to_mask(sample["target_text_lengths"] - 1, log_dur_out.shape[1])                 # -1: no <bos>
+        F_ = min(_feat_out.shape[1], sample["target_audio"].shape[1])
+        tgt_mask = _lengths_to_mask(sample["target_audio_lengths"].clamp(max=F_), F_)
+        feat_out, feat = _feat_out[:, :F_][tgt_mask], sample["target_audio"][:, :F_][tgt_mask]
+        l1_loss = F.l1_loss(feat_out, feat, reduction="mean")
+        pitch_loss = F.mse_loss(pitch_out[src_mask], sample["pitches"][src_mask], reduction="mean")
+        energy_loss = F.mse_loss(energy_out[src_mask], sample["energies"][src_mask], reduction="mean")
+        log_dur = torch.log(sample["durations"].to(log_dur_out.dtype) + 1)[src_mask]
+        dur_loss = F.mse_loss(log_dur_out[src_mask], log_dur, reduction="mean")
+        tts_loss = l1_loss + dur_loss + pitch_loss + energy_loss
+        loss = dag_loss["loss"] + tts_loss * self.cfg.tts_loss_weight
+        sample_size = 1
+        logging_output = {
+            "loss": loss.data, "dag-loss": dag_loss["loss"].data, "tts-loss": tts_loss.data, "l1-loss": l1_loss.data,
+            "dur-loss": dur_loss.data, "pitch-loss": pitch_loss.data, "energy-loss": energy_loss.data,
+            "ntokens": dag_loss["ntokens"], "nvalidtokens": dag_loss["nvalidtokens"], "nsentences": dag_loss["nsentences"],
+            "invalid_nsentences": dag_loss["invalid_nsentences"], "sample_size": sample_size,
+            "glat_acc": outputs.get("glat_accu", 0), "glat_keep": outputs.get("glat_keep", 0),
+        }
+        return loss, sample_size, logging_output
+
+    __call__ = forward
+
+
+def s2s_dag_fastspeech2_loss(model, sample: Dict[str, Tensor], glat_p="0.1", tts_loss_weight: float = 5.0,
+                             glance_strategy: Optional[str] = "number-random", update_num: int = 1):
+    """Functional shorthand used by bench.py: one evaluation of the released training objective (README.md:299-307:
+    --glat-p 0.5:0.1@..., --glance-strategy number-random, --training-strategy expect, --tts-loss-weight 5.0)."""
+    crit = S2SDAGFastSpeech2Loss(glat_p=str(glat_p), glance_strategy=glance_strategy, tts_loss_weight=tts_loss_weight)
+    s = dict(sample)
+    s.setdefault("update_num", update_num)
+    loss, _, log = crit(model, s)
+    return loss, log

@@ -28,7 +28,15 @@ struct HgParams {
     int shifts[DSP_HG_MAX_TAPS];
     int min_shift, max_shift;
     int dbg;                      // ablation bits (HG_ABLATE env, timing experiments only): 1 no staging loads, 2 no MFMA loop, 4 no epilogue
+    const int* lens; int len_mul; // per-sample valid input length = lens[b] * len_mul (NULL: T): rows beyond it are read as ZERO, so a
+                                  // padded batch computes, on each sample's valid region, what the sample computes alone
 };
+
+__device__ __forceinline__ int hg_valid_len(const int* lens, int len_mul, int b, int T) {
+    if (!lens) return T;
+    const int v = lens[b] * len_mul;
+    return v < T ? v : T;
+}
 
 template <int CI>
 __device__ __forceinline__ int hg_swz(int row, int chunk) {
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     const _Float16* X = p.x + (size_t)b * p.T * CI;
 
     // ---- stage lrelu(x) tile: rows t0+min_shift .. t0+NT-1+max_shift, zero outside [0,T) ----
-    hg_stage_tile<CI, 6>(smem, X, p.T, t0 + p.min_shift, R, p.pre_slope, (p.dbg & 1) != 0, tid);
+    hg_stage_tile<CI, 6>(smem, X, hg_valid_len(p.lens, p.len_mul, b, p.T), t0 + p.min_shift, R, p.pre_slope, (p.dbg & 1) != 0, tid);
     __syncthreads();
 
     f4 acc[MI][NI];
@@ -237,6 +245,7 @@ struct HgUnitParams {
     const _Float16* x; const _Float16* w1; const float* b1; const _Float16* w2; const float* b2; _Float16* out;
     int B, T, ntaps, dil, accumulate;
     float slope, scale;
+    const int* lens; int len_mul;          // as HgParams
 };
 
 template <int C, int NT, int WM, int WN>
@@ -264,7 +273,8 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
     const _Float16* X = p.x + (size_t)b * p.T * C;
     const _Float16 slope = (_Float16)p.slope;
 
-    hg_stage_tile<C, 6>(xin, X, p.T, t0 - 8 - h1, R1, p.slope, false, tid);
+    const int Tb = hg_valid_len(p.lens, p.len_mul, b, p.T);
+    hg_stage_tile<C, 6>(xin, X, Tb, t0 - 8 - h1, R1, p.slope, false, tid);
     __syncthreads();
 
     f4 acc[MI][NI];
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
             for (int e = 0; e < 4; ++e) {
                 _Float16 h = (_Float16)(acc[i][j][e] + bv[e]);
                 h = h > (_Float16)0 ? h : h * slope;
-                hv[e] = (tm >= 0 && tm < p.T) ? h : (_Float16)0;
+                hv[e] = (tm >= 0 && tm < Tb) ? h : (_Float16)0;
             }
             *reinterpret_cast<uint2*>(mid + ((size_t)m * CH + hg_swz<C>(m, co >> 3)) * 16 + (co & 4) * 2) = *reinterpret_cast<uint2*>(hv);
         }
@@ -430,18 +440,20 @@ __global__ void hg_pack_kernel(const float* __restrict__ x, _Float16* __restrict
 }
 
 __global__ __launch_bounds__(256) void hg_post_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, float bias,
-                                                      float* __restrict__ wav, int T, int C, int K, float slope)
+                                                      float* __restrict__ wav, int T, int C, int K, float slope,
+                                                      const int* __restrict__ lens, int len_mul)
 {
     extern __shared__ float ws[];              // [K][C]
     for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
     __syncthreads();
     const int b = blockIdx.y;
     const _Float16* X = x + (size_t)b * T * C;
+    const int Tb = hg_valid_len(lens, len_mul, b, T);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
         float acc = bias;
         for (int k = 0; k < K; ++k) {
             const int tt = t + k - (K - 1) / 2;
-            if (tt < 0 || tt >= T) continue;
+            if (tt < 0 || tt >= Tb) continue;
             const _Float16* xr = X + (size_t)tt * C;
             for (int c = 0; c < C; c += 8) {
                 const h8 v = *reinterpret_cast<const h8*>(xr + c);
@@ -459,7 +471,7 @@ using namespace dsp;
 
 static int hg_conv_one(const void* x, const void* w, const float* bias, const void* res, void* out,
                        int B, int T, int CI, int M, int ntaps, const int* host_shifts, float pre_slope, float scale,
-                       int out_mode, int up_u, int up_pad, int Tout, int Cout, hipStream_t st)
+                       int out_mode, int up_u, int up_pad, int Tout, int Cout, hipStream_t st, const int* lens = nullptr, int len_mul = 1)
 {
     if (B < 0 || T < 1 || M < 1 || ntaps < 1 || ntaps > DSP_HG_MAX_TAPS || !host_shifts) { set_error("hifigan_conv: bad sizes"); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
@@ -469,7 +481,7 @@ static int hg_conv_one(const void* x, const void* w, const float* bias, const vo
     HgParams p;
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.res = (const _Float16*)res; p.out = (_Float16*)out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.Tout = Tout; p.Cout = Cout; p.out_mode = out_mode; p.up_u = up_u; p.up_pad = up_pad;
-    p.pre_slope = pre_slope; p.scale = scale;
+    p.pre_slope = pre_slope; p.scale = scale; p.lens = lens; p.len_mul = len_mul;
     { static int ablate = -1; if (ablate < 0) { const char* ab = getenv("HG_ABLATE"); ablate = ab ? atoi(ab) : 0; } p.dbg = ablate; }
     p.min_shift = p.max_shift = host_shifts[0];
     for (int k = 0; k < ntaps; ++k) { p.shifts[k] = host_shifts[k]; p.min_shift = min(p.min_shift, host_shifts[k]); p.max_shift = max(p.max_shift, host_shifts[k]); }
@@ -497,7 +509,8 @@ extern "C" int dsp_hifigan_conv(const void* x, const void* w, const float* bias,
 }
 
 static int hg_unit_one(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
-                       int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate, hipStream_t st)
+                       int B, int T, int C, int ntaps, int dil, float slope, float scale, int accumulate, hipStream_t st,
+                       const int* lens = nullptr, int len_mul = 1)
 {
     if (B < 0 || T < 1 || ntaps < 1 || ntaps > DSP_HG_MAX_TAPS || !(ntaps & 1) || dil < 1) { set_error("hifigan_resunit: bad sizes"); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
@@ -505,6 +518,7 @@ static int hg_unit_one(const void* x, const void* w1, const float* b1, const voi
     HgUnitParams p;
     p.x = (const _Float16*)x; p.w1 = (const _Float16*)w1; p.b1 = b1; p.w2 = (const _Float16*)w2; p.b2 = b2; p.out = (_Float16*)out;
     p.B = B; p.T = T; p.ntaps = ntaps; p.dil = dil; p.accumulate = accumulate; p.slope = slope; p.scale = scale;
+    p.lens = lens; p.len_mul = len_mul;
     // C = 128: 78 KB per workgroup, two per CU (353 us per unit vs 2 x 200 us for its two-launch chain at B=32)
     switch (C) {
         // 112-column tiles (91 KB, one workgroup per CU) when they fill the chip; 48-column tiles (58 KB, two per CU) for small batches:
@@ -535,24 +549,39 @@ extern "C" int dsp_hifigan_resunit_supported(int C, int ntaps, int dil)
 
 // The generator is ~100 of these layers per call; driven one ctypes call at a time the host, not the GPU, sets the pace at
 // vocoder batch sizes.  One call walks a whole layer table.
-extern "C" int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream)
+static int hg_chain(const dsp_hg_layer* layers, int n_layers, int B, const int* lens, int T0, hipStream_t st)
 {
     if (n_layers < 0 || (n_layers > 0 && !layers)) { set_error("hifigan_conv_chain: bad layer table"); return DSP_EINVAL; }
-    hipStream_t st = as_stream(stream);
+    if (lens && T0 < 1) { set_error("hifigan_conv_chain: lens given without the padded frame count T0"); return DSP_EINVAL; }
     for (int i = 0; i < n_layers; ++i) {
         const dsp_hg_layer& l = layers[i];
+        int mul = 1;
+        if (lens) {                                                        // this layer's input runs at l.T / T0 steps per mel frame
+            if (l.T % T0) { set_error("hifigan_conv_chain: layer %d length %d is not a multiple of T0 = %d", i, l.T, T0); return DSP_EINVAL; }
+            mul = l.T / T0;
+        }
         if (l.w2) {                                                        // fused ResBlock unit: x -> c1 -> c2 -> + x
             const int dil = l.ntaps > 1 ? l.shifts[l.ntaps / 2 + 1] : 1;
             int rc = hg_unit_one(l.x, l.w, l.bias, l.w2, l.bias2, l.out, B, l.T, l.CI, l.ntaps, dil, l.pre_slope, l.scale,
-                                 l.out_mode == DSP_HG_OUT_ACCUM, st);
+                                 l.out_mode == DSP_HG_OUT_ACCUM, st, lens, mul);
             if (rc) return rc;
             continue;
         }
         int rc = hg_conv_one(l.x, l.w, l.bias, l.res, l.out, B, l.T, l.CI, l.M, l.ntaps, l.shifts, l.pre_slope, l.scale,
-                             l.out_mode, l.up_u, l.up_pad, l.Tout, l.Cout, st);
+                             l.out_mode, l.up_u, l.up_pad, l.Tout, l.Cout, st, lens, mul);
         if (rc) return rc;
     }
     return DSP_OK;
+}
+
+extern "C" int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream)
+{
+    return hg_chain(layers, n_layers, B, nullptr, 0, as_stream(stream));
+}
+
+extern "C" int dsp_hifigan_conv_chain_lens(const dsp_hg_layer* layers, int n_layers, int B, const int* lens, int T0, dsp_stream_t stream)
+{
+    return hg_chain(layers, n_layers, B, lens, T0, as_stream(stream));
 }
 
 extern "C" long dsp_hifigan_packed_weight_elems(int ntaps, int M, int CI)
@@ -580,12 +609,24 @@ extern "C" int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, i
     return check_launch("hifigan_pack_input");
 }
 
-extern "C" int dsp_hifigan_post(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,
-                                dsp_stream_t stream)
+static int hg_post(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope, const int* lens, int len_mul,
+                   hipStream_t st)
 {
     if (B < 0 || T < 1 || C < 8 || (C & 7) || K < 1) { set_error("hifigan_post: bad sizes"); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
     int gx = (T + 255) / 256; if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(hg_post_kernel, dim3(gx, B), dim3(256), (size_t)K * C * 4, as_stream(stream), (const _Float16*)x, w, bias, wav, T, C, K, slope);
+    hipLaunchKernelGGL(hg_post_kernel, dim3(gx, B), dim3(256), (size_t)K * C * 4, st, (const _Float16*)x, w, bias, wav, T, C, K, slope, lens, len_mul);
     return check_launch("hifigan_post");
+}
+
+extern "C" int dsp_hifigan_post(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,
+                                dsp_stream_t stream)
+{
+    return hg_post(x, w, bias, wav, B, T, C, K, slope, nullptr, 1, as_stream(stream));
+}
+
+extern "C" int dsp_hifigan_post_lens(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,
+                                     const int* lens, int len_mul, dsp_stream_t stream)
+{
+    return hg_post(x, w, bias, wav, B, T, C, K, slope, lens, len_mul, as_stream(stream));
 }

@@ -181,7 +181,9 @@ class DagBestAlignmentFunc(Function):
         with torch.cuda.device(dev):
             alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
             # the banded fast path back-traces lazily from alpha_max: no [B,T,L] trace tensor (the reference always writes one)
-            trace = None if lib.dsp_dag_alignment_trace_optional(L, TR) else torch.empty((B, T, L), dtype=torch.int32, device=dev)
+            # (that path also needs 16-byte aligned rows: a view at an odd storage offset takes the trace-based kernels)
+            lazy_ok = lib.dsp_dag_alignment_trace_optional(L, TR) and m.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0
+            trace = None if lazy_ok else torch.empty((B, T, L), dtype=torch.int32, device=dev)
             path = torch.empty((B, L), dtype=torch.long, device=dev)
             rc = lib.dsp_dag_best_alignment(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
                                             _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.current_stream_handle())

@@ -235,7 +235,8 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
         _, pred_length = torch.max(best / lengths ** decode_viterbibeta, dim=1)
         pred_length = pred_length + 1                                    # (:275-276)
         path = torch.empty((B, L), dtype=torch.int64, device=dev)
-        _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr((pred_length + 2).contiguous()), _lib.ptr(path), B, T, L, st),
+        start_rows = (pred_length + 2).contiguous()                       # bound to a name: must outlive the launch
+        _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr(start_rows), _lib.ptr(path), B, T, L, st),
                    "dsp_dag_backtrace")
     # vertices visited at DP rows 1 .. pred_length, in graph order (= the reference's reversed back-trace, :283-290)
     on = (path >= 1) & (path <= pred_length.unsqueeze(1))
@@ -456,9 +457,10 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
         return None
     lib = _lib.load()
     pm = None if pad_mask is None else pad_mask.to(torch.uint8).contiguous()
+    bu, bv = bias_u.detach().float().contiguous(), bias_v.detach().float().contiguous()      # named: must outlive the launch
     with torch.cuda.device(q.device):
         out = torch.empty_like(q)
-        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pp), _lib.ptr(bias_u.detach().float().contiguous()),
-                                            _lib.ptr(bias_v.detach().float().contiguous()), _lib.ptr(pm), _lib.ptr(out), B, T, heads, 64,
+        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pp), _lib.ptr(bu),
+                                            _lib.ptr(bv), _lib.ptr(pm), _lib.ptr(out), B, T, heads, 64,
                                             _lib.current_stream_handle()), "dsp_relpos_attention")
     return out

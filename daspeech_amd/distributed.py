@@ -17,22 +17,29 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int =
     world_size = world_size or dist.get_world_size()
     if world_size == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    bucket, n = [], 0
+    # every rank must flatten the SAME layout: a parameter without a gradient on this rank (unused branch, zero_grad(set_to_none))
+    # gets a zero gradient, as the reference's legacy DDP does (legacy_distributed_data_parallel.py:134-137)
+    plist = [p for p in params if p.requires_grad]
+    for p in plist:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    by_dtype = {}
+    for p in plist:
+        by_dtype.setdefault(p.grad.dtype, []).append(p.grad)       # _flatten_dense_tensors needs one dtype per bucket
 
-    def flush():
-        nonlocal bucket, n
-        if not bucket:
-            return
+    def reduce_bucket(bucket):
         flat = _flatten_dense_tensors(bucket)
         flat.div_(world_size)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         for g, s in zip(bucket, _unflatten_dense_tensors(flat, bucket)):
             g.copy_(s)
+    for dtype in sorted(by_dtype, key=str):
         bucket, n = [], 0
-    for g in grads:
-        if n + g.numel() > bucket_elems:
-            flush()
-        bucket.append(g)
-        n += g.numel()
-    flush()
+        for g in by_dtype[dtype]:
+            if bucket and n + g.numel() > bucket_elems:
+                reduce_bucket(bucket)
+                bucket, n = [], 0
+            bucket.append(g)
+            n += g.numel()
+        if bucket:
+            reduce_bucket(bucket)

@@ -48,7 +48,8 @@ class S2SNATGenerator:
                 gmax = max(1, max(lens[i] for i in idx))
                 sub = mel_sorted[g0:g0 + gsz, :gmax]
                 fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= len_sorted[g0:g0 + gsz].unsqueeze(1)
-                w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2)).squeeze(1)
+                # per-utterance lengths go down to the vocoder: each utterance's samples are those of vocoding it alone
+                w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2), lengths=len_sorted[g0:g0 + gsz].clamp(min=1)).squeeze(1)
                 for k, i in enumerate(idx):
                     wavs[i] = w[k, : max(lens[i], 1) * hop]
         res = []

@@ -206,8 +206,10 @@ class HiFiGANHipRunner:
         return plan
 
     @torch.no_grad()
-    def __call__(self, mel: Tensor) -> Tensor:
-        """mel [B, 80, T] fp32 -> waveform [B, 1, T*hop] fp32."""
+    def __call__(self, mel: Tensor, lengths: Tensor = None) -> Tensor:
+        """mel [B, 80, T] fp32 -> waveform [B, 1, T*hop] fp32.  `lengths` [B] (mel frames per utterance of a padded batch): every layer
+        then treats rows beyond an utterance's own length as zero, so waveform[b, :, :lengths[b]*hop] is what the utterance gives when
+        vocoded alone (the reference's one-file-at-a-time loop, hifi-gan/inference_e2e.py:47-56); samples beyond are undefined."""
         lib = _lib.load()
         B, C, T = mel.shape
         with torch.cuda.device(mel.device):
@@ -215,8 +217,15 @@ class HiFiGANHipRunner:
             st = _lib.current_stream_handle()
             mt = mel.detach().float().transpose(1, 2).contiguous()
             _lib.check(lib.dsp_hifigan_pack_input(_lib.ptr(mt), ctypes.c_void_p(x_in), B, T, C, self.in_pad, st), "dsp_hifigan_pack_input")
-            _lib.check(lib.dsp_hifigan_conv_chain(table, len(table), B, st), "dsp_hifigan_conv_chain")
             wav = torch.empty((B, Tw), dtype=torch.float32, device=mel.device)
-            _lib.check(lib.dsp_hifigan_post(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl, self.post_k,
-                                            0.01, st), "dsp_hifigan_post")
+            if lengths is None:
+                _lib.check(lib.dsp_hifigan_conv_chain(table, len(table), B, st), "dsp_hifigan_conv_chain")
+                _lib.check(lib.dsp_hifigan_post(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl, self.post_k,
+                                                0.01, st), "dsp_hifigan_post")
+            else:
+                lens = lengths.to(device=mel.device, dtype=torch.int32).contiguous()
+                assert lens.shape == (B,)
+                _lib.check(lib.dsp_hifigan_conv_chain_lens(table, len(table), B, _lib.ptr(lens), T, st), "dsp_hifigan_conv_chain_lens")
+                _lib.check(lib.dsp_hifigan_post_lens(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl,
+                                                     self.post_k, 0.01, _lib.ptr(lens), Tw // T, st), "dsp_hifigan_post_lens")
         return wav.unsqueeze(1)

@@ -227,7 +227,6 @@ class DAGDecoder(nn.Module):
         self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
         self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
-        self.synthetic_link_bias = None
         self.fused_links = True                 # inference: fused compact-band HIP kernel (False: the torch formulation)
 
     @staticmethod
@@ -245,8 +244,9 @@ class DAGDecoder(nn.Module):
     def output_layer(self, feats: Tensor) -> Tensor:
         return decode_ops.linear(feats, self.embed_tokens)        # --share-decoder-input-output-embed (weight [V, d], no bias)
 
-    def extract_links(self, feats: Tensor, prev_output_tokens: Tensor) -> Tensor:
-        """Compact transition log-probs [B, L, TR] fp32 (s2t_conformer_dag.py:171-212, banded branch :191-202)."""
+    def extract_links(self, feats: Tensor, prev_output_tokens: Tensor, dist_bias: Optional[Tensor] = None) -> Tensor:
+        """Compact transition log-probs [B, L, TR] fp32 (s2t_conformer_dag.py:171-212, banded branch :191-202).  `dist_bias` [>= TR]
+        (optional, not in the reference) is added to the content score of distance d before the window soft-max."""
         a = self.a
         B, L, d = feats.shape
         h, ck = a.decoder_attention_heads, d // a.decoder_attention_heads
@@ -257,7 +257,7 @@ class DAGDecoder(nn.Module):
         TR = min(a.max_transition_length, L - 1)
         if feats.is_cuda and not torch.is_grad_enabled() and h == 8 and ck % 4 == 0 and ck <= 128 and TR >= 1 and self.fused_links:
             # inference: the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather
-            bias = None if self.synthetic_link_bias is None else self.synthetic_link_bias[:TR]
+            bias = None if dist_bias is None else dist_bias[:TR]
             return decode_ops.extract_links(q, k, log_gates, prev_output_tokens.ne(PAD).sum(-1), TR, bias)
         content = torch.einsum("bicf,bjcf->bijc", q, k) / (ck ** 0.5)                               # [B,L,L,h]
         idx = torch.arange(L, device=feats.device).unsqueeze(1) + torch.arange(TR, device=feats.device).unsqueeze(0) + 1
@@ -265,8 +265,8 @@ class DAGDecoder(nn.Module):
         invalid = idx.unsqueeze(0) >= out_len.view(B, 1, 1)                                          # [B,L,TR]
         gidx = idx.unsqueeze(0).masked_fill(invalid, 0)
         band = content.gather(2, gidx.unsqueeze(-1).expand(-1, -1, -1, h))
-        if self.synthetic_link_bias is not None:       # benchmark calibration only (synthetic.calibrate_synthetic_weights)
-            band = band + self.synthetic_link_bias[:TR].to(band).view(1, 1, TR, 1)
+        if dist_bias is not None:
+            band = band + dist_bias[:TR].to(band).view(1, 1, TR, 1)
         band = band.masked_fill(invalid.unsqueeze(-1), float("-inf"))
         nouse = invalid.all(-1)                                                                      # [B,L]
         band = band.masked_fill(nouse.view(B, L, 1, 1), 0.0)                # avoid NaN rows; re-masked below (:199-201)
@@ -286,7 +286,6 @@ class S2TConformerDAGModel(nn.Module):
         self.pad, self.bos, self.eos, self.unk = PAD, BOS, EOS, UNK
         self.encoder = ConformerEncoder(self.args)
         self.decoder = DAGDecoder(self.args)
-        self.synthetic_token_cycle = 0
 
     # ---- reference checkpoints ----------------------------------------------------------------------
     # fairseq saves {"model": state_dict, "cfg": ..., ...} (checkpoint_utils.py:288).  Parameter names here follow the reference
@@ -335,24 +334,30 @@ class S2TConformerDAGModel(nn.Module):
     def decode_graph(self, prev_output_tokens, enc):
         feats = self.decoder.extract_features(prev_output_tokens, enc)
         logits = self.decoder.output_layer(feats)
-        if self.synthetic_token_cycle:               # benchmark calibration only: vertex j prefers token 4 + (j mod cycle)
-            L, V = logits.shape[1], logits.shape[2]
-            tok = 4 + torch.arange(L, device=logits.device) % min(self.synthetic_token_cycle, V - 4)
-            logits = 0.0 * logits + 20.0 * F.one_hot(tok, V).to(logits).unsqueeze(0)     # GEMM still runs; values replaced
         return logits, self.decoder.extract_links(feats, prev_output_tokens), feats
 
+    def initialize_output_tokens_by_tokens(self, src_tokens: Tensor, src_lengths: Tensor) -> Tensor:
+        """The criteria's entry point (nat_dag_loss.py:191): graph skeleton <bos> <unk>... <eos> of length scale * src_len."""
+        return self.initialize_output_tokens_by_src(src_lengths, max_src_len=src_tokens.shape[1])
+
     def forward(self, src_tokens, src_lengths, prev_output_tokens, tgt_tokens=None, glat=None, glat_function=None):
-        """Training forward with the GLAT two-pass scheme (s2s_conformer_dag_fastspeech2.py:143-173): pass 1 without grad
-        picks the glanced positions, pass 2 (with grad) produces word_ins / links / features."""
+        """Training forward with the GLAT two-pass scheme (s2s_conformer_dag_fastspeech2.py:143-173): pass 1 (no gradient unless
+        glat["require_glance_grad"]) picks the glanced positions through `glat_function(self, word_ins_out, tgt_tokens,
+        prev_output_tokens, glat, links=links)`, pass 2 produces word_ins / links / features; glat_info is merged into the result."""
         enc = self.encoder(src_tokens, src_lengths)
-        if glat is not None and glat_function is not None and tgt_tokens is not None:
-            with torch.no_grad():
+        glat_info = None
+        if glat and glat_function is not None and tgt_tokens is not None:
+            with torch.set_grad_enabled(bool(glat.get("require_glance_grad", False)) and torch.is_grad_enabled()):
                 logits, links, _ = self.decode_graph(prev_output_tokens, enc)
-                prev_output_tokens, tgt_tokens, glat_info = glat_function(self, logits, links, prev_output_tokens, tgt_tokens, glat)
+                prev_output_tokens, tgt_tokens, glat_info = glat_function(self, logits, tgt_tokens, prev_output_tokens, glat, links=links)
+                logits = None
         logits, links, feats = self.decode_graph(prev_output_tokens, enc)
-        return {"word_ins": {"out": logits, "tgt": tgt_tokens, "mask": tgt_tokens.ne(self.pad) if tgt_tokens is not None else None,
-                             "features": feats, "nll_loss": True},
-                "links": links, "prev_output_tokens": prev_output_tokens}
+        ret = {"word_ins": {"out": logits, "tgt": tgt_tokens, "mask": tgt_tokens.ne(self.pad) if tgt_tokens is not None else None,
+                            "nll_loss": True, "features": feats},
+               "links": links, "prev_output_tokens": prev_output_tokens}
+        if glat_info is not None:
+            ret.update(glat_info)
+        return ret
 
     @torch.no_grad()
     def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]):

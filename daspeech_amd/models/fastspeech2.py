@@ -115,8 +115,9 @@ class VariancePredictor(nn.Module):
 
 
 class VarianceAdaptor(nn.Module):
-    """fastspeech2.py:154-216.  Inference path (predicted durations / pitch / energy) uses the HIP ops; with teacher values
-    (training) the same kernels consume the provided tensors."""
+    """fastspeech2.py:154-216.  Without gradient (inference, predicted or supplied durations / pitch / energy) the glue runs on the
+    HIP ops; with gradient enabled (training) it runs on differentiable torch ops so that the mel loss reaches the encoder FFT
+    layers, the adaptor and both embedding tables as in the reference."""
 
     def __init__(self, dim: int, hidden: int, kernel: int, n_bins: int, pitch_min: float, pitch_max: float,
                  energy_min: float, energy_max: float):
@@ -133,14 +134,32 @@ class VarianceAdaptor(nn.Module):
                 energies: Optional[Tensor] = None, d_factor: float = 1.0, p_factor: float = 1.0, e_factor: float = 1.0):
         B, N, C = x.shape
         log_dur_out = self.duration_predictor(x)
-        dur_out = decode_ops.predicted_durations(log_dur_out, padding_mask, d_factor)                     # :202-205
         pitch_out = self.pitch_predictor(x)
         pv = pitch_out * p_factor if pitches is None else pitches
-        x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), pv.reshape(-1), self.pitch_bins, self.embed_pitch.weight).view(B, N, C)
-        energy_out = self.energy_predictor(x)                                                             # on x + pitch_emb  :209
-        ev = energy_out * e_factor if energies is None else energies
-        x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), ev.reshape(-1), self.energy_bins, self.embed_energy.weight).view(B, N, C)
-        x, out_lens = decode_ops.length_regulate(x, dur_out if durations is None else durations)          # :212-214
+        if torch.is_grad_enabled() or not x.is_cuda:
+            # training (teacher durations / pitch / energy, gradients into x and both embedding tables — the reference's
+            # `x + embed(bucketize(v))` and LengthRegulator are differentiable, fastspeech2.py:98-114,169-214) or CPU tensors:
+            # plain torch ops.  The HIP glue kernels below are forward-only.
+            x = x + F.embedding(torch.bucketize(pv.detach(), self.pitch_bins), self.embed_pitch.weight)
+            energy_out = self.energy_predictor(x)
+            ev = energy_out * e_factor if energies is None else energies
+            x = x + F.embedding(torch.bucketize(ev.detach(), self.energy_bins), self.embed_energy.weight)
+            if durations is None:
+                durations = torch.clamp(torch.round((torch.exp(log_dur_out.detach()) - 1) * d_factor).long(), min=0).masked_fill(padding_mask, 0)
+            out_lens = durations.sum(1)
+            maxlen = int(out_lens.max()) if B else 0
+            # length regulator as one gather: frame f of sample b comes from phoneme searchsorted(cumsum(dur), f, right)
+            cum = durations.cumsum(1)
+            frames = torch.arange(maxlen, device=x.device).unsqueeze(0).expand(B, -1)
+            src = torch.searchsorted(cum, frames.contiguous(), right=True).clamp(max=max(N - 1, 0))
+            x = x.gather(1, src.unsqueeze(-1).expand(-1, -1, C)) * (frames < out_lens.unsqueeze(1)).unsqueeze(-1).to(x.dtype)
+        else:
+            dur_out = decode_ops.predicted_durations(log_dur_out, padding_mask, d_factor)                     # :202-205
+            x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), pv.reshape(-1), self.pitch_bins, self.embed_pitch.weight).view(B, N, C)
+            energy_out = self.energy_predictor(x)                                                             # on x + pitch_emb  :209
+            ev = energy_out * e_factor if energies is None else energies
+            x = decode_ops.bucketize_embed_add(x.reshape(B * N, C), ev.reshape(-1), self.energy_bins, self.embed_energy.weight).view(B, N, C)
+            x, out_lens = decode_ops.length_regulate(x, dur_out if durations is None else durations)          # :212-214
         if pitches is None:
             pitch_out = pitch_out * p_factor
         if energies is None:

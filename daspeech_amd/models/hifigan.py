@@ -85,6 +85,7 @@ class HiFiGANGenerator(nn.Module):
         if "generator" in sd and isinstance(sd["generator"], dict):          # hifi-gan checkpoint file layout
             sd = sd["generator"]
         self.load_state_dict(self.fold_weight_norm(sd), strict=True)
+        self._hip_runner = None                       # packed fp16 weights of the HIP backend are stale now
         return self
 
     @classmethod
@@ -102,13 +103,22 @@ class HiFiGANGenerator(nn.Module):
     def _up(self, x: Tensor, m: nn.ConvTranspose1d, pre_slope: float) -> Tensor:
         return F.conv_transpose1d(F.leaky_relu(x, pre_slope), m.weight, m.bias, stride=m.stride, padding=m.padding)
 
-    def forward(self, mel: Tensor) -> Tensor:
-        """mel [B, 80, T] (de-normalised log-mel) -> waveform [B, 1, T*256] in (-1, 1)."""
+    def forward(self, mel: Tensor, lengths: Tensor = None) -> Tensor:
+        """mel [B, 80, T] (de-normalised log-mel) -> waveform [B, 1, T*256] in (-1, 1).  `lengths` [B]: mel frames per utterance of a
+        zero-padded batch; waveform[b, :, :lengths[b]*hop] then equals the utterance vocoded on its own, which is what the reference
+        does (hifi-gan/inference_e2e.py:47-56) — the HIP backend masks per layer inside its kernels, the torch backend loops."""
         if self.conv_backend == "hip" and mel.is_cuda:
-            if getattr(self, "_hip_runner", None) is None:
+            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            if getattr(self, "_hip_runner", None) is None or getattr(self, "_hip_runner_key", None) != key:
                 from ..hifigan_ops import HiFiGANHipRunner
-                self._hip_runner = HiFiGANHipRunner(self)
-            return self._hip_runner(mel)
+                self._hip_runner, self._hip_runner_key = HiFiGANHipRunner(self), key       # re-packed whenever a weight changed
+            return self._hip_runner(mel, lengths)
+        if lengths is not None:
+            out = mel.new_zeros(mel.shape[0], 1, mel.shape[2] * self.hop)
+            for b, n in enumerate(lengths.tolist()):
+                if n > 0:
+                    out[b, :, : n * self.hop] = self.forward(mel[b:b + 1, :, :n])[0]
+            return out
         x = self._conv(mel, self.conv_pre)
         nk = len(self.rb_kernels)
         for i, up in enumerate(self.ups):

@@ -8,6 +8,6 @@ from .generator import S2SNATGenerator
 from .models.daspeech import S2SConformerDAGFastSpeech2Model, S2TConformerDAGModel
 
 MODEL_REGISTRY = {"s2t_conformer_dag": S2TConformerDAGModel, "s2s_conformer_dag_fastspeech2": S2SConformerDAGFastSpeech2Model}
-CRITERION_REGISTRY = {"nat_dag_loss": criterions.compute_dag_loss, "s2s_dag_fastspeech2_loss": criterions.s2s_dag_fastspeech2_loss}
+CRITERION_REGISTRY = {"nat_dag_loss": criterions.NATDAGLoss, "s2s_dag_fastspeech2_loss": criterions.S2SDAGFastSpeech2Loss}
 TASK_REGISTRY = {"nat_speech_to_text": synthetic.NATSpeechToTextTask, "nat_speech_to_speech": synthetic.NATSpeechToSpeechTask}
 GENERATOR_REGISTRY = {"nat_s2s": S2SNATGenerator}

@@ -49,15 +49,30 @@ class NATSpeechToTextTask(NATSpeechToSpeechTask):
     name = "nat_speech_to_text"
 
 
+def _synthetic_decode_graph(self, prev_output_tokens, enc):
+    """decode_graph of the calibrated benchmark models: every layer of the product path runs (decoder, output GEMM, links head);
+    then vertex j is made to prefer token 4 + (j mod cycle) and the transition logits get a distance prior."""
+    feats = self.decoder.extract_features(prev_output_tokens, enc)
+    logits = self.decoder.output_layer(feats)
+    L, V = logits.shape[1], logits.shape[2]
+    tok = 4 + torch.arange(L, device=logits.device) % min(self.synthetic_token_cycle, V - 4)
+    logits = 0.0 * logits + 20.0 * torch.nn.functional.one_hot(tok, V).to(logits).unsqueeze(0)     # GEMM still runs; values replaced
+    return logits, self.decoder.extract_links(feats, prev_output_tokens, dist_bias=self.synthetic_link_bias), feats
+
+
 @torch.no_grad()
 def calibrate_synthetic_weights(model, mean_jump: float = 6.5, frames_per_phoneme: float = 7.5):
     """Random weights decode degenerate graphs (a handful of tokens, zero-length durations).  For throughput runs the two
     data-dependent SHAPES are pinned to CVSS-C statistics (README.md:165-167: ~13 source frames per phoneme, ~7.5 mel frames
     per phoneme): a distance prior on the transition logits (mean jump 6.5 vertices at L = frames/2), distinct argmax tokens on
-    neighbouring vertices (a random output layer collapses every vertex onto one token), and the duration predictor's bias.  Values elsewhere stay random — throughput does not depend on them."""
+    neighbouring vertices (a random output layer collapses every vertex onto one token), and the duration predictor's bias.  Values
+    elsewhere stay random — throughput does not depend on them.  The two graph hooks live HERE (the instance's `decode_graph` is
+    rebound), not in the product model."""
+    import types
     model.synthetic_token_cycle = 97           # distinct neighbouring tokens: no repeat-collapse, no <pad> emissions
     d = torch.arange(1, model.args.max_target_positions + 1, dtype=torch.float)
-    model.decoder.synthetic_link_bias = -4.0 * ((d - mean_jump) / 2.0) ** 2
+    model.synthetic_link_bias = -4.0 * ((d - mean_jump) / 2.0) ** 2
+    model.decode_graph = types.MethodType(_synthetic_decode_graph, model)
     if hasattr(model, "tts"):                  # the speech-to-text model has no TTS stage
         dp = model.tts.var_adaptor.duration_predictor
         dp.proj.weight.mul_(0.05)

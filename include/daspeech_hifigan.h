@@ -50,6 +50,11 @@ typedef struct dsp_hg_layer {
                                              (w, bias, shifts) and whose residual is x; `res` is ignored, out_mode STORE or ACCUM */
 } dsp_hg_layer;
 int dsp_hifigan_conv_chain(const dsp_hg_layer* layers, int n_layers, int B, dsp_stream_t stream);
+/* The same for a PADDED batch: lens [B] int32 (device) = mel frames of each utterance, T0 = frames of the padded batch (every layer's T
+ * is a multiple of it).  Each layer reads rows at or beyond lens[b] * (layer T / T0) as zero — the zero padding the utterance would see if
+ * it were vocoded alone, as the reference does (hifi-gan/inference_e2e.py:47-56: one file at a time) — so the first lens[b] * hop samples
+ * of every waveform are those of the single-utterance call, bit for bit. */
+int dsp_hifigan_conv_chain_lens(const dsp_hg_layer* layers, int n_layers, int B, const int* lens, int T0, dsp_stream_t stream);
 
 /* One ResBlock1 unit (hifi-gan/models.py:38-42: xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x) in one launch, the
  * intermediate kept in LDS:  out = scale * (x + b2 + c2(lrelu(b1 + c1(lrelu(x))))) [+ out if accumulate].
@@ -66,6 +71,9 @@ int dsp_hifigan_pack_input(const float* x, void* out, int B, int T, int C, int C
 /* conv_post: wav[b][t] = tanh( bias + sum_{k,c} w[k][c] * leaky_relu(x[b][t+k-3][c], slope) ), x fp16 [B,T,C], w fp32 [K][C] */
 int dsp_hifigan_post(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,
                      dsp_stream_t stream);
+/* with per-sample valid lengths lens[b] * len_mul (see dsp_hifigan_conv_chain_lens) */
+int dsp_hifigan_post_lens(const void* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,
+                          const int* lens, int len_mul, dsp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,211 @@
+"""TEST INFRASTRUCTURE ONLY — numpy restatement of the PYTHON-side steps of the DASpeech hot path.
+
+Plain per-sample loops that follow the reference line by line (cited next to each step); sized for the small cases of the
+parity tests, never imported by the product (`daspeech_amd/`).
+Parity status: PINNED — `tests/test_graph_golden.py` checks every function here against `tests/golden/graph_links.npz`,
+`graph_decode.npz` and `glat.npz`, which `tests/golden/make_golden_graph.py` produced by running the reference's own
+functions (lifted from its source files at generation time), and against hand-evaluated cases written out in the tests.
+"""
+import numpy as np
+
+from . import dag_oracle
+
+NEG = np.float32(-np.inf)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# a9 / f1 — links producer.  DASpeech/models/s2t_conformer_dag.py:140-212
+# ----------------------------------------------------------------------------------------------------------------
+
+def make_positions(tokens, pad):
+    """fairseq/fairseq/utils.py:256-266: non-pad symbols get pad+1, pad+2, ...; pads get `pad`."""
+    keep = (tokens != pad).astype(np.int64)
+    return np.cumsum(keep, axis=1) * keep + pad
+
+
+def _log_softmax(x, axis):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        m = np.max(x, axis=axis, keepdims=True)
+        z = x - m
+        return (z - np.log(np.sum(np.exp(z), axis=axis, keepdims=True))).astype(np.float32)
+
+
+def _logsumexp(x, axis):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        m = np.max(x, axis=axis, keepdims=True)
+        ms = np.where(np.isfinite(m), m, 0)
+        return (np.log(np.sum(np.exp(x - ms), axis=axis)) + np.squeeze(ms, axis)).astype(np.float32)
+
+
+def extract_links(features, prev_output_tokens, pos_weight, q_w, q_b, k_w, k_b, g_w, g_b, max_transition_length, heads, pad=1):
+    """Compact transition log-probabilities [B, L, TR] (s2t_conformer_dag.py:171-202, the `max_transition_length != -1` branch).
+    pos_weight is the learned `link_positional` table, indexed by make_positions(prev_output_tokens)."""
+    f32 = np.float32
+    feats = np.asarray(features, f32)
+    B, L, D = feats.shape
+    fp = np.concatenate([feats, np.asarray(pos_weight, f32)[make_positions(prev_output_tokens, pad)]], axis=-1)      # :176-183
+    ck = D // heads
+    q = (fp @ np.asarray(q_w, f32).T + np.asarray(q_b, f32)).reshape(B, L, heads, ck)                                 # :191
+    k = (fp @ np.asarray(k_w, f32).T + np.asarray(k_b, f32)).reshape(B, L, heads, ck)                                 # :192
+    log_gates = _log_softmax(fp @ np.asarray(g_w, f32).T + np.asarray(g_b, f32), -1)                                  # :193
+    content = (np.einsum("bicf,bjcf->bijc", q, k) / f32(ck ** 0.5)).astype(f32)                                       # :194  [B,L,L,h]
+    TR = min(int(max_transition_length), L - 1)                                                                       # :144-147
+    out_len = (np.asarray(prev_output_tokens) != pad).sum(-1)
+    links = np.full((B, L, TR), NEG, f32)
+    for b in range(B):
+        for i in range(L):
+            idx = i + np.arange(TR) + 1                                                                               # :148-149
+            invalid = idx >= out_len[b]                                                                               # :150
+            if invalid.all():                                                                                         # link_nouse_mask (:155,:199,:201)
+                continue
+            band = content[b, i, np.where(invalid, 0, idx), :]                                                        # :151-153  [TR,h]
+            band = np.where(invalid[:, None], NEG, band)                                                              # :154
+            band = _log_softmax(band, 0)                                                                              # :200 (softmax over the window)
+            links[b, i] = _logsumexp(band + log_gates[b, i][None, :], -1)                                             # :202
+            links[b, i, invalid] = NEG
+    return links
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# a12 / f3 — graph decode.  DASpeech/models/s2s_conformer_dag_fastspeech2.py:194-304
+# ----------------------------------------------------------------------------------------------------------------
+
+def _collate(rows, D, dtype=np.float32):
+    n = max((len(r) for r in rows), default=0)
+    out = np.zeros((len(rows), n, D), dtype)
+    for i, r in enumerate(rows):
+        if len(r):
+            out[i, :len(r)] = np.stack(r)
+    lens = np.array([len(r) for r in rows], np.int64)
+    return out, np.arange(n)[None, :] >= lens[:, None], lens
+
+
+def _pad_tokens(rows, pad):
+    n = max(len(r) for r in rows)
+    return np.array([r + [pad] * (n - len(r)) for r in rows], np.int64)
+
+
+def forward_decoder(logits, links, features, prev_output_tokens, strategy, pad=1, decode_beta=1.0, decode_viterbibeta=1.0,
+                    src_upsample_scale=0.5):
+    """(output_tokens [B,N] int64 pad-filled, features [B,F,D] zero-padded, features_padding_mask [B,F], lengths [B])."""
+    f32 = np.float32
+    logits = np.asarray(logits, f32)
+    B, L, V = logits.shape
+    dense = dag_oracle.restore_valid_links(np.asarray(links, f32))                                                    # :205-206
+    out_len = (np.asarray(prev_output_tokens) != pad).sum(-1)                                                         # :207
+    tok, sc = dag_oracle.argmax_logp(logits)                                                                          # :209-211
+    feats = np.asarray(features)
+    toks_out, feat_out = [], []
+    if strategy in ("lookahead", "greedy"):
+        for b in range(B):
+            if strategy == "lookahead":
+                nxt = np.argmax(dense[b] + (sc[b] * f32(decode_beta))[None, :], axis=-1)                              # :216
+            else:
+                nxt = np.argmax(dense[b], axis=-1)                                                                    # :219
+            last = int(tok[b, 0]); j = 0; res = [last]; rf = []                                                       # :224-227
+            while j != out_len[b] - 1:                                                                                # :228
+                j = int(nxt[j]); now = int(tok[b, j])                                                                 # :229-230
+                if now != pad and now != last:                                                                        # :232
+                    res.append(now); rf.append(feats[b, j])
+                last = now                                                                                            # :235
+            toks_out.append(res); feat_out.append(rf)
+    elif strategy in ("viterbi", "jointviterbi"):
+        joint = strategy == "jointviterbi"
+        max_length = int(L / 8 / src_upsample_scale)                                                                  # :256
+        for b in range(B):
+            d, s = dense[b], sc[b] * f32(decode_beta)
+            alpha = d[0].copy()                                                                                       # :248
+            if joint:
+                alpha = alpha + s[0]                                                                                  # :249-250
+            alpha = (alpha + s).astype(f32)                                                                           # :252
+            scores, indexs = [alpha], []
+            for _ in range(max_length - 1):                                                                           # :257
+                cand = alpha[:, None] + d                                                                             # :258
+                index = np.argmax(cand, axis=0); alpha = np.max(cand, axis=0).astype(f32)
+                if joint:
+                    alpha = (alpha + s).astype(f32)                                                                   # :259-260
+                scores.append(alpha); indexs.append(index)
+            scores = np.stack(scores) + d[:, out_len[b] - 1][None, :]                                                 # :266-267
+            max_idx = np.argmax(scores, axis=-1); best = np.max(scores, axis=-1)                                      # :270
+            penalty = (np.arange(1, max_length + 1).astype(f32) ** f32(decode_viterbibeta)).astype(f32)               # :271-272
+            pred_length = int(np.argmax(best / penalty)) + 1                                                          # :273-275
+            j = int(max_idx[pred_length - 1])                                                                         # :277
+            last = int(tok[b, j]); res = [last]; rf = [feats[b, j]]                                                   # :283-285
+            for kk in range(pred_length - 1):                                                                         # :286
+                j = int(indexs[pred_length - kk - 2][j]); now = int(tok[b, j])                                        # :287-288
+                if now != pad and now != last:                                                                        # :289
+                    res.insert(0, now); rf.insert(0, feats[b, j])
+                last = now
+            toks_out.append(res); feat_out.append(rf)
+    else:
+        raise ValueError(strategy)
+    fo, mask, lens = _collate(feat_out, feats.shape[-1], feats.dtype)
+    return _pad_tokens(toks_out, pad), fo, mask, lens
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# a10 — GLAT.  DASpeech/criterions/nat_dag_loss.py:202-264, DASpeech/criterions/utilities.py:17-37
+# ----------------------------------------------------------------------------------------------------------------
+
+def glat(logits, links, prev_output_tokens, tgt_tokens, context_p, strategy=None, noise=None, unif=None, pad=1):
+    """RNG-free outputs (path, matchmask, oracle tokens, same_num, glance_nums / keep_prob) and — given the draws `noise`
+    (the randn of :236) and `unif` (the rand of :251) — keep_word_mask and glat_prev_output_tokens."""
+    f32 = np.float32
+    logits = np.asarray(logits, f32)
+    tgt = np.asarray(tgt_tokens); prev = np.asarray(prev_output_tokens)
+    B, L, V = logits.shape
+    T = tgt.shape[1]
+    tgt_len = (tgt != pad).sum(1); out_len = (prev != pad).sum(1)                                                     # :205-207
+    pred = np.argmax(logits, -1)                                                                                      # :209
+    match = dag_oracle.logsoftmax_gather(logits, np.broadcast_to(tgt[:, None, :], (B, L, T)).astype(np.int64), f32)   # :210-213
+    match = np.ascontiguousarray(match.transpose(0, 2, 1))                                                            # :214
+    path = dag_oracle.dag_best_alignment(match, np.asarray(links, f32), out_len, tgt_len, f32)                        # :216-222
+    on = path >= 0                                                                                                    # :224
+    matchmask = np.zeros((B, T + 1, L), bool)
+    for b in range(B):
+        matchmask[b, path[b] + 1, np.arange(L)] = True                                                                # :225 scatter_(1, path+1, 1)
+    matchmask = matchmask[:, 1:]
+    oracle = np.take_along_axis(tgt, np.clip(path, 0, None), axis=-1)                                                 # :226
+    same = ((pred == oracle) & on).sum(1)                                                                             # :227
+    out = {"path": path, "matchmask": matchmask, "oracle": oracle, "same_num": same,
+           "glat_accu": f32(same.sum()) / f32(tgt_len.sum())}
+    if strategy is None:
+        keep_prob = ((tgt_len - same).astype(f32) / tgt_len.astype(f32) * f32(context_p))[:, None] * on.astype(f32)   # :230
+    elif strategy == "number-random":
+        glance_nums = ((tgt_len - same).astype(f32) * f32(context_p) + f32(0.5)).astype(np.int64)                     # :238
+        out["glance_nums"] = glance_nums
+        if noise is None:
+            return out
+        prob = np.where(on, np.asarray(noise, f32), f32(-100))                                                        # :236-237
+        srt = -np.sort(-prob, axis=-1)                                                                                # :240
+        thresh = srt[np.arange(B), np.clip(glance_nums - 1, 0, None)]
+        thresh = np.where(glance_nums == 0, f32(100), thresh)                                                         # :241
+        keep_prob = (prob >= thresh[:, None]).astype(f32)                                                             # :242
+    else:
+        raise ValueError(strategy)
+    out["keep_prob"] = keep_prob
+    out["glat_keep"] = keep_prob.mean(dtype=np.float64).astype(f32)
+    if unif is not None:
+        keep = np.asarray(unif, f32) < keep_prob                                                                      # :253
+        out["keep_word_mask"] = keep
+        out["glat_prev_output_tokens"] = np.where(keep, 0, prev) + np.where(keep, oracle, 0)                          # :255
+    return out
+
+
+def parse_anneal_argument(s):
+    """utilities.py:17-29: "0.5:0.1@200k" -> [(0.5, 0), (0.1, 200000)]."""
+    res = []
+    for part in s.split(":"):
+        value, pos = part.split("@") if "@" in part else (part, "0")
+        res.append((float(value), float(pos.replace("k", "000"))))
+    return res
+
+
+def get_anneal_value(params, update_num):
+    """utilities.py:31-37: piecewise-linear, with the reference's `+ 1` in the denominator."""
+    last_value, last_pos = params[0][0], 0
+    for value, pos in params:
+        if update_num < pos:
+            return last_value + (value - last_value) * (update_num - last_pos) / (pos - last_pos + 1)
+        last_value, last_pos = value, pos
+    return params[-1][0]
