@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's headline workload on MI355X.
+"""bench.py — BASELINE.json's metric on MI355X: "utterances/sec end-to-end S2ST (fbank→waveform) + dag_loss fwd+bwd ms/batch".
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): per GPU a batch of B=32 utterance graphs, graph_len L=4096, target length
-T=512, vocab V=8192, fp32, transition window TR (default 32, `--tr 4095` = README's --max-transition-length 99999).
-One STEP = one pass of the DAG training hot path over the batch with inputs resident in HBM:
-    dag_logsoftmax_gather_inplace (K1, softmax stored for backward)
- -> dag_loss forward (K2 alpha || K3 beta) -> dag_loss backward (K4, K5) -> K1 backward
- -> dag_best_alignment (K6 + K7, the GLAT alignment).
-`value` = utterances/s over all ranks (weak scaling: every rank owns its own 32 utterances, no data-path collective;
-SURVEY.md §8e); `ms_per_step` is the "dag_loss fwd+bwd ms/batch" of BASELINE.json's metric for this step definition.
-The logits buffer is recycled in place between steps (step s reads what step s-1's K1-backward left there: identical
-bytes, flops and control flow, no extra 8.6 GB restore copy inside the timed region).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks (one per
+GPU, RCCL); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank owns its own utterances (weak scaling, no
+data-path collective — SURVEY.md §8e); the only collectives are the contract's barrier and the max-over-ranks of the timings.
 
-Extra objects on the JSON line: `roofline` (the DAG DP forward launch, HIP-event timed on the launch stream, against
-SURVEY.md §8d's algorithmic bytes), `cpu_baseline` (the reference's torch CPU path, twin in oracle/torch_port.py, on a
-bounded sample, rank 0 / N=1 only), `phases_ms` (per-op event timings).
+The default run (`--workload headline`) measures BOTH halves of the metric and prints them in ONE JSON line:
+
+  A. C4 (BASELINE configs[3]): the full S2ST pipeline fbank -> waveform, B=32 per GPU, lookahead decode, fp32, HIP vocoder.
+     One STEP = one batch through S2SNATGenerator.generate.  K steps timed between barrier + synchronize on both sides.
+     `value` = utterances/s over all ranks, `ms_per_step` = ms per batch.
+  B. C2 (configs[1]): the DAG training hot path, B=32 per GPU, graph_len 4096, tgt_len 512, vocab 8192, TR=32, fp32:
+     dag_logsoftmax_gather_inplace -> dag_loss fwd (alpha || beta) -> dag_loss bwd -> gather bwd -> dag_best_alignment.
+     K passes, each phase bracketed by HIP events on the launch stream; `dag.dag_loss_fwd_bwd_ms` is the metric's second half and
+     `roofline` prices the DP forward launch against SURVEY.md §8(d)'s algorithmic bytes.  Every pass starts from FRESH logits
+     (restored from a master copy between the event brackets), and a second input set with peaked, trained-model-like scores
+     (`dag.peaked`) exercises the exactness-guard paths the random inputs never enter.
+  C. C1 (configs[0]: B=4, T=256, L=2048, V=512, TR=L-1, the reference's CPU-runnable case) on the HIP ops, next to
+     `cpu_baseline`: the reference's torch CPU path (twin in oracle/torch_port.py) MEASURED at C1 on this box's host cores
+     — thread count swept, warm-up + median, no extrapolation (rank 0, N=1 only).
+
+Other workloads (`--workload dag|s2st|s2tt|train`) run one of the parts alone (train = C5 per-GPU step with the flat-bucket
+gradient all-reduce).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0
 METRIC = "utterances/sec end-to-end S2ST (fbank→waveform) + dag_loss fwd+bwd ms/batch"
 
 
@@ -38,252 +47,195 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tr", type=int, default=32, help="transition window (32 = tuner default, 4095 = README flag)")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 64 for s2tt, BASELINE configs[2])")
+    ap.add_argument("--workload", default="headline", choices=["headline", "dag", "s2tt", "s2st", "train"],
+                    help="headline (default) = C4 S2ST utt/s + C2 DAG ops with the DP roofline + C1 vs the CPU baseline, one JSON line; "
+                         "dag / s2st / s2tt / train = that part alone")
+    ap.add_argument("--tr", type=int, default=32, help="C2 transition window (32 = banded fast path, 4095 = README's --max-transition-length 99999)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch of the model workloads (default 32; 64 for s2tt, BASELINE configs[2])")
+    ap.add_argument("--dag-batch", type=int, default=32)
     ap.add_argument("--graph-len", type=int, default=4096)
     ap.add_argument("--tgt-len", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=8192)
-    ap.add_argument("--workload", default="dag", choices=["dag", "s2tt", "s2st", "train"],
-                    help="dag = C2 DAG-op hot path (default, the roofline-carrying line); s2tt = C3 speech-to-text forward + graph decode; s2st = C4 full fbank->waveform pipeline; "
-                         "train = C5 DASpeech training step (s2s_dag_fastspeech2_loss + flat-bucket gradient all-reduce)")
     ap.add_argument("--vocoder-backend", default="hip", choices=["torch", "hip"])
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
-                    help="s2st only: autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (the reference runs --fp16); "
-                         "default fp32, the mode the mel parity (<= 1e-4) is stated for")
-    ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"],
-                    help="s2tt / s2st: graph decode mode (the reference's test_scripts run lookahead and jointviterbi)")
+                    help="autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (default fp32, the mode the mel parity is stated for)")
+    ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"])
     ap.add_argument("--vocoder-group", type=int, default=8, help="s2st: utterances per vocoder call (length-sorted groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1,12", help="B,T of the bounded CPU sample")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
+    ap.add_argument("--no-peaked", action="store_true")
+    ap.add_argument("--no-c1", action="store_true")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.workload == "s2tt" else 32
     return args
 
 
-def cpu_baseline(args):
-    """Reference CPU path (torch_dag_logsoftmax_gather_inplace -> torch_dag_loss fwd+bwd -> torch_dag_best_alignment,
-    dense [B,L,L] links) on a bounded sample of the same workload; cost is linear in B and in T."""
+# ======================================================================================================================
+# launcher: --gpus N spawns N ranks itself when it was not started by one
+# ======================================================================================================================
+def maybe_spawn(args):
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return False
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Ctx:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if args.gpus != self.world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch one rank per GPU")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=self.dev)
+            self.world = dist.get_world_size()            # n_gpus of the line comes from RCCL's world, not from the flag
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world > 1:
+            t = self.torch.tensor([seconds], device=self.dev, dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
+    def timed(self, step, steps, warmup):
+        for i in range(warmup):
+            step(i)
+        self.barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            out = step(warmup + i)
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), out
+
+
+# ======================================================================================================================
+# C1 CPU baseline (rank 0, N = 1): the reference's torch path, measured — SURVEY.md §8(d)
+# ======================================================================================================================
+def cpu_baseline_c1(budget_s):
+    """torch_dag_logsoftmax_gather_inplace -> torch_dag_loss (dense [B,L,L] links) fwd + autograd bwd at C1 (B=4, T=256, L=2048,
+    V=512) on the host cores.  Thread count swept on a short slice (T=9), then full-size runs — one warm-up on the slice, then as
+    many full repetitions (<= 3) as the budget allows; the median is reported.  Nothing is extrapolated: if not even ONE full C1
+    pass fits the budget, T is halved until it does and the sample says so."""
     import torch
     from oracle import torch_port
+    B, T, L, V = 4, 256, 2048, 512
     cores = os.cpu_count() or 1
-    sb, stt = [int(v) for v in args.cpu_sample.split(",")]
-    L, V = args.graph_len, min(args.vocab, 8192)
-    # dense links make the reference CPU path's cost independent of TR; the sample uses TR=L-1 so the end is reachable
-    r = torch_port.time_cpu_dag_path(sb, stt, L, V, L - 1, threads=cores)
-    sample_s = r["fwd_s"] + r["bwd_s"] + r.get("align_s", 0.0)
-    # linear extrapolation to the full batch: B/sb samples, (T-1)/(stt-1) DP rows (fwd, bwd and alignment all scale so)
-    full_s = sample_s * (args.batch / sb) * ((args.tgt_len - 1) / (stt - 1))
+    t_start = time.perf_counter()
+    sweep = {}
+    cand = sorted({n for n in (8, 16, 32, 64, 128, cores) if n <= cores})
+    torch_port.time_cpu_dag_path(1, 5, 512, V, 511, threads=cand[0], with_alignment=False)           # page in, warm the allocator
+    for n in cand:
+        r = torch_port.time_cpu_dag_path(B, 9, L, V, L - 1, threads=n, with_alignment=False)
+        sweep[n] = r["fwd_s"] + r["bwd_s"]
+        if time.perf_counter() - t_start > 0.35 * budget_s:
+            break
+    best = min(sweep, key=sweep.get)
+    est_full = sweep[best] * (T - 1) / 8.0
+    Tm = T
+    while est_full > 0.6 * budget_s and Tm > 16:                      # does one full pass fit?  (it does on every box seen so far)
+        Tm //= 2
+        est_full /= 2
+    runs = []
+    while len(runs) < 3 and (not runs or time.perf_counter() - t_start + est_full < budget_s):
+        r = torch_port.time_cpu_dag_path(B, Tm, L, V, L - 1, threads=best, with_alignment=False)
+        runs.append((r["fwd_s"] + r["bwd_s"], r["fwd_s"], r["bwd_s"]))
+        est_full = runs[-1][0]
+    runs.sort()
+    med = runs[len(runs) // 2]
     return {
-        "value": args.batch / full_s, "unit": "utt/s", "cores": cores, "kind": "port",
-        "threads": torch.get_num_threads(),
-        "sample": f"B={sb},T={stt} of B={args.batch},T={args.tgt_len} at L={L},V={V} (dense links); "
-                  f"measured {sample_s:.2f}s (fwd {r['fwd_s']:.2f} bwd {r['bwd_s']:.2f} align {r.get('align_s', 0):.2f}), "
-                  f"extrapolated linearly in B and T to {full_s:.0f}s per batch",
-        "sample_seconds": sample_s, "extrapolated_batch_seconds": full_s,
+        "value": B / med[0], "unit": "utt/s", "cores": best, "kind": "port", "host_cores": cores,
+        "sample": f"C1 (BASELINE configs[0]) B={B}, T={Tm}, L={L}, V={V}, dense links: torch_dag_logsoftmax_gather_inplace + torch_dag_loss forward + "
+                  f"autograd backward, {best} threads (best of sweep {dict((k, round(v, 3)) for k, v in sweep.items())} s on a T=9 slice), "
+                  f"median of {len(runs)} full runs after a warm-up" + ("" if Tm == T else f" — T reduced from {T} to fit the time budget"),
+        "seconds_per_batch": med[0], "fwd_s": med[1], "bwd_s": med[2], "runs": len(runs), "tgt_len": Tm,
+        "leg_seconds": time.perf_counter() - t_start,
     }
 
 
-def run_model_workload(args, torch, dist, dev, world, rank):
-    """C4 (s2st) / C5 (train): released architecture (93.6 M parameters), random weights, synthetic CVSS-C shaped batches."""
-    from daspeech_amd.criterions import s2s_dag_fastspeech2_loss
-    from daspeech_amd.distributed import all_reduce_gradients
-    from daspeech_amd.generator import S2SNATGenerator
-    from daspeech_amd.models import HiFiGANGenerator
-    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model, S2TConformerDAGModel
-    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
-    torch.manual_seed(1234)
-    B = args.batch
-    model = calibrate_synthetic_weights(S2TConformerDAGModel() if args.workload == "s2tt" else S2SConformerDAGFastSpeech2Model()).to(dev)
-    model.args.decode_strategy = args.decode_strategy
-    batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
-    args.warmup = max(args.warmup, 2 * len(batches))     # MIOpen/hipBLASLt pick algorithms per new shape: keep that out of the timing
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    extra = {}
-    roof = None
-    amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
-    if args.workload == "s2tt":
-        model.eval()
-
-        @torch.no_grad()
-        def step(i):
-            ni = batches[i % len(batches)]["net_input"]
-            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
-                enc = model.forward_encoder(ni["src_tokens"], ni["src_lengths"])
-                prev = model.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
-                return model.forward_decoder(prev, enc)["output_tokens"]
-        wl = (f"C3 S2TT full forward (s2t_conformer_dag): Conformer(12L,256) -> DA-Transformer(4L,512) + fused links -> {args.decode_strategy} "
-              f"graph decode to tokens, B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast"))
-    elif args.workload == "s2st":
-        model.eval()
-        voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
-        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=args.vocoder_group)
-        frames = [0]
-
-        def step(i):
-            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
-                out = gen.generate(model, batches[i % len(batches)])
-            frames[0] += sum(o["feature"].shape[0] for o in out)
-            return out
-        wl = (f"C4 full S2ST pipeline, {args.decode_strategy} decode: Conformer(12L,256) -> DA-Transformer(4L,512) + links -> HIP graph decode -> "
-              f"FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) -> HiFi-GAN V1 ({args.vocoder_backend} convs), "
-              f"B={B}/GPU, fbank80 300-800 frames, " + ("fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"))
-    else:
-        model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01,
-                               fused=True)        # one multi-tensor kernel (fairseq uses its FusedAdam the same way); foreach: 73 ms, fused: 68.5 ms per step
-        # the reference trains with fairseq's --fp16 (README.md:241,274: fp16 compute, dynamic loss scaling); --amp bf16 selects
-        # bf16 autocast instead (no loss scaling; MIOpen falls back to a naive bf16 weight-gradient conv: 83 vs 72 ms per step)
-        use_fp16 = args.amp != "bf16"
-        train_dtype = torch.float16 if use_fp16 else torch.bfloat16
-        scaler = torch.amp.GradScaler("cuda", enabled=use_fp16, init_scale=2.0 ** 7)
-
-        def step(i):
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=train_dtype):
-                loss, log = s2s_dag_fastspeech2_loss(model, batches[i % len(batches)])
-            scaler.scale(loss).backward()
-            all_reduce_gradients(model.parameters(), world)            # ONE flat bucket (SURVEY §2.4)
-            scaler.unscale_(opt)
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-            scaler.step(opt)
-            scaler.update()
-            return loss
-        wl = (f"C5 DASpeech training step: s2s_dag_fastspeech2_loss (GLAT two-pass, HIP DAG ops, expect strategy) fwd+bwd + "
-              f"flat-bucket gradient all-reduce + Adam, B={B}/GPU (global {B * world}), " + ("fp16 autocast + loss scaling" if use_fp16 else "bf16 autocast") + " dense layers / fp32 DAG ops")
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if args.workload == "s2tt" and rank == 0 and amp_dtype is None:
-        # roofline of the workload's dominant kernel family, the fp32-accurate split GEMM on the fp16 matrix cores (DESIGN.md §5i):
-        # the Conformer feed-forward's first GEMM at this batch's row count; 3 MFMAs per product, priced against the dense fp16 peak
-        from daspeech_amd import decode_ops
-        lin = model.encoder.conformer_layers[0].ffn1["w_1"]
-        ni = batches[0]["net_input"]
-        with torch.no_grad():
-            Tenc = int(model.forward_encoder(ni["src_tokens"], ni["src_lengths"])["encoder_out"].shape[1])
-            xg = torch.randn(B, Tenc, lin.in_features, device=dev)
-            if decode_ops.split_linear(xg, lin, act="silu") is not None:
-                for _ in range(3):
-                    decode_ops.split_linear(xg, lin, act="silu")
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    decode_ops.split_linear(xg, lin, act="silu")
-                e1.record(); torch.cuda.synchronize()
-                g_ms = e0.elapsed_time(e1) / 20
-                mf = 3 * 2.0 * B * Tenc * lin.in_features * lin.out_features / (g_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": f"conv1d_split_kernel (Linear {lin.in_features}->{lin.out_features} + SiLU on {B * Tenc} rows, fp32-accurate: "
-                                                   "3 fp16 MFMAs per product)", "achieved": mf, "peak": 2500.0, "unit": "TFLOP/s", "frac": mf / 2500.0,
-                        "traffic": None, "avg_call_ms": g_ms, "effective_fp32_TFLOPs": mf / 3}
-    if args.workload == "s2st":
-        extra["mel_frames_per_utt"] = frames[0] / max(1, (args.steps + args.warmup) * B)
-        # roofline of the pipeline's dominant hand-written kernel family, the HiFi-GAN conv stack (MFMA bound, 0.614 GFLOP per mel
-        # frame, DESIGN.md §5c): one vocoder call of the pipeline's group shape, timed with events on the launch stream
-        if rank == 0 and args.vocoder_backend == "hip":
-            Tm = max(8, int(round(extra["mel_frames_per_utt"])))
-            mel = torch.randn(args.vocoder_group, 80, Tm, device=dev)
-            with torch.no_grad():
-                for _ in range(2):
-                    voc(mel)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    voc(mel)
-                e1.record(); torch.cuda.synchronize()
-            v_ms = e0.elapsed_time(e1) / 5
-            tf = 0.614e9 * args.vocoder_group * Tm / (v_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "HiFi-GAN V1 generator conv stack (hifigan_conv / hifigan_resunit kernels), one call of "
-                                               f"{args.vocoder_group} x {Tm} frames", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": tf / 2500.0, "traffic": None, "avg_call_ms": v_ms}
-    result = {
-        "metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("f32" if args.amp == "none" else args.amp) if args.workload in ("s2st", "s2tt") else ("bf16" if args.amp == "bf16" else "fp16"), "data": "synthetic",
-        "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"dp{world}", **extra},
-        "roofline": roof, "cpu_baseline": None,
-    }
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    from daspeech_amd import custom_ops as ops
-    from daspeech_amd import _lib
-    _lib.load()
-    if args.workload != "dag":
-        return run_model_workload(args, torch, dist, dev, world, rank)
-    import sys as _sys
-    _mod = _sys.modules["daspeech_amd.custom_ops.dag_loss"]
-    lsg_fwd, lsg_bwd, lsg_fwd_lazy = _mod._lsg_forward, _mod._lsg_backward, _mod._lsg_forward_lazy
-
-    B, L, T, V = args.batch, args.graph_len, args.tgt_len, args.vocab
-    TR = min(args.tr, L - 1)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    cg = torch.Generator().manual_seed(1234 + rank)
-    logits = torch.randn(B, L, V, device=dev, generator=gen)
+# ======================================================================================================================
+# DAG ops (C2 / C1)
+# ======================================================================================================================
+def make_dag_inputs(torch, dev, B, L, T, V, TR, seed, peaked=False):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    cg = torch.Generator().manual_seed(seed)
     out_len = (L - torch.randint(0, 5, (B,), generator=cg)).to(dev)
     tgt_len = (T - torch.randint(0, 5, (B,), generator=cg)).to(dev)
     tgt = torch.randint(4, V, (B, T), generator=cg).to(dev)
+    logits = torch.randn(B, L, V, device=dev, generator=gen)
     raw = torch.randn(B, L, TR, device=dev, generator=gen)
+    if peaked:
+        # what a trained model produces (tools/peaked_bench.py): the aligned token of a band of vertices around the diagonal scores
+        # ~+14 nats over the rest of the vocabulary (log-prob ~ -0.3 on the band, ~ -12 - 14 elsewhere), 4-sigma transition logits
+        raw = raw * 4.0
+        j = torch.arange(L, device=dev).view(1, L)
+        centre = (j.float() * (T - 1) / (L - 1)).round().long().clamp(0, T - 1)            # target index a vertex most likely emits
+        for off in (-1, 0, 1):
+            t_idx = (centre + off).clamp(0, T - 1).expand(B, L)
+            tok = tgt.gather(1, t_idx)
+            logits.scatter_add_(2, tok.unsqueeze(-1), torch.full((B, L, 1), 9.0 if off else 14.0, device=dev))
     i = torch.arange(L, device=dev).view(1, L, 1)
     d = torch.arange(TR, device=dev).view(1, 1, TR)
     valid = (i + d + 1) < out_len.view(B, 1, 1)
     dead = ~valid.any(-1, keepdim=True)
     links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(dead, 0.0), -1)
     links = links.masked_fill(~valid, float("-inf")).contiguous()
-    del raw, valid, dead
-    idx = tgt.unsqueeze(1).expand(-1, L, -1)
+    return logits, links, out_len, tgt_len, tgt
 
+
+def run_dag_ops(ctx, B, L, T, V, TR, steps, warmup, seed, peaked=False, lazy=False, fresh=True):
+    """K passes of the DAG hot path; returns per-phase HIP-event times (ms) and the wall time of the passes."""
+    torch = ctx.torch
+    from daspeech_amd import custom_ops as ops
+    mod = sys.modules["daspeech_amd.custom_ops.dag_loss"]
+    lsg_fwd, lsg_bwd, lsg_fwd_lazy = mod._lsg_forward, mod._lsg_backward, mod._lsg_forward_lazy
+    dev = ctx.dev
+    logits, links, out_len, tgt_len, tgt = make_dag_inputs(torch, dev, B, L, T, V, TR, seed, peaked)
+    master = logits.clone() if fresh else None
+    idx = tgt.unsqueeze(1).expand(-1, L, -1)
     names = ["gather_fwd", "dag_fwd", "dag_bwd", "gather_bwd", "best_alignment"]
     ev = {n: [] for n in names}
 
-    def step(record, lazy=False, store=None):
-        store = ev if store is None else store
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()              # current stream == the stream the C ABI launches on
+        return e
 
-        def mark():
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()              # current stream == the stream the C ABI launches on
-            return e
+    def step(record):
+        if master is not None:
+            logits.copy_(master)                                     # fresh logits every pass; outside every event bracket
         k = links.detach().requires_grad_()
         e0 = mark()
-        # K1 through the same launch wrappers the autograd Function uses (the logits buffer is a recycled leaf here,
-        # so the Function's mark_dirty contract cannot be exercised on it; tests cover the Function itself)
-        if lazy:        # backward state = two floats per row; the logits are only overwritten by the backward (custom_ops.set_lazy_softmax)
+        # K1 through the launch wrappers the autograd Function uses (the logits buffer is a recycled leaf here, so the Function's
+        # mark_dirty contract cannot be exercised on it; tests cover the Function itself)
+        if lazy:
             match_all, stats = lsg_fwd_lazy(logits, idx)
             match_all.requires_grad_()
         else:
-            match_all, stats = lsg_fwd(logits, idx, True).requires_grad_(), None   # [B,T,L] contiguous; logits <- softmax
+            match_all, stats = lsg_fwd(logits, idx, True).requires_grad_(), None           # [B,T,L] contiguous; logits <- softmax
         e1 = mark()
         loss = ops.dag_loss(match_all, k, out_len, tgt_len)
         e2 = mark()
@@ -299,100 +251,241 @@ def main():
         e5 = mark()
         if record:
             for n, (a, b) in zip(names, [(e0, e1), (e1, e2), (e2b, e3), (e3, e4), (e4, e5)]):
-                store[n].append((a, b))
+                ev[n].append((a, b))
         return loss, gx, gk, path
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step(False)
-    barrier()
+    for _ in range(warmup):
+        step(False)
+    ctx.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out[0]).all(), "non-finite loss in the benchmark batch"
-
+    ctx.barrier()
+    wall = ctx.max_over_ranks(time.perf_counter() - t0)
+    finite = bool(torch.isfinite(out[0]).all())
+    if not peaked:
+        assert finite, "non-finite loss in the benchmark batch"
     phases = {n: sum(a.elapsed_time(b) for a, b in ev[n]) / max(1, len(ev[n])) for n in names}
+    from daspeech_amd import _lib
+    status = _lib.last_launch_status()
+    del logits, master
+    torch.cuda.empty_cache()
+    return phases, wall, {"finite_losses": int(torch.isfinite(out[0]).sum()), "launch_status": status}
 
-    # the same step with the gather's backward state kept as row statistics (the mode daspeech_amd.criterions uses; the
-    # reference forbids reading the logits buffer after the op, so the in-place softmax is not observable): reported beside
-    # the headline numbers, never as `value`
-    ev_lazy = {n: [] for n in names}
-    logits.normal_(generator=gen)
-    for _ in range(max(2, args.warmup)):
-        step(False, lazy=True)
-    barrier()
-    t0l = time.perf_counter()
-    for _ in range(args.steps):
-        out_l = step(True, lazy=True, store=ev_lazy)
-    barrier()
-    elapsed_l = time.perf_counter() - t0l
-    if world > 1:
-        tt = torch.tensor([elapsed_l], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_l = float(tt.item())
-    assert torch.isfinite(out_l[0]).all()
-    lazy_report = {"ms_per_step": elapsed_l * 1e3 / args.steps, "value": world * B * args.steps / elapsed_l, "unit": "utt/s",
-                   "phases_ms": {n: sum(a.elapsed_time(b) for a, b in ev_lazy[n]) / max(1, len(ev_lazy[n])) for n in names},
-                   "note": "gather backward state = (max, 1/sum-exp) per row instead of the in-place softmax: same match and gradients"}
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = world * B * args.steps / elapsed
 
-    # roofline of the DAG DP forward launch (alpha + beta): SURVEY.md §8(d)
-    #   2 * (B*T*L*4 [read match] + B*L*TR*4 [read links] + B*T*L*4 [write alpha/beta])
-    alg_bytes = 2.0 * (B * T * L * 4 + B * L * TR * 4 + B * T * L * 4)
-    dag_fwd_ms = phases["dag_fwd"]
-    achieved = alg_bytes / (dag_fwd_ms * 1e-3) / 1e9
-    traffic = None
+def dag_report(ctx, args, steps, warmup):
+    B, L, T, V = args.dag_batch, args.graph_len, args.tgt_len, args.vocab
+    TR = min(args.tr, L - 1)
+    phases, wall, info = run_dag_ops(ctx, B, L, T, V, TR, steps, warmup, 1234 + ctx.rank)
+    BTL, BLV, BLTR = B * T * L * 4.0, B * L * V * 4.0, B * L * TR * 4.0
+    # 2 * (B*T*L*4 [read match] + B*L*TR*4 [read links] + B*T*L*4 [write alpha/beta])
+    alg_bytes = 2.0 * (BTL + BLTR + BTL)
+    phase_bytes = {"gather_fwd": 2 * BLV + BTL, "gather_bwd": 2 * BLV + BTL, "dag_fwd": alg_bytes,
+                   "dag_bwd": 3 * BTL + BLTR + BTL + BLTR, "best_alignment": 2 * BTL + BLTR}
+    ms = phases["dag_fwd"]
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic, src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_dag_fwd.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"tr{TR}", {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc)).get(f"tr{TR}", {})
+            if rec.get("shape") in (None, [B, T, L, TR]):
+                traffic, src = rec.get("hbm_bytes_per_launch"), rec.get("source", "profiles/pmc_dag_fwd.json")
         except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "dag_loss forward DP (alpha||beta, one launch)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes": alg_bytes, "avg_launch_ms": dag_fwd_ms}
+            pass
+    roofline = {"bound": "hbm", "kernel": "dag_loss forward DP (alpha||beta, one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes": alg_bytes, "avg_launch_ms": ms}
+    step_ms = sum(phases.values())
+    rep = {
+        "workload": f"C2 DAG training hot path: logsoftmax_gather + dag_loss fwd+bwd + dag_best_alignment, B={B}/GPU, graph_len={L}, "
+                    f"tgt_len={T}, vocab={V}, TR={TR}, fp32, fresh logits every pass",
+        "dag_loss_fwd_bwd_ms": phases["dag_fwd"] + phases["dag_bwd"], "step_ms": step_ms, "utt_per_s": ctx.world * B / (step_ms * 1e-3),
+        "phases_ms": phases, "wall_ms_per_pass_incl_restore": wall * 1e3 / steps,
+        "roofline_phases": {n: {"algorithmic_bytes": phase_bytes[n], "ms": phases[n], "achieved_GBps": phase_bytes[n] / (phases[n] * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": phase_bytes[n] / (phases[n] * 1e-3) / 1e9 / HBM_PEAK_GBS} for n in phases},
+        **info,
+    }
+    if not args.no_peaked:
+        pp, _, pinfo = run_dag_ops(ctx, B, L, T, V, TR, max(3, steps // 2), 2, 4321 + ctx.rank, peaked=True)
+        rep["peaked"] = {"note": "trained-model-like scores (aligned tokens +14 nats on a band around the diagonal, 4-sigma transition logits)",
+                         "phases_ms": pp, "dag_loss_fwd_bwd_ms": pp["dag_fwd"] + pp["dag_bwd"],
+                         "dag_fwd_vs_random": pp["dag_fwd"] / phases["dag_fwd"], **pinfo}
+    lp, _, _ = run_dag_ops(ctx, B, L, T, V, TR, max(3, steps // 2), 2, 1234 + ctx.rank, lazy=True)
+    rep["lazy_softmax"] = {"note": "gather backward state = (max, 1/sum-exp) per row instead of the in-place softmax (the mode daspeech_amd.criterions "
+                                   "uses): same match and gradients", "phases_ms": lp, "step_ms": sum(lp.values())}
+    return rep, roofline
 
-    # the same accounting for every phase of the step (SURVEY.md §8(d) byte counts; a phase = the launches of one operator call)
-    BTL, BLV, BLTR = B * T * L * 4.0, B * L * V * 4.0, B * L * TR * 4.0
-    phase_bytes = {
-        "gather_fwd": 2 * BLV + BTL,                     # logits read, softmax written in place, match written
-        "gather_bwd": 2 * BLV + BTL,                     # softmax read, gradient written in place, grad_match read
-        "dag_fwd": alg_bytes,
-        "dag_bwd": 3 * BTL + BLTR + BTL + BLTR,          # alpha, beta, match + links read; grad_match + grad_links written
-        "best_alignment": 2 * BTL + BLTR,                # match read, alpha_max written (no trace tensor), links read
-    }
-    roofline_phases = {n: {"algorithmic_bytes": phase_bytes[n], "ms": phases[n],
-                           "achieved_GBps": phase_bytes[n] / (phases[n] * 1e-3) / 1e9,
-                           "frac_of_hbm_peak": phase_bytes[n] / (phases[n] * 1e-3) / 1e9 / HBM_PEAK_GBS} for n in names}
-    result = {
-        "metric": METRIC, "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2 DAG training hot path: logsoftmax_gather + dag_loss fwd+bwd + dag_best_alignment, "
-                               f"B={B}/GPU, graph_len={L}, tgt_len={T}, vocab={V}, TR={TR}, fp32",
-                   "batch_per_gpu": B, "graph_len": L, "tgt_len": T, "vocab": V, "trans_len": TR,
-                   "parallelism": f"dp{world} (independent utterances per rank, no data-path collective)"},
-        "roofline": roofline, "phases_ms": phases, "roofline_phases": roofline_phases, "lazy_softmax": lazy_report,
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args)
-    elif rank == 0:
-        result["cpu_baseline"] = None
+
+def c1_report(ctx, steps):
+    """BASELINE configs[0] on the HIP ops: B=4, T=256, L=2048, V=512, TR=L-1 (the reference's dense training window)."""
+    B, T, L, V = 4, 256, 2048, 512
+    phases, _, info = run_dag_ops(ctx, B, L, T, V, L - 1, max(3, steps // 2), 2, 99 + ctx.rank)
+    return {"workload": f"C1 B={B}, T={T}, L={L}, V={V}, TR={L - 1} on the HIP ops", "phases_ms": phases,
+            "dag_loss_fwd_bwd_ms": phases["dag_fwd"] + phases["dag_bwd"],
+            "gather_plus_dag_fwd_bwd_ms": phases["gather_fwd"] + phases["dag_fwd"] + phases["dag_bwd"] + phases["gather_bwd"], **info}
+
+
+# ======================================================================================================================
+# model workloads (C3 / C4 / C5)
+# ======================================================================================================================
+def build_model_step(ctx, args, workload):
+    torch = ctx.torch
+    from daspeech_amd.criterions import s2s_dag_fastspeech2_loss
+    from daspeech_amd.distributed import all_reduce_gradients
+    from daspeech_amd.generator import S2SNATGenerator
+    from daspeech_amd.models import HiFiGANGenerator
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model, S2TConformerDAGModel
+    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    torch.manual_seed(1234)
+    B = args.batch
+    model = calibrate_synthetic_weights(S2TConformerDAGModel() if workload == "s2tt" else S2SConformerDAGFastSpeech2Model()).to(dev)
+    model.args.decode_strategy = args.decode_strategy
+    batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
+    amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
+    state = {"frames": 0, "model": model, "batches": batches, "B": B}
+    prec = "fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"
+    if workload == "s2tt":
+        model.eval()
+
+        @torch.no_grad()
+        def step(i):
+            ni = batches[i % len(batches)]["net_input"]
+            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                enc = model.forward_encoder(ni["src_tokens"], ni["src_lengths"])
+                prev = model.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
+                return model.forward_decoder(prev, enc)["output_tokens"]
+        wl = (f"C3 S2TT full forward (s2t_conformer_dag): Conformer(12L,256) -> DA-Transformer(4L,512) + fused links -> {args.decode_strategy} "
+              f"graph decode to tokens, B={B}/GPU, fbank80 300-800 frames, {prec}")
+    elif workload == "s2st":
+        model.eval()
+        voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
+        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=args.vocoder_group)
+        state["voc"] = voc
+
+        def step(i):
+            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                out = gen.generate(model, batches[i % len(batches)])
+            state["frames"] += sum(o["feature"].shape[0] for o in out)
+            return out
+        wl = (f"C4 full S2ST pipeline (s2s_conformer_dag_fastspeech2 + HiFi-GAN V1), {args.decode_strategy} decode: Conformer(12L,256) -> "
+              f"DA-Transformer(4L,512) + links -> HIP graph decode -> FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) "
+              f"-> HiFi-GAN V1 ({args.vocoder_backend} convs, groups of {args.vocoder_group} with per-utterance lengths), B={B}/GPU, fbank80 300-800 frames, {prec}")
+    else:
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
+        # the reference trains with fairseq's --fp16 (README.md:241,274: fp16 compute, dynamic loss scaling); --amp bf16 selects bf16 autocast
+        use_fp16 = args.amp != "bf16"
+        train_dtype = torch.float16 if use_fp16 else torch.bfloat16
+        scaler = torch.amp.GradScaler("cuda", enabled=use_fp16, init_scale=2.0 ** 7)
+
+        def step(i):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=train_dtype):
+                loss, log = s2s_dag_fastspeech2_loss(model, batches[i % len(batches)], glat_p="0.5:0.1@200k", update_num=100000 + i)
+            scaler.scale(loss).backward()
+            all_reduce_gradients(model.parameters(), world)            # ONE flat bucket per dtype (SURVEY §2.4)
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            scaler.step(opt)
+            scaler.update()
+            return loss
+        wl = (f"C5 DASpeech training step: s2s_dag_fastspeech2_loss (GLAT two-pass with number-random glancing, HIP DAG ops, expect strategy) fwd+bwd + "
+              f"flat-bucket gradient all-reduce + Adam, B={B}/GPU (global {B * world}), " + ("fp16 autocast + loss scaling" if use_fp16 else "bf16 autocast")
+              + " dense layers / fp32 DAG ops")
+    return step, wl, state
+
+
+def vocoder_roofline(ctx, args, state):
+    """The pipeline's dominant hand-written kernel family, the HiFi-GAN conv stack (MFMA bound, 0.614 GFLOP per mel frame):
+    one vocoder call of the pipeline's group shape, timed with events on the launch stream."""
+    torch = ctx.torch
+    voc = state.get("voc")
+    if voc is None or args.vocoder_backend != "hip":
+        return None
+    Tm = max(8, int(round(state["mel_frames_per_utt"])))
+    mel = torch.randn(args.vocoder_group, 80, Tm, device=ctx.dev)
+    with torch.no_grad():
+        for _ in range(2):
+            voc(mel)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            voc(mel)
+        e1.record(); torch.cuda.synchronize()
+    v_ms = e0.elapsed_time(e1) / 5
+    tf = 0.614e9 * args.vocoder_group * Tm / (v_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"HiFi-GAN V1 generator conv stack (hifigan_conv / hifigan_resunit kernels), one call of {args.vocoder_group} x {Tm} frames",
+            "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None, "avg_call_ms": v_ms}
+
+
+def run_model(ctx, args, workload, steps, warmup):
+    step, wl, state = build_model_step(ctx, args, workload)
+    warmup = max(warmup, 2 * len(state["batches"]))      # MIOpen / hipBLASLt pick algorithms per new shape: keep that out of the timing
+    elapsed, _ = ctx.timed(step, steps, warmup)
+    B = state["B"]
+    rep = {"workload": wl, "value": ctx.world * B * steps / elapsed, "unit": "utt/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps,
+           "warmup": warmup, "batch_per_gpu": B}
+    if workload == "s2st":
+        state["mel_frames_per_utt"] = state["frames"] / max(1, (steps + warmup) * B)
+        rep["mel_frames_per_utt"] = state["mel_frames_per_utt"]
+        if ctx.rank == 0:
+            rep["roofline"] = vocoder_roofline(ctx, args, state)
+    state.clear()
+    ctx.torch.cuda.empty_cache()
+    return rep
+
+
+# ======================================================================================================================
+def main():
+    args = parse()
+    maybe_spawn(args)
+    ctx = Ctx(args)
+    from daspeech_amd import _lib
+    _lib.load()                                       # fails loudly if the HIP extension is missing
+    world, rank = ctx.world, ctx.rank
+    base = {"metric": METRIC, "unit": "utt/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "data": "synthetic"}
+    par = f"dp{world} (independent utterances per rank, no data-path collective)"
+    if args.workload in ("s2tt", "s2st", "train"):
+        rep = run_model(ctx, args, args.workload, args.steps, args.warmup)
+        dtype = ("f32" if args.amp == "none" else args.amp) if args.workload != "train" else ("bf16" if args.amp == "bf16" else "fp16")
+        result = {**base, "value": rep["value"], "steps": rep["steps"], "warmup": rep["warmup"], "ms_per_step": rep["ms_per_step"], "dtype": dtype,
+                  "config": {"workload": rep["workload"], "batch_per_gpu": rep["batch_per_gpu"], "parallelism": par,
+                             **({"mel_frames_per_utt": rep["mel_frames_per_utt"]} if "mel_frames_per_utt" in rep else {})},
+                  "roofline": rep.get("roofline"), "cpu_baseline": None}
+    elif args.workload == "dag":
+        rep, roofline = dag_report(ctx, args, args.steps, args.warmup)
+        result = {**base, "value": rep["utt_per_s"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["step_ms"], "dtype": "f32",
+                  "config": {"workload": rep["workload"], "batch_per_gpu": args.dag_batch, "parallelism": par}, "roofline": roofline, "dag": rep,
+                  "cpu_baseline": None}
+        if not args.no_c1:
+            result["c1"] = c1_report(ctx, args.steps)
+    else:
+        # headline: A (C4 S2ST, carries `value`), B (C2 DAG ops, carries `roofline`), C (C1 HIP vs the measured CPU baseline)
+        s2st = run_model(ctx, args, "s2st", args.steps, args.warmup)
+        dag, roofline = dag_report(ctx, args, args.steps, args.warmup)
+        result = {**base, "value": s2st["value"], "steps": s2st["steps"], "warmup": s2st["warmup"], "ms_per_step": s2st["ms_per_step"],
+                  "dtype": "f32" if args.amp == "none" else args.amp,
+                  "dag_loss_fwd_bwd_ms_per_batch": dag["dag_loss_fwd_bwd_ms"],
+                  "config": {"workload": "value / ms_per_step: " + s2st["workload"] + "  ||  dag_loss_fwd_bwd_ms_per_batch / roofline: " + dag["workload"],
+                             "batch_per_gpu": s2st["batch_per_gpu"], "dag_batch_per_gpu": args.dag_batch, "graph_len": args.graph_len,
+                             "tgt_len": args.tgt_len, "vocab": args.vocab, "trans_len": min(args.tr, args.graph_len - 1),
+                             "mel_frames_per_utt": s2st.get("mel_frames_per_utt"), "parallelism": par},
+                  "roofline": roofline, "s2st_vocoder_roofline": s2st.get("roofline"), "dag": dag, "cpu_baseline": None}
+        if not args.no_c1:
+            result["c1"] = c1_report(ctx, args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("headline", "dag"):
+        cb = cpu_baseline_c1(args.cpu_budget)
+        result["cpu_baseline"] = cb
+        if "c1" in result and cb["tgt_len"] == 256:
+            gpu_s = result["c1"]["gather_plus_dag_fwd_bwd_ms"] * 1e-3
+            result["c1"]["speedup_vs_cpu_baseline"] = cb["seconds_per_batch"] / gpu_s
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
-        dist.destroy_process_group()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -18,14 +18,8 @@ int launch_max_alpha_generic(const float* match, const float* links, const int64
                              float* alpha, int32_t* trace, int B, int T, int L, int TR, hipStream_t st);
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
 
-bool strip4_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
-int launch_dag_strip4(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
-
 bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
 int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
-
-bool strip4h_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
-int launch_dag_strip4h(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
@@ -34,10 +28,11 @@ bool strip2_supported(const void* match, const void* alpha, const void* beta, co
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
-// 3 = strip4 (4 columns/lane, 3 helper waves), 4 = strip2 (2 columns/lane, loader wave),
-// 5 = strip4g (strip4 with one exponent per lane group), 6 = strip4h (strip4g, two compute waves per SIMD),
-// 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL)
-static int g_path = 0;
+// 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
+// 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL).
+// (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
+// another thread's calls launch.
+static thread_local int g_path = 0;
 static unsigned int g_last_fallbacks = 0;
 static unsigned int g_dbg[64] = {0};
 
@@ -61,17 +56,12 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    const bool s4 = strip4_supported(match, alpha, beta, nullptr, L, TR);
-    // auto: strip4g for the log-sum DP (0.56 ms at C2 vs 0.71 ms strip4, 0.94 ms strip2), strip2 for the max-DP
-    if (g_path == 6 && strip4h_supported(match, alpha, beta, L, TR))
-        rc = launch_dag_strip4h(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
-    else if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
+    // auto: strip4g for the log-sum DP, strip2 for the max-DP with a trace
+    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    else if (g_path == 3 && s4)
-        rc = launch_dag_strip4(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    else if ((g_path == 0 || g_path == 2 || g_path == 3) && TR <= 32 && banded_supported(L, TR))
+    else if ((g_path == 0 || g_path == 2) && TR <= 32 && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else
         rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
@@ -109,18 +99,12 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
         if (!trace) { set_error("dag_best_alignment: this shape / kernel family needs a trace buffer (see dsp_dag_alignment_trace_optional)"); return DSP_EINVAL; }
     }
     if ((size_t)L * 4 <= 160 * 1024) {
-        const bool s4 = strip4_supported(match, alpha_max, nullptr, trace, L, TR);
         if ((g_path == 0 || g_path == 4) && strip2_supported(match, alpha_max, nullptr, trace, L, TR)) {
             rc = launch_dag_strip2(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
         }
-        if (g_path == 3 && s4) {
-            rc = launch_dag_strip4(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
-            if (rc) return rc;
-            return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
-        }
-        if ((g_path == 0 || g_path == 2 || g_path == 3) && TR <= 32 && banded_supported(L, TR)) {
+        if ((g_path == 0 || g_path == 2) && TR <= 32 && banded_supported(L, TR)) {
             rc = launch_dag_banded(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
