@@ -26,6 +26,11 @@ int launch_dag_strip5(const float*, const float*, const int64_t*, const int64_t*
 void set_s5_cpl(int v);
 void set_s5_w(int v);
 
+bool dense_mfma_supported(int L, int TR);
+int launch_dag_dense_mfma(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+void set_dm_mt(int v);
+void set_dm_ng(int v);
+
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
 
@@ -35,7 +40,8 @@ int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, cons
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
-// 8 = strip5 (exp space, one exponent per 64-column superblock, 2 or 4 columns per lane; experimental).
+// 8 = strip5 (exp space, one exponent per 64-column superblock, 2 or 4 columns per lane; experimental),
+// 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 64).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
 static thread_local int g_path = 0;
@@ -71,6 +77,8 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 2) && TR <= 32 && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
+    else if ((g_path == 0 || g_path == 9) && dense_mfma_supported(L, TR))
+        rc = launch_dag_dense_mfma(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else
         rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     if (rc) return rc;
@@ -151,6 +159,8 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
     if (name && !strcmp(name, "s5_cpl")) { set_s5_cpl(value); return DSP_OK; }
     if (name && !strcmp(name, "s5_w")) { set_s5_w(value); return DSP_OK; }
+    if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
+    if (name && !strcmp(name, "dm_ng")) { set_dm_ng(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");
     return DSP_EINVAL;

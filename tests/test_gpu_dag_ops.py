@@ -476,3 +476,82 @@ def test_alignment_large_graph_properties(L):
         assert np.all(np.diff(pos) >= 1) and np.all(np.diff(pos) <= TR)
     ref = orc.dag_best_alignment(match[:1], links[:1], ol[:1], tl[:1], np.float32)
     np.testing.assert_array_equal(path[:1], ref)
+
+
+# ---------------------------------------------------------------------------------------------- dense window on the f32 matrix cores
+DENSE_SHAPES = [(3, 24, 200, 199), (2, 40, 256, 255), (4, 33, 130, 129), (2, 20, 500, 100), (2, 70, 400, 399), (1, 9, 1024, 1023),
+                (3, 18, 192, 191), (2, 50, 640, 639)]
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape", DENSE_SHAPES)
+def test_dense_mfma_dp_matches_oracle(shape, masked):
+    """dag_dp_dense_mfma.hip (TR > 64: exp-space blocked products on v_mfma_f32_16x16x4_f32 + sequential diagonal blocks) against the
+    fp64 oracle: ragged lengths, windows between 64 and L-1, graph sizes that are not multiples of the 64-column block, and
+    force-emit style emissions (whole rows -inf except one column, scattered -inf cells: nat_dag_loss.py:130-132)."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(11 + L, B, T, L, TR)
+    if masked:
+        rng = np.random.default_rng(L)
+        match[0, min(3, T - 1), :] = -np.inf; match[0, min(3, T - 1), min(L - 1, 10)] = 0.0
+        match[rng.random(match.shape) < 0.1] = -np.inf
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_()
+    try:
+        res = {}
+        for path in (9, 1):                       # 9 = matrix-core kernel (also the auto choice), 1 = log-space row-sequential kernels
+            _lib.set_option("dp_path", path)
+            loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+            assert _lib.last_launch_status() == 0
+            res[path] = (alpha.cpu().numpy(), beta.cpu().numpy(), loss.detach().cpu().numpy())
+    finally:
+        _lib.set_option("dp_path", 0)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    for path, (a, b, ls) in res.items():
+        assert not np.isnan(a).any() and not np.isnan(b).any(), path
+        assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), path
+        fa = np.isfinite(a64); fb = np.isfinite(b64)
+        np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T)
+        np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T)
+        fl = np.isfinite(b64[:, 0, 0])
+        np.testing.assert_allclose(ls[fl], b64[fl, 0, 0], rtol=3e-6, atol=2e-5 * T)
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 2048, 2047), (32, 100, 400, 399)])
+def test_dense_window_full_size_c1_and_readme_shape(shape):
+    """BASELINE configs[0] (C1: B=4, T=256, L=2048, dense window) and the README's training shape (B=32, T=100, L=400,
+    --max-transition-length 99999) at FULL size on the HIP ops: loss = beta[0,0] = alpha[T_b-1, L_b-1], the matrix-core DP and the
+    log-space DP agree, gradients are a distribution over the alignment (sum_j grad_match[t, j] = d loss for every t), the Viterbi
+    path is a valid monotone alignment and scores no more than the marginal."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(3 + L, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_(); k.requires_grad_()
+    loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    assert _lib.last_launch_status() == 0 and torch.isfinite(loss).all()
+    ar = torch.arange(B, device=m.device)
+    torch.testing.assert_close(alpha[ar, t - 1, o - 1], loss, rtol=3e-6, atol=2e-5 * T)
+    try:
+        _lib.set_option("dp_path", 1)
+        loss_l, (alpha_l, beta_l) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    finally:
+        _lib.set_option("dp_path", 0)
+    assert torch.equal(torch.isneginf(alpha), torch.isneginf(alpha_l)) and torch.equal(torch.isneginf(beta), torch.isneginf(beta_l))
+    fa = torch.isfinite(alpha_l); fb = torch.isfinite(beta_l)
+    torch.testing.assert_close(alpha[fa], alpha_l[fa], rtol=6e-6, atol=4e-5 * T)
+    torch.testing.assert_close(beta[fb], beta_l[fb], rtol=6e-6, atol=4e-5 * T)
+    gm, gk = torch.autograd.grad(loss.sum(), [m, k])
+    assert torch.isfinite(gm).all() and torch.isfinite(gk).all()
+    rows = gm.sum(-1)                                          # [B, T]: 1 on rows < T_b, 0 beyond
+    want = (torch.arange(T, device=m.device).unsqueeze(0) < t.unsqueeze(1)).float()
+    torch.testing.assert_close(rows, want, rtol=0, atol=2e-3)
+    path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+    for b in range(B):
+        pos = np.nonzero(path[b] >= 0)[0]
+        Tb, Lb = int(tl[b]), int(ol[b])
+        assert len(pos) == Tb and pos[0] == 0 and pos[-1] == Lb - 1 and np.array_equal(path[b][pos], np.arange(Tb))
+        score = match[b, np.arange(Tb), pos].sum() + sum(links[b, pos[i], pos[i + 1] - pos[i] - 1] for i in range(Tb - 1))
+        assert score <= float(loss[b]) + 1e-3 * abs(float(loss[b]))

@@ -1,0 +1,34 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from daspeech_amd import _lib
+B, T, L = 4, 256, 2048; TR = L - 1
+g = torch.Generator(device="cuda").manual_seed(0)
+match = torch.randn(B, T, L, device="cuda", generator=g) * 2 - 6
+ol = torch.full((B,), L, device="cuda"); tl = torch.full((B,), T, device="cuda")
+raw = torch.randn(B, L, TR, device="cuda", generator=g)
+i = torch.arange(L, device="cuda").view(1, L, 1); d = torch.arange(TR, device="cuda").view(1, 1, TR)
+valid = (i + d + 1) < ol.view(-1, 1, 1)
+links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1).masked_fill(~valid, float("-inf"))
+lib = _lib.load(); st = _lib.current_stream_handle()
+alpha = torch.empty_like(match)
+_lib.set_option("dp_path", 9); _lib.set_option("dm_mt", 1)
+assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), None, None, B, T, L, TR, None, 0, st) == 0
+import time
+for mt, ng in ((1, 1), (1, 2), (2, 1)):
+    _lib.set_option("dm_mt", mt); _lib.set_option("dm_ng", ng)
+    beta = torch.empty_like(match)
+    for _ in range(2):
+        assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), None, B, T, L, TR, None, 0, st) == 0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), None, B, T, L, TR, None, 0, st) == 0
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    _lib.last_launch_status(); w = lib.dsp_dag_debug_words()
+    print(f"mt={mt} ng={ng}: wall {dt*1e3:.3f} ms; last block of sd 0: ready-wait {w[39]*16/2.4e3:.1f} us, gemm {w[40]*16/2.4e3:.1f} us, diag {w[41]*16/2.4e3:.1f} us (at 2.4 GHz), chunks {w[42]}")
+_lib.set_option("dm_mt", 1)
+print("status", _lib.last_launch_status(), "exact cells", _lib.last_fallback_count())
+print(_lib.debug_fallback_cells())
+a = alpha[0].cpu()
+for (b, t, j, P) in _lib.debug_fallback_cells()[:6]:
+    b &= 0xff
+    print("cell", b, t, j, "P", P, "prev row around diag:", alpha[b, t - 1, max(0, j - 12): j + 4].cpu().tolist())
