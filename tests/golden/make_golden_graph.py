@@ -24,10 +24,15 @@ import random
 import types
 from typing import List  # noqa: F401  (used by the lifted _collate_frames)
 
+import sys
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tests.util_inputs import seeded_weights  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
@@ -107,6 +112,35 @@ def links_golden():
                       f"{tag}_links": links.numpy(), f"{tag}_dense": dense.numpy()})
         print("links", tag, tuple(links.shape), "finite", int(torch.isfinite(links).sum()))
     np.savez_compressed(os.path.join(HERE, "graph_links.npz"), **store)
+    # released head geometry (8 heads x 32 / 64 channels: what the fused HIP kernel serves); weights rebuilt from a seed by the tests
+    store = {}
+    for tag, (B, L, heads, dim, TR, seed) in {"h32": (2, 48, 8, 256, 20, 901), "h64": (2, 40, 8, 512, 99999, 902)}.items():
+        s = make_self(TR, heads, dim)
+        shapes = {"pos.weight": (L + 2, dim), "q.weight": (dim, 2 * dim), "q.bias": (dim,), "k.weight": (dim, 2 * dim), "k.bias": (dim,),
+                  "g.weight": (heads, 2 * dim), "g.bias": (heads,)}
+        w = {k: torch.from_numpy(v) for k, v in seeded_weights(shapes, seed, gain=2.0).items()}
+        w["pos.weight"] = w["pos.weight"] * 4.0
+        w["pos.weight"][PAD] = 0
+        lp = nn.Embedding(L + 2, dim, padding_idx=PAD); ql, kl, gl = nn.Linear(2 * dim, dim), nn.Linear(2 * dim, dim), nn.Linear(2 * dim, heads)
+        with torch.no_grad():
+            lp.weight.copy_(w["pos.weight"]); ql.weight.copy_(w["q.weight"]); ql.bias.copy_(w["q.bias"]); kl.weight.copy_(w["k.weight"])
+            kl.bias.copy_(w["k.bias"]); gl.weight.copy_(w["g.weight"]); gl.bias.copy_(w["g.bias"])
+        feats = torch.from_numpy(rng.standard_normal((B, L, dim)).astype(np.float32))
+        lens = torch.tensor([L, L - 7])
+        prev = torch.full((B, L), 3, dtype=torch.long)
+        prev[torch.arange(L).unsqueeze(0) >= lens.unsqueeze(1)] = PAD
+
+        class LinkPos2(nn.Module):
+            def forward(self, toks):
+                keep = toks.ne(PAD).int()
+                return lp((torch.cumsum(keep, 1) * keep).long() + PAD)
+        with torch.no_grad():
+            links = s.extract_links(feats, prev, LinkPos2(), ql, kl, gl)
+        store.update({f"{tag}_feats": feats.numpy(), f"{tag}_prev": prev.numpy(), f"{tag}_seed": np.int64(seed), f"{tag}_heads": np.int64(heads),
+                      f"{tag}_max_transition_length": np.int64(TR), f"{tag}_links": links.numpy()})
+        fin = links[torch.isfinite(links)]
+        print("links", tag, tuple(links.shape), "finite", int(torch.isfinite(links).sum()), "range", float(fin.min()), float(fin.max()))
+    np.savez_compressed(os.path.join(HERE, "graph_links_released_heads.npz"), **store)
 
 
 def make_links(rng, B, L, TR, lens):

@@ -78,28 +78,61 @@ def test_product_torch_extract_links_vs_reference(golden_dir, tag):
     assert_links_close(links.numpy(), g[f"{tag}_links"])
 
 
+def _released_heads_case(g, tag):
+    """graph_links_released_heads.npz: 8 heads x 32 / 64 channels, weights rebuilt from the seed (tests/util_inputs.seeded_weights)."""
+    from tests.util_inputs import seeded_weights
+    feats, prev = g[f"{tag}_feats"], g[f"{tag}_prev"]
+    L, dim = feats.shape[1:]
+    heads = int(g[f"{tag}_heads"])
+    shapes = {"pos.weight": (L + 2, dim), "q.weight": (dim, 2 * dim), "q.bias": (dim,), "k.weight": (dim, 2 * dim), "k.bias": (dim,),
+              "g.weight": (heads, 2 * dim), "g.bias": (heads,)}
+    w = seeded_weights(shapes, int(g[f"{tag}_seed"]), gain=2.0)
+    w["pos.weight"] = w["pos.weight"] * np.float32(4.0)
+    w["pos.weight"][PAD] = 0
+    return feats, prev, w, heads, int(g[f"{tag}_max_transition_length"])
+
+
+@pytest.mark.parametrize("tag", ["h32", "h64"])
+def test_oracle_extract_links_vs_reference_released_heads(golden_dir, tag):
+    g = load(golden_dir, "graph_links_released_heads")
+    feats, prev, w, heads, mtl = _released_heads_case(g, tag)
+    links = gorc.extract_links(feats, prev, w["pos.weight"], w["q.weight"], w["q.bias"], w["k.weight"], w["k.bias"], w["g.weight"], w["g.bias"],
+                               mtl, heads, PAD)
+    assert_links_close(links, g[f"{tag}_links"], atol=5e-5)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["band", "wide"])
+@pytest.mark.parametrize("tag", ["h32", "h64"])
 def test_hip_extract_links_vs_reference_and_oracle(golden_dir, tag):
-    """dsp_extract_links (fused, band only) against the reference-produced links AND the oracle restatement."""
+    """dsp_extract_links (fused, band only; head widths 32 / 64 / 128) against links the REFERENCE's extract_links produced for the same
+    seeded weights, directly and through the model's dispatch, and against the oracle restatement."""
     from daspeech_amd import decode_ops
-    g = load(golden_dir, "graph_links")
-    dec = decoder_from_golden(g, tag, "cuda")
-    feats, prev = torch.from_numpy(g[f"{tag}_feats"]).cuda(), torch.from_numpy(g[f"{tag}_prev"]).cuda()
-    B, L, d = feats.shape
-    h = int(g[f"{tag}_heads"])
+    from daspeech_amd.models.daspeech import DAGDecoder, DEFAULT_ARGS
+    g = load(golden_dir, "graph_links_released_heads")
+    feats_np, prev_np, w, h, mtl = _released_heads_case(g, tag)
+    B, L, d = feats_np.shape
+    a = SimpleNamespace(**{**DEFAULT_ARGS, "decoder_embed_dim": d, "decoder_attention_heads": h, "decoder_layers": 0, "vocab_size": 8,
+                           "max_target_positions": L, "max_transition_length": mtl})
+    dec = DAGDecoder(a)
+    with torch.no_grad():
+        dec.link_positional.weight.copy_(torch.from_numpy(w["pos.weight"]))
+        for m, n in ((dec.query_linear, "q"), (dec.key_linear, "k"), (dec.gate_linear, "g")):
+            m.weight.copy_(torch.from_numpy(w[f"{n}.weight"])); m.bias.copy_(torch.from_numpy(w[f"{n}.bias"]))
+    dec = dec.cuda().eval()
+    feats, prev = torch.from_numpy(feats_np).cuda(), torch.from_numpy(prev_np).cuda()
     with torch.no_grad():
         fp = torch.cat([feats, dec.link_positional(dec.positions(prev))], -1)
         q = dec.query_linear(fp).view(B, L, h, d // h); k = dec.key_linear(fp).view(B, L, h, d // h)
         lg = torch.log_softmax(dec.gate_linear(fp), -1, dtype=torch.float)
-        TR = min(int(g[f"{tag}_max_transition_length"]), L - 1)
+        TR = min(mtl, L - 1)
         got = decode_ops.extract_links(q, k, lg, prev.ne(PAD).sum(-1), TR)              # the HIP kernel itself
+        assert dec.fused_links
         via_model = dec.extract_links(feats, prev)                                       # and through the model's dispatch
-    assert_links_close(got.cpu().numpy(), g[f"{tag}_links"])
-    assert_links_close(via_model.cpu().numpy(), g[f"{tag}_links"])
-    want = gorc.extract_links(g[f"{tag}_feats"], g[f"{tag}_prev"], g[f"{tag}_pos_w"], g[f"{tag}_q_w"], g[f"{tag}_q_b"], g[f"{tag}_k_w"],
-                              g[f"{tag}_k_b"], g[f"{tag}_g_w"], g[f"{tag}_g_b"], int(g[f"{tag}_max_transition_length"]), h, PAD)
-    assert_links_close(got.cpu().numpy(), want)
+    assert_links_close(got.cpu().numpy(), g[f"{tag}_links"], atol=5e-5)
+    assert_links_close(via_model.cpu().numpy(), g[f"{tag}_links"], atol=5e-5)
+    want = gorc.extract_links(feats_np, prev_np, w["pos.weight"], w["q.weight"], w["q.bias"], w["k.weight"], w["k.bias"], w["g.weight"], w["g.bias"],
+                              mtl, h, PAD)
+    assert_links_close(got.cpu().numpy(), want, atol=5e-5)
 
 
 @pytest.mark.gpu
