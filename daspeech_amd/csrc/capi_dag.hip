@@ -10,6 +10,9 @@ int launch_dag_bwd_generic(const float*, const float*, const float*, const float
                            float*, float*, int, int, int, int, hipStream_t);
 
 bool banded_supported(int L, int TR);
+void caller_ws_begin(void* p, size_t n);
+void caller_ws_end();
+struct CallerWsScope { CallerWsScope(void* p, size_t n) { caller_ws_begin(p, n); } ~CallerWsScope() { caller_ws_end(); } };
 void set_k5_path(int v);
 int k5_diag(unsigned int* out);
 int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
@@ -56,13 +59,47 @@ static int check_dims(const char* fn, int B, int T, int L, int TR) {
 
 using namespace dsp;
 
-extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR) { (void)B; (void)T; (void)L; (void)TR; return 0; }
+// Scratch a forward launch takes from the caller (mirrors the launchers' own sizing; a launcher that finds the workspace too small
+// falls back to the library's scratch, so an under-estimate costs a hipMalloc, not correctness).
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
+{
+    if (B <= 0 || T <= 0 || L <= 0 || TR <= 0) return 0;
+    size_t halo;
+    if (TR <= 32 && !(L & 3)) {                       // strip4g: 1024-column strips when they still fill the chip, else 512
+        const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
+        const long NS = (2L * B * ns1024 >= 200) ? ns1024 : ns512;
+        halo = (size_t)2 * B * NS * T * 32 * 8;
+    } else if (TR <= 64) {                            // banded 2-column strips of 512
+        halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
+    } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
+        const size_t NJ = (size_t)(L + 63) / 64;
+        halo = align256((size_t)2 * B * NJ * 4) + (size_t)2 * B * T * NJ * 8;
+    }
+    return align256(256 + halo) + 512;
+}
+
+// ... and the alignment (dsp_dag_best_alignment_ws): the value-only strip DP's hand-off rows, or for dense windows the re-laid-out
+// ("incoming") copy of the transition matrix plus the row hand-off of the log-space max-DP.
+extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
+{
+    if (B <= 0 || T <= 0 || L <= 0 || TR <= 0) return 0;
+    if (TR <= 32) {
+        const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
+        const long NS = ((long)B * ns1024 >= 200) ? ns1024 : ns512;
+        const size_t strip = (size_t)B * ((L + 383) / 384) * T * 32 * 8;              // strip2 (with a trace buffer): 384-column strips
+        const size_t mx = (size_t)B * NS * T * 32 * 8;
+        return align256(256 + (strip > mx ? strip : mx)) + 512;
+    }
+    if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
+    return align256((size_t)B * L * TR * 4) + align256(256 + (size_t)B * 2 * L * 8) + 1024;
+}
 
 extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                                 float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
                                 void* workspace, size_t workspace_bytes, dsp_stream_t stream)
 {
-    (void)workspace; (void)workspace_bytes;
+    CallerWsScope ws_scope(workspace, workspace_bytes);
     int rc = check_dims("dag_loss_fwd", B, T, L, TR);
     if (rc) return rc;
     if (B == 0) return DSP_OK;
@@ -99,9 +136,26 @@ extern "C" int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const
     return launch_dag_bwd_generic(grad_out, alpha, beta, match, links, out_len, tgt_len, grad_match, grad_links, B, T, L, TR, as_stream(stream));
 }
 
+static int best_alignment_impl(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream);
+
 extern "C" int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                                       float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                                       dsp_stream_t stream)
+{
+    return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);      // library scratch
+}
+
+extern "C" int dsp_dag_best_alignment_ws(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                         float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                                         void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    CallerWsScope ws_scope(workspace, workspace_bytes);
+    return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);
+}
+
+static int best_alignment_impl(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream)
 {
     int rc = check_dims("dag_best_alignment", B, T, L, TR);
     if (rc) return rc;

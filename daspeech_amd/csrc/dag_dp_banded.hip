@@ -254,21 +254,40 @@ __global__ __launch_bounds__(ST_THREADS) void dag_strip_kernel(StripParams p)
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct BandedWS { void* base = nullptr; size_t bytes = 0; u32 tag_base = 0; };
+// ---- scratch memory of the DP launches --------------------------------------------------------------------------------------
+// 1) CALLER workspace (the `workspace` / `workspace_bytes` arguments of the C ABI, sized by dsp_dag_workspace_bytes /
+//    dsp_dag_alignment_workspace_bytes): the entry point opens it for the calling thread (caller_ws_begin), the launchers carve what
+//    they need out of it (caller_ws_take).  It is zeroed by a hipMemsetAsync ON THE LAUNCH STREAM and the hand-off tags start at 1, so
+//    a launch holds no host-side state: the memory belongs to the caller's allocator and the memset + kernel pair is hipGraph-capturable.
+// 2) LIBRARY scratch (workspace == NULL or too small): a grow-only per-(device, stream) hipMalloc buffer with monotonically increasing
+//    tag epochs (never re-zeroed between launches; a regrow hipFrees, i.e. synchronises) — kept for callers that pass no workspace.
+struct CallerWS { char* base; size_t bytes; size_t used; };
+static thread_local CallerWS t_cws = {nullptr, 0, 0};
+void caller_ws_begin(void* p, size_t n) { t_cws.base = (char*)p; t_cws.bytes = p ? n : 0; t_cws.used = 0; }
+void caller_ws_end() { t_cws.base = nullptr; t_cws.bytes = 0; t_cws.used = 0; }
+void* caller_ws_take(size_t n)
+{
+    n = (n + 255) & ~(size_t)255;
+    const size_t off = (256 - ((uintptr_t)(t_cws.base + t_cws.used) & 255)) & 255;          // 256-byte aligned pieces
+    if (!t_cws.base || t_cws.used + off + n > t_cws.bytes) return nullptr;
+    void* r = t_cws.base + t_cws.used + off;
+    t_cws.used += off + n;
+    return r;
+}
+
+struct BandedWS { void* base = nullptr; size_t bytes = 0; u32 tag_base = 0; void* last_status = nullptr; };
 static std::mutex g_ws_mutex;
 static std::unordered_map<u64, BandedWS> g_ws;       // key: (device << 48) ^ stream
 
+static u64 ws_key(hipStream_t st) { int devid = 0; (void)hipGetDevice(&devid); return ((u64)devid << 48) ^ (u64)(uintptr_t)st; }
+
 static int get_ws(hipStream_t st, size_t need, BandedWS** out)
 {
-    int devid = 0;
-    hipError_t e = hipGetDevice(&devid);
-    if (e != hipSuccess) { set_error("hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
-    const u64 key = ((u64)devid << 48) ^ (u64)(uintptr_t)st;
-    BandedWS& w = g_ws[key];
+    BandedWS& w = g_ws[ws_key(st)];
     if (w.bytes < need) {
         if (w.base) (void)hipFree(w.base);
         w.base = nullptr; w.bytes = 0;
-        e = hipMalloc(&w.base, need);
+        hipError_t e = hipMalloc(&w.base, need);
         if (e != hipSuccess) { set_error("dag banded workspace: hipMalloc(%zu): %s", need, hipGetErrorString(e)); return (int)e; }
         w.bytes = need; w.tag_base = 0;
         e = hipMemsetAsync(w.base, 0, need, st);
@@ -280,12 +299,22 @@ static int get_ws(hipStream_t st, size_t need, BandedWS** out)
 
 bool banded_supported(int L, int TR) { (void)L; return TR <= 64; }
 
-// Shared by dag_dp_banded.hip and dag_dp_strip4.hip: per-(device, stream) workspace with monotonically increasing tag
-// epochs, so the halo granules never need re-zeroing between launches.  Caller holds no lock; this function locks.
+// Shared by every DP launcher that hands rows between workgroups: 256 bytes of counters (ticket, status word, fallback counters,
+// debug slots) + `halo_bytes` of tagged granules / progress words.
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base)
 {
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
     const size_t need = 256 + halo_bytes;
+    if (void* c = caller_ws_take(need)) {
+        hipError_t e = hipMemsetAsync(c, 0, need, st);               // stream-ordered, capturable; tags of this launch start at 1
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        *counters = reinterpret_cast<u32*>(c);
+        *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(c) + 256);
+        *tag_base = 0;
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        g_ws[ws_key(st)].last_status = c;
+        return DSP_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     BandedWS* ws = nullptr;
     int rc = get_ws(st, need, &ws);
     if (rc) return rc;
@@ -300,6 +329,7 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
     *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws->base) + 256);
     *tag_base = ws->tag_base;
     ws->tag_base += (u32)T + 1u;
+    ws->last_status = ws->base;
     return DSP_OK;
 }
 
@@ -328,15 +358,14 @@ int launch_dag_banded(int mode, const float* match, const float* links, const in
     return check_launch(mode == 0 ? "dag_loss_fwd(banded)" : "dag_best_alignment(banded)");
 }
 
-// error word of the most recent banded launch on this stream (host-synchronising; used by tests / debugging only)
+// error word of the most recent DP launch on this stream (host-synchronising; used by tests / debugging only).  With a caller
+// workspace the words live in the caller's memory: valid as long as the caller has not recycled it.
 int banded_last_error_word(hipStream_t st, u32* word)
 {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    int devid = 0; (void)hipGetDevice(&devid);
-    const u64 key = ((u64)devid << 48) ^ (u64)(uintptr_t)st;
-    auto it = g_ws.find(key);
-    if (it == g_ws.end() || !it->second.base) { *word = 0; return DSP_OK; }
-    hipError_t e = hipMemcpyAsync(word, reinterpret_cast<char*>(it->second.base) + 4, 252, hipMemcpyDeviceToHost, st);
+    auto it = g_ws.find(ws_key(st));
+    if (it == g_ws.end() || !it->second.last_status) { *word = 0; return DSP_OK; }
+    hipError_t e = hipMemcpyAsync(word, reinterpret_cast<char*>(it->second.last_status) + 4, 252, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("banded_last_error_word: %s", hipGetErrorString(e)); return (int)e; }
     return DSP_OK;

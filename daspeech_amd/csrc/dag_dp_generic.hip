@@ -211,10 +211,17 @@ __global__ __launch_bounds__(256) void dag_transpose_links_kernel(const float* _
 static std::mutex g_et_mutex;
 static std::unordered_map<unsigned long long, std::pair<void*, size_t>> g_et;
 
+void* caller_ws_take(size_t n);
+
 static const float* transposed_links(const float* links, int B, int L, int TR, hipStream_t st, long* sR, long* sD, long* sB)
 {
     *sR = TR; *sD = 1; *sB = (long)L * TR;
     if (TR <= 64) return links;                         // short windows: the original layout is fine
+    if (void* c = caller_ws_take((size_t)B * L * TR * sizeof(float))) {          // caller workspace first (capi: dsp_dag_*_workspace_bytes)
+        hipLaunchKernelGGL(dag_transpose_links_kernel, dim3((TR + 31) / 32, (L + 31) / 32, B), dim3(256), 0, st, links, (float*)c, L, TR);
+        *sR = 1; *sD = L;
+        return (const float*)c;
+    }
     std::lock_guard<std::mutex> lock(g_et_mutex);
     int dev = 0; (void)hipGetDevice(&dev);
     const unsigned long long key = ((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st;
@@ -410,6 +417,11 @@ static std::unordered_map<unsigned long long, std::pair<void*, size_t>> g_in;
 
 static const float* incoming_links(const float* links, int B, int L, int TR, hipStream_t st)
 {
+    int gx0 = (TR + 255) / 256; if (gx0 > 8) gx0 = 8;
+    if (void* c = caller_ws_take((size_t)B * L * TR * sizeof(float))) {
+        hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx0, L, B), dim3(256), 0, st, links, (float*)c, L, TR);
+        return (const float*)c;
+    }
     std::lock_guard<std::mutex> lock(g_in_mutex);
     int dev = 0; (void)hipGetDevice(&dev);
     const unsigned long long key = ((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st;

@@ -67,6 +67,20 @@ def _f32c(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+# Scratch of the DP launches comes from torch's allocator (one grow-only tensor per device and stream, like the reference's per-call
+# ATen scratch, dag_loss.cu:154): the C ABI zeroes what it uses on the launch stream, so nothing is allocated, freed or kept by the
+# library and the launches are graph-capturable.
+_WS = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> Tensor:
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):
     dev = _require_gpu("dag_loss", match_all, links, output_length, target_length)
     B, T, L, TR = _check_dp_args("dag_loss", match_all, links, output_length, target_length)
@@ -80,9 +94,9 @@ def _dag_forward(match_all, links, output_length, target_length, need_beta: bool
         beta = torch.empty((B, T, L), dtype=torch.float32, device=dev) if need_beta else None
         loss = torch.empty((B,), dtype=torch.float32, device=dev)
         wsz = lib.dsp_dag_workspace_bytes(B, T, L, TR)
-        ws = torch.empty((wsz,), dtype=torch.uint8, device=dev) if wsz else None
+        ws = _workspace(dev, wsz)
         rc = lib.dsp_dag_loss_fwd(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta),
-                                  _lib.ptr(loss), B, T, L, TR, _lib.ptr(ws), wsz, _lib.current_stream_handle())
+                                  _lib.ptr(loss), B, T, L, TR, _lib.ptr(ws), ws.numel(), _lib.current_stream_handle())
         _lib.check(rc, "dsp_dag_loss_fwd")
     return m, k, ol, tl, alpha, beta, loss
 
@@ -96,8 +110,7 @@ def _dag_backward(grad_output, alpha, beta, m, k, ol, tl, need_match: bool, need
         go = grad_output.detach().to(torch.float32).contiguous()
         gm = torch.empty_like(m) if need_match else None
         gl = torch.empty_like(k) if need_links else None
-        wsz = lib.dsp_dag_workspace_bytes(B, T, L, TR)
-        ws = torch.empty((wsz,), dtype=torch.uint8, device=dev) if wsz else None
+        wsz, ws = 0, None                       # the gradient kernels keep no scratch
         rc = lib.dsp_dag_loss_bwd(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(m), _lib.ptr(k), _lib.ptr(ol),
                                   _lib.ptr(tl), _lib.ptr(gm), _lib.ptr(gl), B, T, L, TR, _lib.ptr(ws), wsz,
                                   _lib.current_stream_handle())
@@ -185,9 +198,11 @@ class DagBestAlignmentFunc(Function):
             lazy_ok = lib.dsp_dag_alignment_trace_optional(L, TR) and m.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0
             trace = None if lazy_ok else torch.empty((B, T, L), dtype=torch.int32, device=dev)
             path = torch.empty((B, L), dtype=torch.long, device=dev)
-            rc = lib.dsp_dag_best_alignment(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
-                                            _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.current_stream_handle())
-            _lib.check(rc, "dsp_dag_best_alignment")
+            ws = _workspace(dev, lib.dsp_dag_alignment_workspace_bytes(B, T, L, TR))
+            rc = lib.dsp_dag_best_alignment_ws(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
+                                               _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream_handle())
+            _lib.check(rc, "dsp_dag_best_alignment_ws")
         ctx.mark_non_differentiable(path)
         return path
 

@@ -84,7 +84,10 @@ int dsp_logsoftmax_gather_bwd_lazy(void* logits_inout, int dtype,
  *   alpha [B,T,L] fp32 out; beta [B,T,L] fp32 out or NULL (= the reference's require_gradient=false).
  *   loss  [B] fp32 out or NULL: beta[b,0,0] when beta != NULL else alpha[b,T_b-1,L_b-1] (dag_loss.py:107-110).
  *   Cells the recurrence never reaches are -inf.  Unreachable ends give loss = -inf (no device assert).
- *   workspace: dsp_dag_workspace_bytes(B,T,L,TR) bytes of device scratch (may be 0 -> pass NULL). */
+ *   workspace: dsp_dag_workspace_bytes(B,T,L,TR) bytes of device scratch owned by the CALLER (the reference allocates its scratch
+ *   per call with ATen, dag_loss.cu:154,339-340).  It is zeroed on `stream` by the call itself and nothing about it outlives the call
+ *   except the status words read by dsp_dag_last_launch_status — so the launch (memset + kernels) can be captured in a hipGraph.
+ *   workspace == NULL (or too small) selects a library-owned grow-only buffer per (device, stream) instead: not capturable. */
 size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR);
 int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                      float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
@@ -107,6 +110,11 @@ int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* bet
 int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                            float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                            dsp_stream_t stream);
+/* The same with caller-owned scratch (dsp_dag_alignment_workspace_bytes bytes; semantics as for dsp_dag_loss_fwd's workspace). */
+size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR);
+int dsp_dag_best_alignment_ws(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                              float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                              void* workspace, size_t workspace_bytes, dsp_stream_t stream);
 
 /* The two halves of the alignment, separately — what the Viterbi graph decode needs
  * (s2s_conformer_dag_fastspeech2.py:244-304: max-product steps over the links, THEN the length is chosen, THEN the back-trace):
@@ -123,10 +131,11 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
 
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart).
- *   dsp_dag_set_option("dp_path", n) pins the DP kernel family: 0 = auto, 1 = generic row-sequential, 2 = banded
- *   2-column log-space strips, 3 = strip4 (exp-space, per-vertex exponents), 4 = strip2 (2 vertices per lane), 5 = strip4g
- *   (exp-space, one exponent per lane group; the auto choice for the log-sum DP), 6 = strip4h (strip4g with two compute
- *   waves per SIMD), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment); used by tests to cross-check the families.
+ *   dsp_dag_set_option("dp_path", n) pins the DP kernel family FOR THE CALLING THREAD: 0 = auto, 1 = generic row-sequential /
+ *   log-space dense, 2 = banded 2-column log-space strips, 4 = strip2 (2 vertices per lane), 5 = strip4g (exp-space, one exponent per
+ *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment), 8 = strip5
+ *   (experimental), 9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
+ *   cross-check the families.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);

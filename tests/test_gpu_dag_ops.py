@@ -555,3 +555,64 @@ def test_dense_window_full_size_c1_and_readme_shape(shape):
         assert len(pos) == Tb and pos[0] == 0 and pos[-1] == Lb - 1 and np.array_equal(path[b][pos], np.arange(Tb))
         score = match[b, np.arange(Tb), pos].sum() + sum(links[b, pos[i], pos[i + 1] - pos[i] - 1] for i in range(Tb - 1))
         assert score <= float(loss[b]) + 1e-3 * abs(float(loss[b]))
+
+
+def test_workspace_sizes_are_reported_and_library_scratch_still_works():
+    """The ABI is honest about memory: dsp_dag_workspace_bytes / dsp_dag_alignment_workspace_bytes are non-zero, the Python operators
+    pass a torch-allocated workspace, and a caller that passes NULL still gets correct results from the library's own scratch."""
+    from daspeech_amd import _lib
+    lib = _lib.load()
+    assert lib.dsp_dag_workspace_bytes(32, 512, 4096, 32) >= 2 * 32 * 4 * 512 * 32 * 8
+    assert lib.dsp_dag_workspace_bytes(4, 256, 2048, 2047) > 0 and lib.dsp_dag_alignment_workspace_bytes(32, 512, 4096, 32) > 0
+    B, T, L, TR = 3, 20, 1024, 32
+    match, links, ol, tl = make_dag_inputs(31, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    st = _lib.current_stream_handle()
+    res = []
+    for use_ws in (True, False):
+        alpha = torch.empty((B, T, L), device="cuda"); beta = torch.empty_like(alpha); loss = torch.empty(B, device="cuda")
+        n = lib.dsp_dag_workspace_bytes(B, T, L, TR)
+        ws = torch.empty(n, dtype=torch.uint8, device="cuda").fill_(0xAB) if use_ws else None           # garbage in: the call zeroes what it uses
+        _lib.check(lib.dsp_dag_loss_fwd(_lib.ptr(m), _lib.ptr(k), _lib.ptr(o), _lib.ptr(t), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(loss),
+                                        B, T, L, TR, _lib.ptr(ws), n if use_ws else 0, st), "fwd")
+        assert _lib.last_launch_status() == 0
+        res.append((alpha.clone(), beta.clone(), loss.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("shape", [(4, 20, 512, 32), (3, 24, 200, 199)])
+def test_dag_ops_are_graph_capturable(shape):
+    """dag_loss forward + backward and dag_best_alignment captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on new inputs:
+    the launches keep no host-side state (caller workspace zeroed on the stream, tags start at 1), so the replay must give what eager
+    execution gives."""
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(41 + L, B, T, L, TR)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    sm = m.clone().requires_grad_(); sk = k.clone().requires_grad_()
+
+    def step():
+        loss = ops().dag_loss(sm, sk, o, t)
+        gm, gk = torch.autograd.grad(loss.sum(), [sm, sk])
+        with torch.no_grad():
+            path = ops().dag_best_alignment(sm.detach(), sk.detach(), o, t)
+        return loss.detach(), gm, gk, path
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()                                 # warm-up on the capture stream: workspaces, function attributes
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    match2, links2, _, _ = make_dag_inputs(77 + L, B, T, L, TR)
+    links2 = np.where(np.isfinite(links), links2, -np.inf).astype(np.float32)                 # same validity pattern as lengths o / t
+    with torch.no_grad():
+        sm.copy_(torch.from_numpy(match2)); sk.copy_(torch.from_numpy(links2))
+    g.replay()
+    torch.cuda.synchronize()
+    got = [x.clone() for x in out]
+    want = step()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -179,3 +179,66 @@ def test_split_gemm_inference_matches_torch_fp32_within_mel_tolerance():
         assert torch.equal(x["tokens"], y["tokens"]) and x["feature"].shape == y["feature"].shape
         scale = y["feature"].abs().max().item()
         assert (x["feature"] - y["feature"]).abs().max().item() <= 1e-4 * scale, ((x["feature"] - y["feature"]).abs().max().item(), scale)
+
+
+def _released_model(kind):
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model, S2TConformerDAGModel
+    from daspeech_amd.synthetic import calibrate_synthetic_weights
+    torch.manual_seed(1234)
+    return calibrate_synthetic_weights(S2TConformerDAGModel() if kind == "s2tt" else S2SConformerDAGFastSpeech2Model()).cuda().eval()
+
+
+@pytest.mark.parametrize("strategy", ["lookahead", "jointviterbi"])
+def test_c3_s2tt_full_size_properties(strategy):
+    """BASELINE configs[2] at its workload size: S2TT Conformer-DAG full forward, batch 64, released depth (12 + 4 layers), synthetic
+    fr-en fbank80 of 300-800 frames.  Size-independent properties: every output token is a vocabulary id, no <pad> inside a
+    sequence, no immediate repeats (the decode collapses them), lengths consistent with the padding, graph sizes = 0.5 x frames."""
+    from daspeech_amd.synthetic import make_s2st_batch
+    m = _released_model("s2tt")
+    m.args.decode_strategy = strategy
+    s = make_s2st_batch(64, "cuda", seed=11)
+    ni = s["net_input"]
+    with torch.no_grad():
+        enc = m.forward_encoder(ni["src_tokens"], ni["src_lengths"])
+        prev = m.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
+        dec = m.forward_decoder(prev, enc)
+    assert prev.ne(m.pad).sum(-1).tolist() == (ni["src_lengths"].float() * 0.5).long().clamp(2, 1024).tolist()
+    toks, lens = dec["output_tokens"], dec["feature_lengths"]
+    assert toks.shape[0] == 64 and (toks >= 0).all() and (toks < m.args.vocab_size).all()
+    nt = lens + (1 if strategy == "lookahead" else 0)                # lookahead keeps <bos> in the token row, its features exclude it
+    for b in range(64):
+        row = toks[b, : int(nt[b])]
+        assert (row != m.pad).all() and (toks[b, int(nt[b]):] == m.pad).all()
+        assert (row[1:] != row[:-1]).all()
+    assert dec["features"].shape[:2] == (64, int(lens.max())) and torch.isfinite(dec["features"]).all()
+    assert torch.equal(dec["features_padding_mask"], torch.arange(int(lens.max()), device="cuda").unsqueeze(0) >= lens.unsqueeze(1))
+
+
+def test_c4_s2st_full_size_properties():
+    """BASELINE configs[3] at its workload size: the full S2ST pipeline (s2s_conformer_dag_fastspeech2 + HiFi-GAN V1, HIP vocoder),
+    lookahead decode, batch 32, released depth.  Properties: mel length = sum of the predicted durations, waveform length =
+    256 x mel frames, finite values in (-1, 1), and every utterance's waveform equals vocoding its own mel alone."""
+    from daspeech_amd.generator import S2SNATGenerator
+    from daspeech_amd.models import HiFiGANGenerator
+    from daspeech_amd.synthetic import make_s2st_batch
+    m = _released_model("s2st")
+    voc = HiFiGANGenerator(conv_backend="hip").cuda().eval()
+    gen = S2SNATGenerator(voc, torch.zeros(80, device="cuda"), torch.ones(80, device="cuda"), vocoder_group=8)
+    s = make_s2st_batch(32, "cuda", seed=12)
+    out = gen.generate(m, s)
+    assert len(out) == 32
+    ni = s["net_input"]
+    with torch.no_grad():                       # the durations the pipeline used, recomputed through the same modules
+        enc = m.forward_encoder(ni["src_tokens"], ni["src_lengths"])
+        prev = m.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
+        dec = m.forward_decoder(prev, enc)
+        _, out_lens, log_dur, _, _ = m.tts(m.adaptor(dec["features"]), dec["features_padding_mask"])
+        dur = torch.clamp(torch.round(torch.exp(log_dur) - 1).long(), min=0).masked_fill(dec["features_padding_mask"], 0)
+    assert out_lens.tolist() == dur.sum(1).tolist()
+    for b, o in enumerate(out):
+        n = int(out_lens[b])
+        assert o["feature"].shape == (max(n, 1), 80) and torch.isfinite(o["feature"]).all()
+        assert o["waveform"].shape[0] == max(n, 1) * 256 and torch.isfinite(o["waveform"]).all() and o["waveform"].abs().max() <= 1.0
+    for b in (0, 7, 31):
+        alone = voc(out[b]["feature"].t().unsqueeze(0).contiguous())[0, 0]
+        assert torch.equal(alone, out[b]["waveform"])
