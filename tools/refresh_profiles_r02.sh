@@ -1,0 +1,45 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/refresh_profiles_r02.sh <tag>  -> gpurun_out/<tag>/...: the driver-shaped bench line, rocprofv3 kernel
+# stats of the DAG workload, FETCH / WRITE / SQ counter passes (separate --pmc runs, --kernel-trace only) for the DP and HiFi-GAN kernels
+TAG=${1:-r02b}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/bench_headline.json 2> $OUT/bench_headline.err
+python bench.py --workload dag --tr 4095 --steps 3 --warmup 1 --no-cpu-baseline --no-c1 --no-peaked > $OUT/bench_dag_tr4095.json 2> $OUT/bench_dag_tr4095.err
+cd /tmp && export TMPDIR=/tmp
+DAGCMD="python $GRAFT_REPO_ROOT/bench.py --workload dag --no-cpu-baseline --no-c1 --no-peaked --steps 10 --warmup 2"
+rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats -d /tmp/ks -o k --output-format csv -- $DAGCMD > /dev/null 2>&1
+cp /tmp/ks/k_kernel_stats.csv $OUT/dag_kernel_stats.csv
+pmc() {   # $1 = counters, $2 = kernel-name substring filter, $3.. = command
+  local C="$1" PAT="$2"; shift; shift
+  rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $C -d /tmp/pm -o p --output-format csv -- "$@" > /dev/null 2>&1
+  python - "$PAT" <<'PY'
+import csv, collections, sys
+pat = sys.argv[1].split("|")
+rows = list(csv.DictReader(open("/tmp/pm/p_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+for r in rows:
+    k = r["Kernel_Name"][:90]
+    if not any(p in k for p in pat): continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+for k in sorted(agg): print(k, "| dispatches", len(n[k]), "| per dispatch:", {c: round(v / len(n[k]), 1) for c, v in sorted(agg[k].items())})
+PY
+}
+{
+echo "# rocprofv3 --pmc passes (separate runs, --kernel-trace only) over: $DAGCMD"
+echo "## FETCH_SIZE (raw KB; double it for 16-byte-per-lane streams, MI355X_MICROARCH.md HBM section)"; pmc FETCH_SIZE "dsp::" $DAGCMD
+echo "## WRITE_SIZE (KB)"; pmc WRITE_SIZE "dsp::" $DAGCMD
+echo "## SQ issue / wait counters of the DP kernels (quad-cycle units)"
+pmc "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "strip|maxstrip|grad_links" $DAGCMD
+pmc "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "strip|maxstrip|grad_links" $DAGCMD
+pmc "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "strip|maxstrip|grad_links" $DAGCMD
+} > $OUT/pmc_dag.txt 2>&1
+HGCMD="python $GRAFT_REPO_ROOT/tools/hifigan_bench.py 32 330"
+rm -rf /tmp/kh; rocprofv3 --kernel-trace --stats -d /tmp/kh -o k --output-format csv -- $HGCMD > $OUT/hifigan_bench.txt 2>&1
+cp /tmp/kh/k_kernel_stats.csv $OUT/hifigan_kernel_stats.csv
+{
+echo "# rocprofv3 --pmc passes over: $HGCMD"
+echo "## MFMA busy / LDS"; pmc "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES" "hifigan" $HGCMD
+pmc "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "hifigan" $HGCMD
+echo "## FETCH_SIZE (raw KB)"; pmc FETCH_SIZE "hifigan" $HGCMD
+echo "## WRITE_SIZE (KB)"; pmc WRITE_SIZE "hifigan" $HGCMD
+} > $OUT/pmc_hifigan.txt 2>&1
