@@ -24,10 +24,6 @@ int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t
 bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
 int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
-bool strip5_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
-int launch_dag_strip5(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
-void set_s5_cpl(int v);
-void set_s5_w(int v);
 
 bool dense_mfma_supported(int L, int TR);
 int launch_dag_dense_mfma(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
@@ -43,7 +39,6 @@ int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, cons
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
-// 8 = strip5 (exp space, one exponent per 64-column superblock, 2 or 4 columns per lane; experimental),
 // 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 64).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
@@ -106,9 +101,7 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     // auto: strip4g for the log-sum DP, strip2 for the max-DP with a trace
-    if (g_path == 8 && strip5_supported(match, alpha, beta, L, TR))          // experimental (r02): not the auto choice yet
-        rc = launch_dag_strip5(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
-    else if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
+    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
@@ -211,8 +204,6 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
 {
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
-    if (name && !strcmp(name, "s5_cpl")) { set_s5_cpl(value); return DSP_OK; }
-    if (name && !strcmp(name, "s5_w")) { set_s5_w(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_ng")) { set_dm_ng(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }

@@ -133,8 +133,8 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family FOR THE CALLING THREAD: 0 = auto, 1 = generic row-sequential /
  *   log-space dense, 2 = banded 2-column log-space strips, 4 = strip2 (2 vertices per lane), 5 = strip4g (exp-space, one exponent per
- *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment), 8 = strip5
- *   (experimental), 9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
+ *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment),
+ *   9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
  *   cross-check the families.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
