@@ -30,6 +30,9 @@ int launch_dag_dense_mfma(const float*, const float*, const int64_t*, const int6
 void set_dm_mt(int v);
 void set_dm_ng(int v);
 
+bool dense_max_supported(int L, int TR);
+int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
+
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
 
@@ -87,6 +90,10 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
         return align256(256 + (strip > mx ? strip : mx)) + 512;
     }
     if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
+    if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
+        const size_t NJ = (size_t)(L + 63) / 64;
+        return align256(256 + align256((size_t)B * NJ * 4) + (size_t)B * T * NJ * 4) + 512;
+    }
     return align256((size_t)B * L * TR * 4) + align256(256 + (size_t)B * 2 * L * 8) + 1024;
 }
 
@@ -155,6 +162,9 @@ static int best_alignment_impl(const float* match, const float* links, const int
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    // dense window: blocked max-plus DP + trace-free back-trace (the trace buffer, if given, is left untouched)
+    if ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR))
+        return launch_dag_dense_max(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
     // trace == NULL: values-only DP + lazy back-trace (no B*T*L trace tensor); only the banded strip kernel offers it
     if (!trace || g_path == 7) {
         if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR))
@@ -197,6 +207,7 @@ extern "C" int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, c
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
 {
+    if ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR)) return 1;
     return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 8192) ? 1 : 0;
 }
 

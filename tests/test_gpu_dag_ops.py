@@ -616,3 +616,28 @@ def test_dag_ops_are_graph_capturable(shape):
     want = step()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("quant", [False, True])
+@pytest.mark.parametrize("shape", DENSE_SHAPES)
+def test_dense_alignment_bit_exact_with_ties(shape, quant):
+    """dag_dp_dense_max.hip (blocked max-plus DP + trace-free back-trace) for dense windows: paths bit-exact against the f32 oracle —
+    also with quantised scores, where most rows hold exact ties (rule: smallest predecessor index) — and identical to the
+    row-sequential kernels with a trace tensor (dp_path 1)."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(13 + L, B, T, L, TR)
+    if quant:
+        match = (np.round(match * 2) / 2).astype(np.float32)
+        links = np.where(np.isfinite(links), np.round(links * 2) / 2, links).astype(np.float32)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+    try:
+        for path in (0, 1):
+            _lib.set_option("dp_path", path)
+            got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
+            assert _lib.last_launch_status() == 0
+            np.testing.assert_array_equal(got, ref, err_msg=f"dp_path {path}")
+    finally:
+        _lib.set_option("dp_path", 0)
+    assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == 1          # no B*T*L trace tensor for dense windows either
