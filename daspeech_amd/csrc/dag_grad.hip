@@ -348,7 +348,10 @@ int k5_diag(unsigned int* out) {
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gx_diag), z, 16);
     return (int)e;
 }
-static int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel
+bool grad_dense_supported(int L, int TR);
+int launch_dag_grad_links_dense(const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, int, hipStream_t);
+
+static int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
 void set_k5_path(int v) { g_k5_path = v; }
 
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,
@@ -369,6 +372,13 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         hipLaunchKernelGGL(dag_grad_links_exp_kernel, dim3((L + 255) / 256, B), dim3(256), lds, st,
                            g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
         int rc = check_launch("dag_loss_bwd(grad_links, exp space)");
+        if (rc) return rc;
+    } else if (g_links && g_k5_path != 1 && grad_dense_supported(L, TR)) {
+        // dense window: block products over the target axis on the f32 matrix cores (dag_grad_dense.hip).  Half of the compact
+        // [L][TR] layout addresses vertices past the graph (i + d + 1 >= L): zeros, as the reference's at::zeros leaves them.
+        hipError_t e = hipMemsetAsync(g_links, 0, (size_t)B * L * TR * sizeof(float), st);
+        if (e != hipSuccess) { set_error("hipMemsetAsync(grad_links): %s", hipGetErrorString(e)); return (int)e; }
+        int rc = launch_dag_grad_links_dense(g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR, st);
         if (rc) return rc;
     } else if (g_links) {
         hipLaunchKernelGGL(dag_grad_links_tiled_kernel, dim3((L + 63) / 64, (TR + 31) / 32, B), dim3(256), 0, st,

@@ -519,6 +519,45 @@ def test_dense_mfma_dp_matches_oracle(shape, masked):
         np.testing.assert_allclose(ls[fl], b64[fl, 0, 0], rtol=3e-6, atol=2e-5 * T)
 
 
+@pytest.mark.parametrize("weak", [False, True])
+@pytest.mark.parametrize("shape", DENSE_SHAPES)
+def test_dense_grad_links_block_products_match_oracle(shape, weak):
+    """dag_grad_dense.hip (K5 for TR > 64: per-block-pair products over the target axis on v_mfma_f32_16x16x4_f32, diagonal and
+    window-edge pairs term by term) against the fp64 oracle and the tiled log-space kernel (k5_path 1): ragged lengths, windows between
+    64 and L-1, -inf emissions, transitions ~2^-130 (weak), and the compact layout's entries past the graph (i + d + 1 >= L_b) are
+    exactly zero as the reference's at::zeros output leaves them (dag_loss.cu:493)."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(17 + L, B, T, L, TR)
+    rng = np.random.default_rng(L + 5)
+    match[rng.random(match.shape) < 0.08] = -np.inf
+    if weak:
+        links = np.where(np.isfinite(links), links + (rng.integers(0, 6, links.shape) == 0) * -90.0, links).astype(np.float32)
+    res = {}
+    try:
+        for k5 in (0, 1):
+            _lib.set_option("k5_path", k5)
+            m, k, o, t = to_dev(match, links, ol, tl)
+            m.requires_grad_(); k.requires_grad_()
+            loss = ops().dag_loss(m, k, o, t)
+            fin = torch.isfinite(loss)
+            gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
+            assert _lib.last_launch_status() == 0
+            res[k5] = (gm.cpu().numpy(), gl.cpu().numpy())
+    finally:
+        _lib.set_option("k5_path", 0)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+    i = np.arange(L)[None, :, None]; d = np.arange(TR)[None, None, :]
+    outside = (i + d + 1) >= ol[:, None, None]
+    for k5, (gm_, gl_) in res.items():
+        assert np.isfinite(gl_).all(), k5
+        assert (gl_[outside] == 0).all(), k5
+        np.testing.assert_allclose(gl_, gl64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
+        np.testing.assert_allclose(gm_, gm64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
+
+
 @pytest.mark.parametrize("shape", [(4, 256, 2048, 2047), (32, 100, 400, 399)])
 def test_dense_window_full_size_c1_and_readme_shape(shape):
     """BASELINE configs[0] (C1: B=4, T=256, L=2048, dense window) and the README's training shape (B=32, T=100, L=400,
