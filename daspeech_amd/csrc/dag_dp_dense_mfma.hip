@@ -31,6 +31,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace dsp {
 
@@ -73,33 +74,34 @@ constexpr int DM_EP = 68;                   // pitch of a weight-tile row in LDS
 constexpr int DM_NG = 8;                    // diagonal block: exponent groups of 8 columns (a vertex 8 columns right of the DP's diagonal
                                             // already carries ~2^45 times the paths: 16-column groups pushed the diagonal under the guard)
 
-// TM rows per chunk (16 * MT).  BETA: mirrored coordinates, see the header.
-// NG wave-groups of 4 waves split the source blocks of a tile between them (block V goes to group V % NG): NG blocks are staged and
-// multiplied per loop iteration, so the memory round trip of a stage is paid once per NG blocks (one group: 2.2 us per source block at
-// C1, the last block's 31 x 16 products = 1.1 ms on the critical path).
-template <int NG> constexpr int dm_group_floats(int TM) { return TM * 64 + 64 * DM_EP + TM + TM + TM * 64 + TM + TM; }
+// One chunk = 16 rows (one MFMA M-tile: 32- and 64-row chunks halve / quarter the passes over the transition matrix but lengthen the
+// (chunk, block) wavefront — they lost the r02 sweep at every shape).  The products of a tile run as a software pipeline over the source
+// blocks: the register stage of block V + D is requested while block V is converted (exp2) into one of two LDS buffers under the MFMAs
+// of block V - 1, so a source block costs max(MFMA, conversion) instead of a memory round trip (2.2 us per block before: C1's last block
+// spent 1.08 of its 2.1 ms there, and C2 at TR = 4095 was bound by the same per-block latency on every CU).
+constexpr int DM_TM = 16;
+constexpr int DM_AP = 68;                   // pitch of an A row (64 + 4, as DM_EP: fragment reads of 16 rows spread over all banks)
+constexpr int DM_AT = DM_TM * DM_AP;        // floats of one A buffer
+constexpr int DM_ET = 64 * DM_EP;           // floats of one E buffer
 
-template <int MT, int NG, bool BETA>
+template <int D, bool BETA>
 __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_raw, int b, int U, int sd)
 {
-    constexpr int TM = 16 * MT;
-    constexpr int GF = dm_group_floats<NG>(TM);
-    const int grp = threadIdx.x >> 8;                          // wave-group
-    float* gbase = reinterpret_cast<float*>(smem_raw) + grp * GF;
-    float* At = gbase;                                         // [TM][4][16]   A fragment order: [m][k % 4][k / 4]
-    float* Et = At + TM * 64;                                  // [64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
-    float* Sb = Et + 64 * DM_EP;                               // [TM]          exponent of the source block per row
-    float* FLb = Sb + TM;                                      // [TM]          first live column of the source block per row (global u, or 1e9)
-    float* Poff = FLb + TM;                                    // [TM][64]      off-diagonal sums of the tile (this group's share)
-    float* Roff = Poff + TM * 64;                              // [TM]          their reference exponents
-    float* FLo = Roff + TM;                                    // [TM]          first live column (global u) among the group's source blocks
-    float* Vd = reinterpret_cast<float*>(smem_raw) + NG * GF;  // [64]          diagonal block: previous row, 2^(a2 - X[group of 8])
-    int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]           broadcast slot of the readiness poll
-    float* A2d = Vd + 68;                                      // [64]          diagonal block: previous row, exact log2 values
-    float* Wd = A2d + 64;                                      // [64][64]      diagonal block: log2 weights [source i][column], -inf for i >= column
-    float* Md = Wd + 64 * 64;                                  // [TM][64]      diagonal block: the chunk's emissions
+    constexpr int TM = DM_TM;
+    float* At = reinterpret_cast<float*>(smem_raw);            // [2][TM][4][16]   A fragment order: [m][k % 4][k / 4], row pitch DM_AP
+    float* Et = At + 2 * DM_AT;                                // [2][64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
+    float* Sb = Et + 2 * DM_ET;                                // [2][TM]          exponent of the source block per row
+    float* FLb = Sb + 2 * TM;                                  // [2][TM]          first live column of the source block per row (global u, or 1e9)
+    float* Poff = FLb + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
+    float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
+    float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
+    float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
+    int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]              broadcast slot of the readiness poll
+    float* A2d = Vd + 68;                                      // [64]             diagonal block: previous row, exact log2 values
+    float* Wd = A2d + 64;                                      // [64][64]         diagonal block: log2 weights [source i][column], -inf for i >= column
+    float* Md = Wd + 64 * 64;                                  // [TM][64]         diagonal block: the chunk's emissions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tl = tid & 255, wg = wave & 3;                   // thread / wave inside the wave-group
+    const int tl = tid, wg = wave;
     const int T = p.T, L = p.L, TR = p.TR, NJ = p.NJ;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const float* M = p.match + (size_t)b * T * L;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
 
     // ---- rows the recurrence never reaches, and the seed row (tt = 0) of this block
     for (int t = Tb; t < T; ++t)
-        for (int ul = tid; ul < DM_BW; ul += 256 * NG) { const int u = ub + ul; if (u < L) O[(size_t)t * L + col(u)] = NEG_INF; }
+        for (int ul = tid; ul < DM_BW; ul += 256) { const int u = ub + ul; if (u < L) O[(size_t)t * L + col(u)] = NEG_INF; }
 
     // ---- diagonal-block state of wave 0 (lane = column ul of the block)
     const int ul = lane, u = ub + lane;
@@ -137,11 +139,15 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     for (int g = 0; g < DM_NG; ++g) Xg[g] = DM_SENT;
     int fl_prev = 1 << 30;                                   // first live column (global u) of the previous row inside this block
     if (wave == 0) {
+        // (-inf for i >= ul: the distance is negative.  All 64 requests first, unguarded, no LDS store between them: guarded loads, or
+        //  loads separated by stores through pointers the compiler cannot tell from global memory, are 64 serialized memory round
+        //  trips at the head of every block's critical path, ~0.1 ms)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) Ecol[i] = wlog2(ub + i, u);
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
-            const float wl = (i < ul) ? wlog2(ub + i, u) : NEG_INF;
-            Ecol[i] = dm_exp2(wl);
-            Wd[i * 64 + ul] = wl;                // kept for the in-block exact redo of near-diagonal cells
+            Wd[i * 64 + ul] = Ecol[i];           // kept for the in-block exact redo of near-diagonal cells
+            Ecol[i] = dm_exp2(Ecol[i]);
         }
         // seed row
         const bool seed = (u == u0) && u < L;
@@ -166,25 +172,72 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     }
     __syncthreads();
 
+    // loop-invariant 32-bit thread offsets of the fast-path loads (see prefetchE): element (it, e) of a source block, relative to the
+    // block's uniform base
+    unsigned offE[16];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!BETA) {
+                const int n = tid & 63, g = (tid >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4, cc = 4 * (kk0 + e) + kq;
+                offE[4 * it + e] = (unsigned)(cc * (TR - 1) + ub + n - 1);                    // links[vb + cc][ub + n - vb - cc - 1]
+            } else {
+                const int e0 = tid + 256 * it, hi = e0 >> 4, cc = 4 * (e0 & 15) + e;
+                offE[4 * it + e] = (unsigned)((L - 1 - ub - hi) * TR + hi + 63 - cc);         // links[L-1-u][u - vb - cc - 1], base K + ub - 64 - vb
+            }
+        }
     const int lr = lane & 15, lq = lane >> 4;
-    const bool prof = p.dbg == 2 && sd == 0 && U == p.NJ - 1;
+    const bool prof = (p.dbg & 2) && sd == 0 && U == p.NJ - 1;
+    u64 pf_p[6] = {0, 0, 0, 0, 0, 0};
     u64 pf_ready = 0, pf_gemm = 0, pf_diag = 0, pf_last = prof ? __builtin_amdgcn_s_memtime() : 0;
     auto stamp = [&](u64& acc) { if (prof) { const u64 t = __builtin_amdgcn_s_memtime(); acc += t - pf_last; pf_last = t; } };
     for (int c = 0; c < nchunks; ++c) {
         const int tt0 = c * TM;
         // ================================================================ off-diagonal products: source blocks V < U
-        v4f acc[MT];                          // running sums of this wave's 16-column slice, rows 4*lq + r of each 16-row subtile
-        float R[MT][4];
-        int FL[MT][4];
+        // The tile's sums stay in the MFMA accumulators across ALL source blocks (reading them back per block stalls the wave for the
+        // matrix pipe's latency every step).  Row m is scaled by ONE reference exponent: that of its first live source block, moved
+        // (and the sums rescaled) only when a block's exponent exceeds it by more than 60 binades — A <= 2^60, E <= 1, <= 4096 terms:
+        // the sums stay under 2^72.  Blocks far below the reference flush to zero exactly as they would against a running maximum.
+        // Three parties follow the same rule on the same sequence of block exponents and so agree without talking: the thread that
+        // converts row tid / 16 (Rm), the lanes that own rows 4 lq + r of the accumulators (R[r]), and threads < 16 (Rt, for the
+        // diagonal wave, with the first live column FLt).
+        v4f pa = (v4f){0.f, 0.f, 0.f, 0.f}, pb = (v4f){0.f, 0.f, 0.f, 0.f};
+        float R[4] = {DM_SENT, DM_SENT, DM_SENT, DM_SENT};
+        float Rm = DM_SENT, Rt = DM_SENT, FLt = 1.0e9f;
+        auto ref_rule = [](float& ref, float sx) -> float {        // returns log2 of the factor the row's sums take (0: none); selects only
+            const bool livex = sx != DM_SENT, first = ref == DM_SENT;
+            const bool jump = livex && !first && sx > ref + 60.f;
+            const float sc = jump ? ref - sx : 0.f;
+            ref = (livex && (first || jump)) ? sx : ref;
+            return sc;
+        };
+        // the chunk's emissions [TM x 64], 4 per thread, requested now and parked in LDS after the products (unconditional loads at
+        // clamped addresses: guarded ones compile to one exec-masked block and one memory round trip EACH — 16 us per chunk)
+        float em[4];
+        {
+            const int m = tid >> 4, q4 = tid & 15, tt = tt0 + m;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e) {
+                const int ue = ub + 4 * q4 + e;
+                const bool ok = tt >= 1 && tt < Tb && ue < L;
+                const float raw = M[ok ? ((size_t)row(tt) * L + col(ue)) : (size_t)0];
+                em[e] = ok ? raw * DM_LOG2E : NEG_INF;
+            }
+        }
+        const bool chunk_full = tt0 >= 1 && tt0 + TM <= Tb;            // every row of the chunk has a source row: no row predicates
+        const unsigned offS0 = (unsigned)((tt0 + (tid & 15) - 1) * NJ), offS1 = (unsigned)((tt0 + (tid >> 4) - 1) * NJ);
+        unsigned offA[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { R[mt][r] = DM_SENT; FL[mt][r] = 1 << 30; } }
+        for (int e = 0; e < 4; ++e) {
+            const int srow = row(tt0 + (tid >> 4) - 1), q4 = tid & 15;
+            offA[e] = BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e);
+        }
         if (U > 0) {
             // Source block V is usable for this chunk once progress[V] >= tag + c + 1 (then every block left of it is too).  Blocks are
-            // consumed left to right and only the LAST one (the left neighbour, still working on this chunk) is ever waited for long, so
-            // the products over V <= U-2 overlap the neighbour's work.  `ready_hi` = largest V known complete, refreshed by one vector
-            // poll of the next 64 progress words.
+            // consumed left to right and only the LAST ones (the left neighbours, still working on this chunk) are ever waited for, so
+            // the products over the earlier blocks overlap the neighbours' work.  `ready_hi` = largest V known complete, refreshed by
+            // one vector poll of the next 64 progress words.
             const u32 want = p.tag_base + (u32)c + 1u;
             int ready_hi = -1;
             auto ensure_ready = [&](int V) {
@@ -210,144 +263,310 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             // first source block inside the transition window
             int Vmin = 0;
             { const int lim = ub - TR - DM_BW; if (lim >= 0) Vmin = lim / DM_BW + 1; }
-            // register stage of block V: exponent / first-live per source row (threads < TM), 4 raw a2 values and 16 raw link values per thread
-            float st_s = DM_SENT, st_f = 64.f, st_a[MT][4], st_e[16];
-            auto prefetch = [&](int V) {
+            // register stage of a block: RAW loaded words only — exponent (row tl % 16: LDS copy + liveness vote; row tl / 16: this thread's
+            // A row) and first-live per source row, 4 alpha values and 16 link values per thread.  Nothing touches a stage between its
+            // request and its conversion D steps later (a select right behind the load would put the memory round trip back on every
+            // step: that, not the MFMAs, was the 2.2 us per source block of the first version); the validity predicates are integer
+            // functions of (V, thread) and are recomputed at conversion time.  All indices are 32-bit (dense_mfma_supported bounds them).
+            float st_s[D], st_sa[D], st_f[D], st_a[D][4], st_e[D][16];
+            // E element (it, e) of source block V: transition v -> u, address and validity
+            auto e_vu = [&](int V, int it, int e, int& v, int& uu) {
                 const int vb = V * DM_BW;
-                if (tl < TM) {
-                    const int tt = tt0 + tl;                             // this row's source row is tt - 1
-                    const bool ok = tt >= 1 && tt < Tb;
-                    const size_t si = ok ? ((size_t)(tt - 1) * NJ + V) : (size_t)0;
-                    const float sx = dm_ld(&S[si].x), sy = dm_ld(&S[si].y);
-                    st_s = ok ? sx : DM_SENT; st_f = ok ? sy : 64.f;
+                if (!BETA) {
+                    // lane <-> column n (coalesced along the row of links), the thread's 4 values of a step share (n, k % 4) and have
+                    // consecutive k / 4: one 16-byte LDS store in fragment order
+                    const int n = tl & 63, g = (tl >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4;
+                    v = vb + 4 * (kk0 + e) + kq; uu = ub + n;
+                } else {
+                    // W[v][u] = links[col(u)][u-v-1]: for a fixed u contiguous in v
+                    const int e0 = tl + 256 * it;
+                    v = vb + 4 * (e0 & 15) + e; uu = ub + (e0 >> 4);
+                }
+            };
+            auto e_ok = [&](int v, int uu) -> bool { return (uu - v - 1) < TR && uu < L; };          // (v < ub <= uu: the distance is >= 0)
+            // Fast path (every block pair of a dense window except the graph's last, ragged block): all 64 x 64 transitions exist, so
+            // the loads are  uniform base (scalar, moves with V) + loop-invariant 32-bit thread offset  and the conversion has no
+            // predicates — the predicated version below spends ~450 VALU/SALU instructions per source block, 3x the MFMA time.
+            auto e_full = [&](int V) -> bool { return (ub + 63 < L) && (ub + 62 - V * DM_BW < TR); };
+            auto prefetchE = [&](auto SC, int V) {
+                constexpr int s = decltype(SC)::value;
+                if (e_full(V)) {
+                    const float* Kv = K + (BETA ? (size_t)(ub - DM_BW - V * DM_BW) : (size_t)(V * DM_BW) * (size_t)(TR - 1));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st_e[s][i] = Kv[offE[i]];
+                    return;
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {                        // A: rows m = 16 mt + tid / 16, source columns 4 (tid % 16) .. +3
-                    const int m = 16 * mt + (tl >> 4), q4 = tl & 15;
-                    const int tt = tt0 + m;
+                for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int v = vb + 4 * q4 + e;
-                        const bool ok = tt >= 1 && tt < Tb && v < L;
-                        const float raw = dm_ld(O + (ok ? ((size_t)row(tt - 1) * L + col(v)) : (size_t)0));
-                        st_a[mt][e] = ok ? raw : NEG_INF;
+                        int v, uu; e_vu(V, it, e, v, uu);
+                        const int src = BETA ? (L - 1 - uu) : v;
+                        const unsigned idx = e_ok(v, uu) ? (unsigned)(src * TR + (uu - v - 1)) : 0u;
+                        st_e[s][4 * it + e] = K[idx];
+                    }
+            };
+            auto row_ok = [&](int m) -> bool { const int tt = tt0 + m; return tt >= 1 && tt < Tb; };      // this row's source row is tt - 1
+            auto prefetchA = [&](auto SC, int V) {
+                constexpr int s = decltype(SC)::value;
+                const int vb = V * DM_BW;
+                if (chunk_full) {
+                    const float2* Sv = S + V;
+                    st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y); st_sa[s] = dm_ld(&Sv[offS1].x);
+                    const float* Ov = O + (BETA ? (ub - DM_BW - vb) : vb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st_a[s][e] = dm_ld(Ov + offA[e]);
+                    return;
+                }
+                {
+                    const int m = tl & 15;
+                    const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
+                    st_s[s] = dm_ld(&S[si].x); st_f[s] = dm_ld(&S[si].y);
+                }
+                const int m = tl >> 4, q4 = tl & 15;                      // A: row m, source columns 4 q4 .. +3
+                {
+                    const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
+                    st_sa[s] = dm_ld(&S[si].x);
+                }
+                const int srow = row(tt0 + m - 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = vb + 4 * q4 + e;
+                    const unsigned idx = (row_ok(m) && v < L) ? (unsigned)(srow * L + col(v)) : 0u;
+                    st_a[s][e] = dm_ld(O + idx);
+                }
+            };
+            auto stage_live = [&](auto SC) -> bool {                     // lanes 0..15 of every wave hold the 16 rows: same vote in all waves
+                constexpr int s = decltype(SC)::value;
+                return __any(row_ok(tl & 15) && st_s[s] != DM_SENT);
+            };
+            // convert a register stage into LDS buffer nb: exponents, A = 2^(a2 - s), E = 2^(weight)
+            auto commit = [&](auto SC, int V, int nb) {
+                constexpr int s = decltype(SC)::value;
+                const int vb = V * DM_BW;
+                if (tl < TM) {
+                    const bool ok = row_ok(tl);
+                    const float sx = ok ? st_s[s] : DM_SENT;
+                    Sb[nb * TM + tl] = sx;
+                    (void)ref_rule(Rt, sx);
+                    FLt = fminf(FLt, (ok && st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
+                }
+                {
+                    const int m = tl >> 4, q4 = tl & 15;
+                    float* Ab = At + nb * DM_AT;
+                    if (chunk_full) {           // a dead row has exponent DM_SENT and 64 values -inf: 2^(-inf - ref) = 0 without a select
+                        (void)ref_rule(Rm, st_sa[s]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][e], DM_LOG2E, -Rm));
+                    } else {
+                        const float sx = row_ok(m) ? st_sa[s] : DM_SENT;
+                        (void)ref_rule(Rm, sx);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool ok = sx != DM_SENT && (vb + 4 * q4 + e) < L;
+                            Ab[m * DM_AP + e * 16 + q4] = ok ? dm_exp2(st_a[s][e] * DM_LOG2E - Rm) : 0.f;       // [m][k % 4][k / 4]
+                        }
                     }
                 }
+                float* Eb = Et + nb * DM_ET;
+                const bool efull = e_full(V);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {                         // E: 64 x 64 weights, 16 per thread
-                    if (!BETA) {
-                        // lane <-> column n (coalesced along the row of links), the thread's 4 values of a step share (n, k % 4) and have
-                        // consecutive k / 4: one 16-byte LDS store in fragment order
-                        const int n = tl & 63, g = (tl >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4;
+                for (int it = 0; it < 4; ++it) {
+                    float w[4];
+                    if (efull) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st_e[4 * it + e] = wlog2(vb + 4 * (kk0 + e) + kq, ub + n);
+                        for (int e = 0; e < 4; ++e) w[e] = dm_exp2(st_e[s][4 * it + e] * DM_LOG2E);
                     } else {
-                        // W[v][u] = links[col(u)][u-v-1]: for a fixed u contiguous in v
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int v, uu; e_vu(V, it, e, v, uu);
+                            w[e] = e_ok(v, uu) ? dm_exp2(st_e[s][4 * it + e] * DM_LOG2E) : 0.f;
+                        }
+                    }
+                    if (!BETA) {
+                        const int n = tl & 63, g = (tl >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4;
+                        *reinterpret_cast<v4f*>(Eb + n * DM_EP + kq * 16 + kk0) = (v4f){w[0], w[1], w[2], w[3]};
+                    } else {
                         const int e0 = tl + 256 * it;
                         const int hi = e0 >> 4, q4 = e0 & 15;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st_e[4 * it + e] = wlog2(vb + 4 * q4 + e, ub + hi);
+                        for (int e = 0; e < 4; ++e) Eb[hi * DM_EP + e * 16 + q4] = w[e];      // k = 4 q4 + e, n = hi
                     }
                 }
             };
-            // iteration Vp handles blocks Vp .. Vp + NG - 1, one per wave-group (a group past the end idles through the barriers)
-            if (Vmin < U) { ensure_ready(min(Vmin + NG - 1, U - 1)); if (Vmin + grp < U) prefetch(Vmin + grp); }
-            for (int Vp = Vmin; Vp < U; Vp += NG) {
-                const int V = Vp + grp;
-                const bool mine = V < U;
+            int cur = 0;                       // LDS buffer of the block whose products are pending
+            bool have = false;
+            auto mfma_issue = [&](int nb) {    // 16 x (16x16x4): this wave's slice = columns 16*wave .. +15 of the block; two chains (40-cycle dependent latency)
+                const float* Ab = At + nb * DM_AT; const float* Eb = Et + nb * DM_ET;
+                // the rows' reference exponents follow the same rule as the converting threads' (ref_rule): a change rescales the sums
+                const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 4 * lq);
+                float sc[4]; bool resc = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[r], sx4[r]); resc |= sc[r] != 0.f; }
+                if (__any(resc)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[r] *= f; pb[r] *= f; }
+                }
+                float bf[16], af[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f t4 = *reinterpret_cast<const v4f*>(Eb + (16 * wg + lr) * DM_EP + lq * 16 + 4 * q);
+                    bf[4 * q] = t4.x; bf[4 * q + 1] = t4.y; bf[4 * q + 2] = t4.z; bf[4 * q + 3] = t4.w;
+                    const v4f a4 = *reinterpret_cast<const v4f*>(Ab + lr * DM_AP + lq * 16 + 4 * q);
+                    af[4 * q] = a4.x; af[4 * q + 1] = a4.y; af[4 * q + 2] = a4.z; af[4 * q + 3] = a4.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 2) {
+                    pa = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], pa, 0, 0, 0);
+                    pb = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], pb, 0, 0, 0);
+                }
+            };
+            // one pipeline step: products of the pending block || conversion of block V (stage s) || requests for block V + D.
+            // The loads are UNCONDITIONAL (a step past the last block re-requests block U-1 and drops it): s_waitcnt counts in order, so
+            // the compiler can only leave younger stages in flight at a conversion if every path issues the same number of loads —
+            // with the requests under `if (W < U)` it had to assume none and emitted vmcnt(0): no pipelining at any depth.
+            // Readiness is never waited for AHEAD of need: a block beyond `ready_hi` when its stage is requested gets its (static) weights
+            // requested anyway, and its alpha rows / exponents re-requested when its turn comes (st_ok).  Only the left neighbour(s) are
+            // ever in that state, and waiting for them D blocks early would put D - 1 conversions + products behind the wait, on the
+            // (chunk, block) wavefront's critical path.
+            bool st_ok[D];
+            // The common step, fused: (pending block in LDS) x (block V converted) x (block V + D requested), every load and the whole
+            // conversion on the predicate-free paths.  The 8 fragment reads go out together (inline asm: the compiler otherwise reuses
+            // 8 registers and serialises read -> 4 MFMAs -> read ...: four exposed LDS round trips per block), the alpha conversion
+            // covers their latency, and the transition-matrix conversion and the next requests are interleaved with the 16 MFMAs.
+            auto fused_step = [&](auto SC, int V, int Wc) {
+                constexpr int s = decltype(SC)::value;
+                const int nb = cur, wb = cur ^ 1;
+                const u32 a_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(At + nb * DM_AT + lr * DM_AP + lq * 16);
+                const u32 e_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Et + nb * DM_ET + (16 * wg + lr) * DM_EP + lq * 16);
+                v4f fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;
+                asm volatile("ds_read_b128 %0, %8\n\t"
+                             "ds_read_b128 %4, %9\n\t"
+                             "ds_read_b128 %1, %8 offset:16\n\t"
+                             "ds_read_b128 %5, %9 offset:16\n\t"
+                             "ds_read_b128 %2, %8 offset:32\n\t"
+                             "ds_read_b128 %6, %9 offset:32\n\t"
+                             "ds_read_b128 %3, %8 offset:48\n\t"
+                             "ds_read_b128 %7, %9 offset:48"
+                             : "=&v"(fa0), "=&v"(fa1), "=&v"(fa2), "=&v"(fa3), "=&v"(fb0), "=&v"(fb1), "=&v"(fb2), "=&v"(fb3)
+                             : "v"(a_addr), "v"(e_addr) : "memory");
+                const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 4 * lq);
+                // ---- alpha rows of block V -> A (buffer wb), exponents
                 const int vb = V * DM_BW;
-                // ---- commit the register stage to LDS: exponents first (A needs them), then A = 2^(a2 - s) and E = 2^(weight)
-                if (tl < TM) { Sb[tl] = mine ? st_s : DM_SENT; FLb[tl] = (mine && st_f < 64.f) ? (float)vb + st_f : 1.0e9f; }
-                __syncthreads();
-                bool any_live = false;
-#pragma unroll
-                for (int m = 0; m < TM; ++m) any_live |= (Sb[m] != DM_SENT);
-                if (any_live) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int m = 16 * mt + (tl >> 4), q4 = tl & 15;
-                        const float sx = Sb[m];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            At[(m * 4 + e) * 16 + q4] = (sx != DM_SENT) ? dm_exp2(st_a[mt][e] * DM_LOG2E - sx) : 0.f;       // [m][k % 4][k / 4]
-                    }
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        if (!BETA) {
-                            const int n = tl & 63, g = (tl >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4;
-                            v4f w4;
-                            w4.x = dm_exp2(st_e[4 * it]); w4.y = dm_exp2(st_e[4 * it + 1]); w4.z = dm_exp2(st_e[4 * it + 2]); w4.w = dm_exp2(st_e[4 * it + 3]);
-                            *reinterpret_cast<v4f*>(Et + n * DM_EP + kq * 16 + kk0) = w4;
-                        } else {
-                            const int e0 = tl + 256 * it;
-                            const int hi = e0 >> 4, q4 = e0 & 15;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) Et[hi * DM_EP + e * 16 + q4] = dm_exp2(st_e[4 * it + e]);      // k = 4 q4 + e, n = hi
-                        }
-                    }
+                if (tl < TM) {
+                    const float sx = st_s[s];
+                    Sb[wb * TM + tl] = sx;
+                    (void)ref_rule(Rt, sx);
+                    FLt = fminf(FLt, (st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
-                __syncthreads();
-                // ---- the next blocks' loads go out now and land under these blocks' MFMAs
-                if (Vp + NG < U) { ensure_ready(min(Vp + 2 * NG - 1, U - 1)); if (V + NG < U) prefetch(V + NG); }
-                if (any_live) {
-                    // ---- 16 x (16x16x4) MFMA per 16-row subtile; this wave's slice = columns 16*wave .. +15 of the block
-                    float bf[16];
+                {
+                    const int m = tl >> 4, q4 = tl & 15;
+                    float* Ab = At + wb * DM_AT;
+                    (void)ref_rule(Rm, st_sa[s]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const v4f t4 = *reinterpret_cast<const v4f*>(Et + (16 * wg + lr) * DM_EP + lq * 16 + 4 * q);
-                        bf[4 * q] = t4.x; bf[4 * q + 1] = t4.y; bf[4 * q + 2] = t4.z; bf[4 * q + 3] = t4.w;
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        float af[16];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const v4f t4 = *reinterpret_cast<const v4f*>(At + ((16 * mt + lr) * 4 + lq) * 16 + 4 * q);
-                            af[4 * q] = t4.x; af[4 * q + 1] = t4.y; af[4 * q + 2] = t4.z; af[4 * q + 3] = t4.w;
-                        }
-                        v4f pa = (v4f){0.f, 0.f, 0.f, 0.f}, pb = (v4f){0.f, 0.f, 0.f, 0.f};          // two chains: 40-cycle dependent latency
-#pragma unroll
-                        for (int kk = 0; kk < 16; kk += 2) {
-                            pa = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], pa, 0, 0, 0);
-                            pb = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], pb, 0, 0, 0);
-                        }
-                        // fold into the running sums against the running maximum of the block exponents (rows 4*lq + r)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = 16 * mt + 4 * lq + r;
-                            const float sx = Sb[m];
-                            const float rn = fmaxf(R[mt][r], sx);
-                            acc[mt][r] = acc[mt][r] * dm_exp2(R[mt][r] - rn) + (pa[r] + pb[r]) * dm_exp2(sx - rn);
-                            R[mt][r] = rn;
-                            FL[mt][r] = min(FL[mt][r], (int)fminf(FLb[m], 1.0e9f));
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][e], DM_LOG2E, -Rm));
                 }
+                // ---- the pending block's rows: reference exponents (a change rescales the sums: rare)
+                float sc[4]; bool resc = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[r], sx4[r]); resc |= sc[r] != 0.f; }
+                if (__any(resc)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[r] *= f; pb[r] *= f; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3) :: "memory");
+                float* Eb = Et + wb * DM_ET;
+                auto convE = [&](int it) {
+                    v4f w4;
+                    w4.x = dm_exp2(st_e[s][4 * it] * DM_LOG2E); w4.y = dm_exp2(st_e[s][4 * it + 1] * DM_LOG2E);
+                    w4.z = dm_exp2(st_e[s][4 * it + 2] * DM_LOG2E); w4.w = dm_exp2(st_e[s][4 * it + 3] * DM_LOG2E);
+                    if (!BETA) {
+                        const int n = tl & 63, g = (tl >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4;
+                        *reinterpret_cast<v4f*>(Eb + n * DM_EP + kq * 16 + kk0) = w4;
+                    } else {
+                        const int e0 = tl + 256 * it, hi = e0 >> 4, q4 = e0 & 15;
+                        Eb[hi * DM_EP + q4] = w4.x; Eb[hi * DM_EP + 16 + q4] = w4.y; Eb[hi * DM_EP + 32 + q4] = w4.z; Eb[hi * DM_EP + 48 + q4] = w4.w;
+                    }
+                };
+                const float* Kv = K + (BETA ? (size_t)(ub - DM_BW - Wc * DM_BW) : (size_t)(Wc * DM_BW) * (size_t)(TR - 1));
+                const float2* Sv = S + Wc;
+                const float* Ov = O + (BETA ? (ub - DM_BW - Wc * DM_BW) : Wc * DM_BW);
+#define DM_MF(A_, B_, j_) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[j_], B_[j_], pa, 0, 0, 0); pb = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[j_ + 1], B_[j_ + 1], pb, 0, 0, 0);
+                DM_MF(fa0, fb0, 0) convE(0);
+                DM_MF(fa0, fb0, 2) convE(1);
+                DM_MF(fa1, fb1, 0) convE(2);
+                DM_MF(fa1, fb1, 2) convE(3);
+                DM_MF(fa2, fb2, 0)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st_e[s][i] = Kv[offE[i]];
+                DM_MF(fa2, fb2, 2)
+#pragma unroll
+                for (int i = 8; i < 16; ++i) st_e[s][i] = Kv[offE[i]];
+                DM_MF(fa3, fb3, 0)
+                st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y); st_sa[s] = dm_ld(&Sv[offS1].x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st_a[s][e] = dm_ld(Ov + offA[e]);
+                DM_MF(fa3, fb3, 2)
+#undef DM_MF
+                st_ok[s] = (V + D) <= ready_hi;
                 __syncthreads();
+                cur ^= 1;
+            };
+            auto step = [&](auto SC, int V) {
+                constexpr int s = decltype(SC)::value;
+                stamp(pf_gemm);
+                if (V < U && !st_ok[s]) {
+                    ensure_ready(V); prefetchA(SC, V);
+                    // (consumed here, so that the wait for this re-request sits inside the branch: at the join the compiler must otherwise
+                    //  assume "no younger loads behind the stage" on every path and emits vmcnt(0) for the common one too)
+                    asm volatile("" :: "v"(st_a[s][3]), "v"(st_a[s][0]), "v"(st_s[s]) : "memory");
+                }
+                const bool live = V < U && stage_live(SC);
+                const int W = V + D, Wc = min(W, U - 1);
+                if (have && live && chunk_full && e_full(V)) { fused_step(SC, V, Wc); stamp(pf_p[1]); return; }      // (e_full(V) => e_full(Wc))
+                stamp(pf_p[0]);                                               // (DSP_DEBUG=prof) wait for the stage's loads
+                if (have) mfma_issue(cur);
+                if (live) commit(SC, V, cur ^ 1);
+                stamp(pf_p[2]);
+                prefetchE(SC, Wc);
+                prefetchA(SC, Wc);
+                st_ok[s] = W <= ready_hi;
+                stamp(pf_p[3]);
+                if (have || live) __syncthreads();
+                stamp(pf_p[5]);
+                if (live) cur ^= 1;
+                have = live;
+            };
+            auto fill = [&](auto SC) {
+                constexpr int s = decltype(SC)::value;
+                const int W = Vmin + s, Wc = min(W, U - 1);
+                prefetchE(SC, Wc);
+                if (s == 0) ensure_ready(Vmin);                             // the chunk's one poll ahead of need: blocks done so far
+                prefetchA(SC, Wc);
+                st_ok[s] = W <= ready_hi;
+            };
+            fill(std::integral_constant<int, 0>{});
+            if constexpr (D > 1) fill(std::integral_constant<int, 1>{});
+            if constexpr (D > 2) fill(std::integral_constant<int, 2>{});
+            if constexpr (D > 3) fill(std::integral_constant<int, 3>{});
+            for (int Vb = Vmin; Vb < U; Vb += D) {
+                step(std::integral_constant<int, 0>{}, Vb);
+                if constexpr (D > 1) step(std::integral_constant<int, 1>{}, Vb + 1);
+                if constexpr (D > 2) step(std::integral_constant<int, 2>{}, Vb + 2);
+                if constexpr (D > 3) step(std::integral_constant<int, 3>{}, Vb + 3);
             }
+            if (have) mfma_issue(cur);
         }
         stamp(pf_gemm);
-        // ---- hand the tile's off-diagonal sums to the diagonal wave
+        // ---- hand the tile's off-diagonal sums and the chunk's emissions to the diagonal wave
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 16 * mt + 4 * lq + r;
-                Poff[m * 64 + 16 * wg + lr] = acc[mt][r];
-                if (wg == 0 && lr == 0) { Roff[m] = R[mt][r]; FLo[m] = (float)FL[mt][r]; }
-            }
+        for (int r = 0; r < 4; ++r) Poff[(4 * lq + r) * 64 + 16 * wg + lr] = pa[r] + pb[r];
+        if (tid < TM) { Roff[tid] = Rt; FLo[tid] = FLt; }
+        *reinterpret_cast<v4f*>(Md + (tid >> 4) * 64 + 4 * (tid & 15)) = (v4f){em[0], em[1], em[2], em[3]};
         __syncthreads();
 
         // ================================================================ diagonal block: rows of the chunk in sequence (wave 0)
         if (wave == 0) {
-            // the chunk's emissions for this column: all loads in flight at once (one per row made the row time a memory round trip)
-            {
-                float mrow[TM];
-#pragma unroll
-                for (int m = 0; m < TM; ++m) { const int tt = tt0 + m; mrow[m] = (tt >= 1 && tt < Tb && u < L) ? M[(size_t)row(tt) * L + col(u)] : NEG_INF; }
-#pragma unroll
-                for (int m = 0; m < TM; ++m) Md[m * 64 + ul] = mrow[m] * DM_LOG2E;
-            }
 #pragma unroll 1
             for (int m = 0; m < TM; ++m) {
                 const int tt = tt0 + m;
@@ -371,17 +590,13 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 float ref = Xg[0];
 #pragma unroll
                 for (int g = 1; g < DM_NG; ++g) if (gl >= g) ref = fmaxf(ref, Xg[g]);
-                float ro = Roff[m], flo = FLo[m];                  // (wave 0 belongs to group 0: its pointers are group 0's)
-#pragma unroll
-                for (int g2 = 1; g2 < NG; ++g2) { ro = fmaxf(ro, Roff[g2 * GF + m]); flo = fminf(flo, FLo[g2 * GF + m]); }
+                const float ro = Roff[m], flo = FLo[m];
                 const float rt = fmaxf(ro, ref);
                 float Pd = 0.f;
 #pragma unroll
                 for (int g = 0; g < DM_NG; ++g) Pd += (g <= gl) ? part[g] * dm_exp2(Xg[g] - rt) : 0.f;   // (a group right of the column has a
                                                                                        // zero sum but may have a LARGER exponent: 0 * inf)
-                float P = Pd;
-#pragma unroll
-                for (int g2 = 0; g2 < NG; ++g2) P += Poff[g2 * GF + m * 64 + ul] * dm_exp2(Roff[g2 * GF + m] - rt);
+                const float P = Pd + Poff[m * 64 + ul] * dm_exp2(ro - rt);
                 float a2 = __builtin_amdgcn_logf(P) + rt + m2;                                // P = 0 -> -inf
                 // ---- exactness guard.  A sum under the threshold is only trusted as "dead" when the cell has no live predecessor.
                 const int flp = min((int)fminf(flo, 1.0e9f), fl_prev);                      // first live column of the previous row (global)
@@ -459,12 +674,13 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         __syncthreads();
         stamp(pf_diag);
     }
-    if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks; }
+    if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks;
+                             for (int i = 0; i < 6; ++i) p.counters[44 + i] = (u32)(pf_p[i] >> 4); }
     (void)a2prev;
 }
 
-template <int MT, int NG>
-__global__ __launch_bounds__(256 * NG) void dag_dense_mfma_kernel(DMParams p)
+template <int D>
+__global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ u32 s_ticket;
@@ -484,32 +700,30 @@ __global__ __launch_bounds__(256 * NG) void dag_dense_mfma_kernel(DMParams p)
     if (!valid) {                                    // invalid sample: -inf everywhere, no trap; its other blocks do the same, nobody waits
         float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * L;
         for (int t = 0; t < T; ++t)
-            for (int ul = tid; ul < DM_BW; ul += 256 * NG) { const int u = U * DM_BW + ul; if (u < L) O[(size_t)t * L + (is_beta ? (L - 1 - u) : u)] = NEG_INF; }
+            for (int ul = tid; ul < DM_BW; ul += 256) { const int u = U * DM_BW + ul; if (u < L) O[(size_t)t * L + (is_beta ? (L - 1 - u) : u)] = NEG_INF; }
         return;
     }
-    if (is_beta) dense_mfma_body<MT, NG, true>(p, smem_raw, b, U, sd);
-    else dense_mfma_body<MT, NG, false>(p, smem_raw, b, U, sd);
+    if (is_beta) dense_mfma_body<D, true>(p, smem_raw, b, U, sd);
+    else dense_mfma_body<D, false>(p, smem_raw, b, U, sd);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
-bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128; }
+bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31); }
 
-template <int MT, int NG>
+template <int D>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
-    constexpr int TM = 16 * MT;
-    const size_t lds = (size_t)(NG * dm_group_floats<NG>(TM) + 64 + 4 + 64 + 64 * 64 + TM * 64) * 4 + 64;
-    auto k = dag_dense_mfma_kernel<MT, NG>;
+    const size_t lds = (size_t)(2 * DM_AT + 2 * DM_ET + 4 * DM_TM + DM_TM * 64 + 2 * DM_TM + 68 + 64 + 64 * 64 + DM_TM * 64) * 4 + 64;
+    auto k = dag_dense_mfma_kernel<D>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256 * NG), lds, st, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
     return check_launch("dag_loss_fwd(dense mfma)");
 }
 
-static int g_dm_mt = 0, g_dm_ng = 0;
-void set_dm_mt(int v) { g_dm_mt = v; }
-void set_dm_ng(int v) { g_dm_ng = v; }
+static int g_dm_depth = 0;
+void set_dm_depth(int v) { g_dm_depth = v; }
 
 int launch_dag_dense_mfma(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                           float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
@@ -528,19 +742,10 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float2*>(reinterpret_cast<char*>(area) + prog_bytes);
     const int nwg = ndir * B * NJ;
-    // rows per chunk: 16 keeps the (chunk, block) wavefront short — it won the r02 sweep at every shape tried (C1: 2.2 / 3.0 / 3.4 ms,
-    // C2 at TR = 4095: 35 / 65 / 52 ms for 16 / 32 / 64 rows, which halve / quarter the passes over the transition matrix)
-    int mt = g_dm_mt ? g_dm_mt : 1;
-    // two wave-groups only with 16-row chunks: with 32 / 64 rows the second group's accumulators no longer fit the register file
-    const int ng = (mt == 1) ? (g_dm_ng ? g_dm_ng : 1) : 1;      // (two groups halve the last block's product time at C1 but not the launch: r02 sweep)
-    if (ng == 1) {
-        if (mt >= 4) return launch_dm<4, 1>(p, nwg, st);
-        if (mt == 2) return launch_dm<2, 1>(p, nwg, st);
-        return launch_dm<1, 1>(p, nwg, st);
-    }
-    if (mt >= 4) return launch_dm<4, 2>(p, nwg, st);
-    if (mt == 2) return launch_dm<2, 2>(p, nwg, st);
-    return launch_dm<1, 2>(p, nwg, st);
+    const int depth = g_dm_depth ? g_dm_depth : 2;       // source blocks in flight per workgroup
+    if (depth <= 1) return launch_dm<1>(p, nwg, st);
+    if (depth == 2) return launch_dm<2>(p, nwg, st);
+    return launch_dm<3>(p, nwg, st);
 }
 
 }  // namespace dsp

@@ -12,11 +12,11 @@ valid = (i + d + 1) < ol.view(-1, 1, 1)
 links = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1).masked_fill(~valid, float("-inf"))
 lib = _lib.load(); st = _lib.current_stream_handle()
 alpha = torch.empty_like(match)
-_lib.set_option("dp_path", 9); _lib.set_option("dm_mt", 1)
+_lib.set_option("dp_path", 9); _lib.set_option("dm_depth", 1)
 assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), None, None, B, T, L, TR, None, 0, st) == 0
 import time
-for mt, ng in ((1, 1), (1, 2), (2, 1)):
-    _lib.set_option("dm_mt", mt); _lib.set_option("dm_ng", ng)
+for mt in (1, 2, 3, 4):
+    _lib.set_option("dm_depth", mt)
     beta = torch.empty_like(match)
     for _ in range(2):
         assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), None, B, T, L, TR, None, 0, st) == 0
@@ -24,8 +24,8 @@ for mt, ng in ((1, 1), (1, 2), (2, 1)):
     assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), None, B, T, L, TR, None, 0, st) == 0
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     _lib.last_launch_status(); w = lib.dsp_dag_debug_words()
-    print(f"mt={mt} ng={ng}: wall {dt*1e3:.3f} ms; last block of sd 0: ready-wait {w[39]*16/2.4e3:.1f} us, gemm {w[40]*16/2.4e3:.1f} us, diag {w[41]*16/2.4e3:.1f} us (at 2.4 GHz), chunks {w[42]}")
-_lib.set_option("dm_mt", 1)
+    print(f"depth={mt}: wall {dt*1e3:.3f} ms; last block of sd 0: ready-wait {w[39]*16/2.4e3:.1f} us, gemm {w[40]*16/2.4e3:.1f} us, diag {w[41]*16/2.4e3:.1f} us (at 2.4 GHz), chunks {w[42]}; step phases (us): loads-wait {w[43]*16/2.4e3:.0f} mfma-issue {w[44]*16/2.4e3:.0f} commit {w[45]*16/2.4e3:.0f} prefetch {w[46]*16/2.4e3:.0f} fold {w[47]*16/2.4e3:.0f} barrier {w[48]*16/2.4e3:.0f}")
+_lib.set_option("dm_depth", 0)
 print("status", _lib.last_launch_status(), "exact cells", _lib.last_fallback_count())
 print(_lib.debug_fallback_cells())
 a = alpha[0].cpu()
