@@ -38,6 +38,7 @@ namespace dsp {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct DMParams {
     const float* match; const float* links; const int64_t* out_len; const int64_t* tgt_len;
@@ -70,6 +71,17 @@ __device__ __forceinline__ float dm_max8(float v) {
                  "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
     return v;
 }
+// inclusive prefix maximum over the wave's 8-lane groups of a value that is uniform inside each group (result again uniform per group):
+// shift by one group inside each 16-lane row, then the classic row_bcast:15 / row_bcast:31 steps of a wave64 scan
+__device__ __forceinline__ float dm_prefmax_groups(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+}
 constexpr int DM_EP = 68;                   // pitch of a weight-tile row in LDS (64 + 4: the staging b128 stores of 8 lanes hit 8 different bank groups)
 constexpr int DM_NG = 8;                    // diagonal block: exponent groups of 8 columns (a vertex 8 columns right of the DP's diagonal
                                             // already carries ~2^45 times the paths: 16-column groups pushed the diagonal under the guard)
@@ -91,8 +103,8 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     float* At = reinterpret_cast<float*>(smem_raw);            // [2][TM][4][16]   A fragment order: [m][k % 4][k / 4], row pitch DM_AP
     float* Et = At + 2 * DM_AT;                                // [2][64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
     float* Sb = Et + 2 * DM_ET;                                // [2][TM]          exponent of the source block per row
-    float* FLb = Sb + 2 * TM;                                  // [2][TM]          first live column of the source block per row (global u, or 1e9)
-    float* Poff = FLb + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
+    float* Xd = Sb + 2 * TM;                                   // [8] (of 2 TM)    diagonal block: exponent of each 8-column group of the previous row
+    float* Poff = Xd + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
     float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
     float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
@@ -132,43 +144,42 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
 
     // ---- diagonal-block state of wave 0 (lane = column ul of the block)
     const int ul = lane, u = ub + lane;
-    float Ecol[64];                                          // 2^(weight of v = ub + i -> u), 0 for i >= ul
-    float a2prev = NEG_INF;
-    float Xg[DM_NG];                                         // exponent of each 8-column group of the previous row (wave-uniform)
-#pragma unroll
-    for (int g = 0; g < DM_NG; ++g) Xg[g] = DM_SENT;
+    v2f Ec[32];                                              // 2^(weight of v = ub + i -> u), 0 for i >= ul; pairs for v_pk_fma_f32
+    float ref = DM_SENT;                                     // largest group exponent of the previous row among groups 0 .. ul / 8
     int fl_prev = 1 << 30;                                   // first live column (global u) of the previous row inside this block
+    // end of a row of the diagonal block: output, next row's broadcast state (values scaled per 8-column group, exact log2 values,
+    // group exponents, their prefix maximum), block exponent / first live column for the blocks to the right
+    auto row_end = [&](float a2, int tt) {
+        if (u < L) dm_st(O + (size_t)row(tt) * L + col(u), a2 * DM_LN2);
+        const float gm = dm_max8(a2);
+        const float xs = (gm == NEG_INF) ? DM_SENT : ceilf(gm);            // the lane's own group exponent (gm is uniform inside a group)
+        Vd[ul] = dm_exp2(a2 - xs);                                         // (-inf - x = -inf -> 0)
+        A2d[ul] = a2;
+        Xd[ul >> 3] = xs;                                                  // (8 lanes, one address, one value)
+        ref = dm_prefmax_groups(xs);
+        const u64 lv = __ballot(a2 != NEG_INF);
+        fl_prev = lv ? (ub + (int)__builtin_ctzll(lv)) : (1 << 30);
+        const float sblk = __builtin_amdgcn_readlane(ref, 63);
+        if (lane == 0) {
+            dm_st(&S[(size_t)tt * NJ + U].x, sblk);
+            dm_st(&S[(size_t)tt * NJ + U].y, lv ? (float)__builtin_ctzll(lv) : 64.f);
+        }
+    };
     if (wave == 0) {
         // (-inf for i >= ul: the distance is negative.  All 64 requests first, unguarded, no LDS store between them: guarded loads, or
         //  loads separated by stores through pointers the compiler cannot tell from global memory, are 64 serialized memory round
         //  trips at the head of every block's critical path, ~0.1 ms)
 #pragma unroll
-        for (int i = 0; i < 64; ++i) Ecol[i] = wlog2(ub + i, u);
+        for (int i = 0; i < 32; ++i) { Ec[i].x = wlog2(ub + 2 * i, u); Ec[i].y = wlog2(ub + 2 * i + 1, u); }
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            Wd[i * 64 + ul] = Ecol[i];           // kept for the in-block exact redo of near-diagonal cells
-            Ecol[i] = dm_exp2(Ecol[i]);
+        for (int i = 0; i < 32; ++i) {
+            Wd[(2 * i) * 64 + ul] = Ec[i].x; Wd[(2 * i + 1) * 64 + ul] = Ec[i].y;           // kept for the in-block exact redo of near-diagonal cells
+            Ec[i].x = dm_exp2(Ec[i].x); Ec[i].y = dm_exp2(Ec[i].y);
         }
         // seed row
         const bool seed = (u == u0) && u < L;
         const float m0 = seed ? M[(size_t)row(0) * L + col(u)] * DM_LOG2E : NEG_INF;
-        a2prev = m0;
-        if (u < L) dm_st(O + (size_t)row(0) * L + col(u), a2prev * DM_LN2);
-        const float gm = dm_max8(a2prev);
-#pragma unroll
-        for (int g = 0; g < DM_NG; ++g) { const float x = __builtin_amdgcn_readlane(gm, 8 * g); Xg[g] = (x == NEG_INF) ? DM_SENT : ceilf(x); }
-        const float xs0 = (gm == NEG_INF) ? DM_SENT : ceilf(gm);          // the lane's own group exponent (gm is uniform inside a group)
-        Vd[ul] = (a2prev == NEG_INF) ? 0.f : dm_exp2(a2prev - xs0);
-        A2d[ul] = a2prev;
-        const u64 lv = __ballot(a2prev != NEG_INF);
-        fl_prev = lv ? (ub + (int)__builtin_ctzll(lv)) : (1 << 30);
-        if (lane == 0) {
-            float sblk = Xg[0];
-#pragma unroll
-            for (int g = 1; g < DM_NG; ++g) sblk = fmaxf(sblk, Xg[g]);
-            float2 sv; sv.x = sblk; sv.y = lv ? (float)__builtin_ctzll(lv) : 64.f;
-            dm_st(&S[(size_t)0 * NJ + U].x, sv.x); dm_st(&S[(size_t)0 * NJ + U].y, sv.y);
-        }
+        row_end(m0, 0);
     }
     __syncthreads();
 
@@ -567,36 +578,57 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
 
         // ================================================================ diagonal block: rows of the chunk in sequence (wave 0)
         if (wave == 0) {
+            const int m_lo = (tt0 == 0) ? 1 : 0, m_hi = min(TM, Tb - tt0);
+            // this row's LDS operands are requested one row ahead
+            float n_m2 = Md[m_lo * 64 + ul], n_ro = Roff[m_lo], n_flo = FLo[m_lo], n_po = Poff[m_lo * 64 + ul];
+            const u32 vd_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)Vd;
+            const u32 xd_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)Xd;
 #pragma unroll 1
-            for (int m = 0; m < TM; ++m) {
+            for (int m = m_lo; m < m_hi; ++m) {
                 const int tt = tt0 + m;
-                if (tt == 0) continue;
-                if (tt >= Tb) break;
-                const float m2 = Md[m * 64 + ul];
-                // previous row of the block, broadcast: one partial sum per 8-column group (each in its group's scale)
-                float part[DM_NG];
-#pragma unroll
-                for (int g = 0; g < DM_NG; ++g) part[g] = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const v4f t4 = *reinterpret_cast<const v4f*>(Vd + 4 * q);
-                    part[q >> 1] = fmaf(t4.x, Ecol[4 * q], part[q >> 1]);
-                    part[q >> 1] = fmaf(t4.y, Ecol[4 * q + 1], part[q >> 1]);
-                    part[q >> 1] = fmaf(t4.z, Ecol[4 * q + 2], part[q >> 1]);
-                    part[q >> 1] = fmaf(t4.w, Ecol[4 * q + 3], part[q >> 1]);
+                const float m2 = n_m2, ro = n_ro, flo = n_flo, po = n_po;
+                // next row's LDS operands first (older than the batch below: done when it is)
+                {
+                    const int mn = min(m + 1, TM - 1);
+                    n_m2 = Md[mn * 64 + ul]; n_ro = Roff[mn]; n_flo = FLo[mn]; n_po = Poff[mn * 64 + ul];
                 }
-                // a column only uses the groups that hold predecessors of it: reference = largest exponent among groups 0 .. ul/8
-                const int gl = ul >> 3;
-                float ref = Xg[0];
-#pragma unroll
-                for (int g = 1; g < DM_NG; ++g) if (gl >= g) ref = fmaxf(ref, Xg[g]);
-                const float ro = Roff[m], flo = FLo[m];
+                // previous row of the block, broadcast: one partial sum per 8-column group (each in its group's scale).  All 18 reads go
+                // out together into their own registers (the compiler keeps ~3 in flight in 12 registers: six exposed LDS latencies a row)
+                v4f t[16], x0, x1;
+                asm volatile("ds_read_b128 %0, %18\n\t"            "ds_read_b128 %1, %18 offset:16\n\t"
+                             "ds_read_b128 %2, %18 offset:32\n\t"  "ds_read_b128 %3, %18 offset:48\n\t"
+                             "ds_read_b128 %4, %18 offset:64\n\t"  "ds_read_b128 %5, %18 offset:80\n\t"
+                             "ds_read_b128 %6, %18 offset:96\n\t"  "ds_read_b128 %7, %18 offset:112\n\t"
+                             "ds_read_b128 %8, %18 offset:128\n\t" "ds_read_b128 %9, %18 offset:144\n\t"
+                             "ds_read_b128 %10, %18 offset:160\n\t" "ds_read_b128 %11, %18 offset:176\n\t"
+                             "ds_read_b128 %12, %18 offset:192\n\t" "ds_read_b128 %13, %18 offset:208\n\t"
+                             "ds_read_b128 %14, %18 offset:224\n\t" "ds_read_b128 %15, %18 offset:240\n\t"
+                             "ds_read_b128 %16, %19\n\t"           "ds_read_b128 %17, %19 offset:16"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                               "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15]),
+                               "=&v"(x0), "=&v"(x1)
+                             : "v"(vd_addr), "v"(xd_addr) : "memory");
+                v2f acc2[DM_NG];
+                auto grp = [&](int g) {
+                    const v4f a = t[2 * g], b2 = t[2 * g + 1];
+                    v2f r = (v2f){a.x, a.y} * Ec[4 * g];
+                    r = __builtin_elementwise_fma((v2f){a.z, a.w}, Ec[4 * g + 1], r);
+                    r = __builtin_elementwise_fma((v2f){b2.x, b2.y}, Ec[4 * g + 2], r);
+                    acc2[g] = __builtin_elementwise_fma((v2f){b2.z, b2.w}, Ec[4 * g + 3], r);
+                };
+                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]) :: "memory");
+                grp(0); grp(1); grp(2);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]) :: "memory");
+                grp(3); grp(4); grp(5);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]), "+v"(x0), "+v"(x1) :: "memory");
+                grp(6); grp(7);
+                // a column only uses the groups that hold predecessors of it (`ref` = largest exponent among groups 0 .. ul / 8; the sums of
+                // the groups to its right are exactly 0, and ldexp(0, anything) = 0 where 0 * 2^(big) would be 0 * inf)
                 const float rt = fmaxf(ro, ref);
-                float Pd = 0.f;
+                const float xg[DM_NG] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                float P = ldexpf(po, (int)(ro - rt));
 #pragma unroll
-                for (int g = 0; g < DM_NG; ++g) Pd += (g <= gl) ? part[g] * dm_exp2(Xg[g] - rt) : 0.f;   // (a group right of the column has a
-                                                                                       // zero sum but may have a LARGER exponent: 0 * inf)
-                const float P = Pd + Poff[m * 64 + ul] * dm_exp2(ro - rt);
+                for (int g = 0; g < DM_NG; ++g) P += ldexpf(acc2[g].x + acc2[g].y, (int)(xg[g] - rt));
                 float a2 = __builtin_amdgcn_logf(P) + rt + m2;                                // P = 0 -> -inf
                 // ---- exactness guard.  A sum under the threshold is only trusted as "dead" when the cell has no live predecessor.
                 const int flp = min((int)fminf(flo, 1.0e9f), fl_prev);                      // first live column of the previous row (global)
@@ -605,67 +637,51 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 bool flag = in_graph && has_pred && (m2 != NEG_INF) && !(P >= 0x1p-90f && P <= 0x1p126f);
                 if (!in_graph || !has_pred) a2 = NEG_INF;
                 if (BETA && (L - 1 - u) < row(tt)) { a2 = NEG_INF; flag = false; }          // K3 only visits columns j >= t (dag_loss.cu loop bounds)
-                // (a) every live predecessor inside this block (the DP's diagonal runs through it: the cells next to the diagonal are
-                //     tens of binades per column under their right-hand neighbours, beyond any shared exponent): a handful of terms,
-                //     summed in log space from the exact row and the log weights in LDS, all flagged lanes at once
-                if (__any(flag) && flp >= ub) {
-                    if (flag) {
+                if (__any(flag)) {
+                    // (a) every live predecessor inside this block (the DP's diagonal runs through it: the cells next to the diagonal are
+                    //     tens of binades per column under their right-hand neighbours, beyond any shared exponent): a handful of terms,
+                    //     summed in log space from the exact row and the log weights in LDS, all flagged lanes at once
+                    if (flp >= ub) {
+                        if (flag) {
+                            float mx = NEG_INF, sum = 0.f;
+                            for (int i = flp - ub; i < ul; ++i) {
+                                const float x = A2d[i] + Wd[i * 64 + ul];
+                                const float nm = fmaxf(mx, x);
+                                if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
+                                mx = nm;
+                            }
+                            a2 = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx + m2);
+                            flag = false;
+                        }
+                    }
+                    u64 fm = __ballot(flag);
+                    while (fm) {                 // (b) exact log-space redo, one flagged column at a time, the wave scans its predecessors
+                        const int fu_l = (int)__builtin_ctzll(fm); fm &= fm - 1;
+                        const int fu = ub + fu_l;
+                        const int v_lo = max(__builtin_amdgcn_readfirstlane(flp), fu - TR);
                         float mx = NEG_INF, sum = 0.f;
-                        for (int i = flp - ub; i < ul; ++i) {
-                            const float x = A2d[i] + Wd[i * 64 + ul];
+                        for (int v = v_lo + lane; v < fu; v += 64) {
+                            const float x = dm_ld(O + (size_t)row(tt - 1) * L + col(v)) * DM_LOG2E + wlog2(v, fu);
                             const float nm = fmaxf(mx, x);
                             if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
                             mx = nm;
                         }
-                        a2 = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx + m2);
-                        flag = false;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const float m2o = __shfl_xor(mx, o, 64), s2o = __shfl_xor(sum, o, 64);
+                            const float nm = fmaxf(mx, m2o);
+                            sum = (nm == NEG_INF) ? 0.f : sum * dm_exp2(mx - nm) + s2o * dm_exp2(m2o - nm);
+                            mx = nm;
+                        }
+                        const float exact = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx);
+                        if (lane == fu_l) a2 = exact + m2;
+                        if (lane == fu_l) {      // diagnostics: first flagged cells of the launch (sample | dir, step, column, the distrusted sum)
+                            const u32 slot = atomicAdd(&p.counters[2], 1u);
+                            if (slot < 14) { p.counters[8 + 4 * slot] = (u32)sd | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)tt; p.counters[10 + 4 * slot] = (u32)fu; p.counters[11 + 4 * slot] = __float_as_uint(P); }
+                        }
                     }
                 }
-                u64 fm = __ballot(flag);
-                while (fm) {                     // (b) exact log-space redo, one flagged column at a time, the wave scans its predecessors
-                    const int fu_l = (int)__builtin_ctzll(fm); fm &= fm - 1;
-                    const int fu = ub + fu_l;
-                    const int v_lo = max(__builtin_amdgcn_readfirstlane(flp), fu - TR);
-                    float mx = NEG_INF, sum = 0.f;
-                    for (int v = v_lo + lane; v < fu; v += 64) {
-                        const float x = dm_ld(O + (size_t)row(tt - 1) * L + col(v)) * DM_LOG2E + wlog2(v, fu);
-                        const float nm = fmaxf(mx, x);
-                        if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
-                        mx = nm;
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float m2o = __shfl_xor(mx, o, 64), s2o = __shfl_xor(sum, o, 64);
-                        const float nm = fmaxf(mx, m2o);
-                        sum = (nm == NEG_INF) ? 0.f : sum * dm_exp2(mx - nm) + s2o * dm_exp2(m2o - nm);
-                        mx = nm;
-                    }
-                    const float exact = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx);
-                    if (lane == fu_l) a2 = exact + m2;
-                    if (lane == fu_l) {      // diagnostics: first flagged cells of the launch (sample | dir, step, column, the distrusted sum)
-                        const u32 slot = atomicAdd(&p.counters[2], 1u);
-                        if (slot < 14) { p.counters[8 + 4 * slot] = (u32)sd | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)tt; p.counters[10 + 4 * slot] = (u32)fu; p.counters[11 + 4 * slot] = __float_as_uint(P); }
-                    }
-                }
-                // ---- the row: output, next row's broadcast state, block exponent / first live column for the blocks to the right
-                if (u < L) dm_st(O + (size_t)row(tt) * L + col(u), a2 * DM_LN2);
-                a2prev = a2;
-                const float gm = dm_max8(a2);
-#pragma unroll
-                for (int g = 0; g < DM_NG; ++g) { const float x = __builtin_amdgcn_readlane(gm, 8 * g); Xg[g] = (x == NEG_INF) ? DM_SENT : ceilf(x); }
-                const float xs = (gm == NEG_INF) ? DM_SENT : ceilf(gm);            // own group's exponent (gm is uniform inside a group)
-                Vd[ul] = (a2 == NEG_INF) ? 0.f : dm_exp2(a2 - xs);               // (all reads of Vd for this row are done: same wave, program order)
-                A2d[ul] = a2;
-                const u64 lv = __ballot(a2 != NEG_INF);
-                fl_prev = lv ? (ub + (int)__builtin_ctzll(lv)) : (1 << 30);
-                if (lane == 0) {
-                    float sblk = Xg[0];
-#pragma unroll
-                    for (int g = 1; g < DM_NG; ++g) sblk = fmaxf(sblk, Xg[g]);
-                    dm_st(&S[(size_t)tt * NJ + U].x, sblk);
-                    dm_st(&S[(size_t)tt * NJ + U].y, lv ? (float)__builtin_ctzll(lv) : 64.f);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                row_end(a2, tt);
             }
             // ---- publish the chunk: everything above was stored write-through; drain, then the progress word
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -676,7 +692,6 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     }
     if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks;
                              for (int i = 0; i < 6; ++i) p.counters[44 + i] = (u32)(pf_p[i] >> 4); }
-    (void)a2prev;
 }
 
 template <int D>
