@@ -17,7 +17,7 @@ def _latest(pattern):
 
 
 def test_committed_dag_bench_line_has_the_contract_fields():
-    d = json.loads(open(_latest("r01*_bench_dag_tr32.json")).read().strip().split("\n")[-1])
+    d = json.loads(open(_latest("r02*_bench_headline.json")).read().strip().split("\n")[-1])     # `python bench.py`, the driver's command
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -33,6 +33,11 @@ def test_committed_dag_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # the headline is BASELINE.json's two-part metric: S2ST utterances/s (value) and the dag_loss fwd+bwd time of C2 beside it;
+    # ms_per_step and value describe the SAME step (B utterances per step on one GPU)
+    assert d["unit"] == "utt/s" and d["dag_loss_fwd_bwd_ms_per_batch"] > 0
+    assert abs(d["value"] - 1e3 * d["config"]["batch_per_gpu"] / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["c1"]["dag_loss_fwd_bwd_ms"] > 0 and d["c1"]["launch_status"] == 0         # BASELINE configs[0] on the HIP ops, same run
 
 
 def test_bench_cli_accepts_the_driver_flags():

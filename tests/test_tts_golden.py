@@ -262,8 +262,9 @@ def test_hifigan_v1_torch_backend_vs_reference_full_width(golden_dir):
 # Tolerance of the HIP vocoder against the REFERENCE's fp32 waveform.  The kernels keep activations in fp16 (11-bit significand) with
 # fp32 accumulation: every one of the ~50 stored layers adds a relative rounding error of 2^-12 rms to O(1) activations, which the
 # following layers carry with gain ~1 (residual units), i.e. ~sqrt(50) * 2.4e-4 ~ 2e-3 rms before conv_post + tanh (slope <= 1) — a few
-# e-3 max over ~10^4 samples of a (-1, 1) waveform.  Asserted: max < 1.5e-2, mean < 1.5e-3 (measured: see profiles/r02_hifigan_parity.txt).
-HIP_WAV_MAX_ERR, HIP_WAV_MEAN_ERR = 1.5e-2, 1.5e-3
+# e-3 max over ~10^4 samples of a (-1, 1) waveform.  Measured (profiles/r02_hifigan_parity.txt): max 1.5e-3, mean 2.6e-4 on a waveform
+# of rms 0.3 (the torch fp32 path of the same module: 1.3e-6).  Asserted with 3x headroom:
+HIP_WAV_MAX_ERR, HIP_WAV_MEAN_ERR = 5e-3, 8e-4
 
 
 @pytest.mark.gpu
