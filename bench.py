@@ -61,6 +61,7 @@ def parse():
                     help="autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (default fp32, the mode the mel parity is stated for)")
     ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"])
     ap.add_argument("--vocoder-group", type=int, default=8, help="s2st: utterances per vocoder call (length-sorted groups)")
+    ap.add_argument("--no-overlap", action="store_true", help="s2st: one batch at a time (generator.generate) instead of the two-deep batch pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
     ap.add_argument("--no-peaked", action="store_true")
@@ -120,14 +121,20 @@ class Ctx:
             return float(t.item())
         return seconds
 
-    def timed(self, step, steps, warmup):
+    def timed(self, step, steps, warmup, flush=None):
+        """`flush` drains a pipelined step (work of the last submitted batch still queued on the host side): called at the end of the
+        warm-up and INSIDE the timed region after the K-th step, so the K timed steps contain all the work of exactly K batches."""
         for i in range(warmup):
             step(i)
+        if flush is not None:
+            flush()
         self.barrier()
         t0 = time.perf_counter()
         out = None
         for i in range(steps):
             out = step(warmup + i)
+        if flush is not None:
+            flush()
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0), out
 
@@ -364,14 +371,26 @@ def build_model_step(ctx, args, workload):
         gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=args.vocoder_group)
         state["voc"] = voc
 
-        def step(i):
-            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
-                out = gen.generate(model, batches[i % len(batches)])
-            state["frames"] += sum(o["feature"].shape[0] for o in out)
+        def count(out):
+            if out is not None:
+                state["frames"] += sum(o["feature"].shape[0] for o in out)
             return out
+
+        if args.no_overlap:
+            def step(i):
+                with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                    return count(gen.generate(model, batches[i % len(batches)]))
+        else:
+            # two-deep pipeline over consecutive batches (generator.submit / flush): the vocoder of batch i-1 runs on a second stream
+            # under the launch-bound acoustic model of batch i; ctx.timed flushes inside the timed region
+            def step(i):
+                with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                    return count(gen.submit(model, batches[i % len(batches)]))
+            state["flush"] = lambda: count(gen.flush())
         wl = (f"C4 full S2ST pipeline (s2s_conformer_dag_fastspeech2 + HiFi-GAN V1), {args.decode_strategy} decode: Conformer(12L,256) -> "
               f"DA-Transformer(4L,512) + links -> HIP graph decode -> FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) "
-              f"-> HiFi-GAN V1 ({args.vocoder_backend} convs, groups of {args.vocoder_group} with per-utterance lengths), B={B}/GPU, fbank80 300-800 frames, {prec}")
+              f"-> HiFi-GAN V1 ({args.vocoder_backend} convs, groups of {args.vocoder_group} with per-utterance lengths"
+              + ("" if args.no_overlap else "; vocoder of batch i-1 on a second stream under the acoustic model of batch i") + f"), B={B}/GPU, fbank80 300-800 frames, {prec}")
     else:
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
@@ -423,7 +442,7 @@ def vocoder_roofline(ctx, args, state):
 def run_model(ctx, args, workload, steps, warmup):
     step, wl, state = build_model_step(ctx, args, workload)
     warmup = max(warmup, 2 * len(state["batches"]))      # MIOpen / hipBLASLt pick algorithms per new shape: keep that out of the timing
-    elapsed, _ = ctx.timed(step, steps, warmup)
+    elapsed, _ = ctx.timed(step, steps, warmup, flush=state.get("flush"))
     B = state["B"]
     rep = {"workload": wl, "value": ctx.world * B * steps / elapsed, "unit": "utt/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps,
            "warmup": warmup, "batch_per_gpu": B}

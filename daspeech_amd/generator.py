@@ -12,17 +12,25 @@ from torch import Tensor
 
 
 class S2SNATGenerator:
+    """`generate(model, sample)` is the reference's call (one batch, in order).  `submit` / `flush` / `generate_batches` run the same
+    two stages as a two-deep pipeline over consecutive batches: the acoustic model of batch k is ISSUED (≈14 ms of host time for ≈1000
+    small kernels at B=32 — the stage is launch bound, the GPU idles between them) while the vocoder of batch k-1 (≈50 launches, 11 ms
+    of dense MFMA work) runs on a second, lower-priority stream and fills those gaps.  Same kernels, same results, batch by batch."""
+
     def __init__(self, vocoder=None, gcmvn_mean: Optional[Tensor] = None, gcmvn_std: Optional[Tensor] = None,
                  vocoder_group: int = 8):
         self.vocoder, self.mean, self.std, self.vocoder_group = vocoder, gcmvn_mean, gcmvn_std, vocoder_group
+        self._side = None            # vocoder stream of the pipelined mode
+        self._pending = None         # acoustic stage issued, vocoder not yet: (stage-1 outputs, completion event)
+        self._inflight = None        # vocoder issued on the side stream: (results, completion event)
 
     def gcmvn_denormalize(self, x: Tensor) -> Tensor:
         if self.mean is None:
             return x
         return x * self.std.view(1, 1, -1).to(x) + self.mean.view(1, 1, -1).to(x)
 
-    @torch.no_grad()
-    def generate(self, model, sample: Dict, generate_waveform: bool = True) -> List[Dict[str, Tensor]]:
+    # ---- stage 1: fbank -> mel (forward_encoder -> graph decode -> adaptor -> tts; s2s_nat_generator.py:49-258), no host sync
+    def _acoustic(self, model, sample: Dict) -> Dict[str, Tensor]:
         net = sample["net_input"]
         enc = model.forward_encoder(net["src_tokens"], net["src_lengths"])
         # the encoder's 4x subsampling keeps lengths on the device; the padded frame count is a host integer already
@@ -30,36 +38,111 @@ class S2SNATGenerator:
         dec = model.forward_decoder(prev, enc)
         tts_in = model.adaptor(dec["features"])
         mel, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
-        mel = self.gcmvn_denormalize(mel)
+        return {"mel": self.gcmvn_denormalize(mel), "out_lens": out_lens, "tokens": dec["output_tokens"]}
+
+    # ---- stage 2: mel -> waveforms on the CURRENT stream; `lens` = out_lens on the host
+    def _vocode(self, mel: Tensor, out_lens: Tensor, lens: List[int]) -> List[Optional[Tensor]]:
         hop = getattr(self.vocoder, "hop", 256)
-        lens = out_lens.tolist()
-        wavs = [None] * len(lens)
-        if generate_waveform and self.vocoder is not None and mel.shape[1] > 0:
-            # vocode in length-sorted groups: the batch is padded to each GROUP's maximum, not the batch maximum
-            # (the reference vocodes one file at a time, hifi-gan/inference_e2e.py:47-56)
-            # (sorted and regrouped on the device: the only host data needed are the lengths fetched above)
-            order = sorted(range(len(lens)), key=lambda i: lens[i])
-            dev_order = torch.argsort(out_lens, stable=True)
-            mel_sorted = mel.index_select(0, dev_order)
-            len_sorted = out_lens.index_select(0, dev_order)
-            gsz = max(1, self.vocoder_group)
-            for g0 in range(0, len(order), gsz):
-                idx = order[g0:g0 + gsz]
-                gmax = max(1, max(lens[i] for i in idx))
-                sub = mel_sorted[g0:g0 + gsz, :gmax]
-                fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= len_sorted[g0:g0 + gsz].unsqueeze(1)
-                # per-utterance lengths go down to the vocoder: each utterance's samples are those of vocoding it alone
-                w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2), lengths=len_sorted[g0:g0 + gsz].clamp(min=1)).squeeze(1)
-                for k, i in enumerate(idx):
-                    wavs[i] = w[k, : max(lens[i], 1) * hop]
-        res = []
+        wavs: List[Optional[Tensor]] = [None] * len(lens)
+        if self.vocoder is None or mel.shape[1] == 0:
+            return wavs
+        # vocode in length-sorted groups: the batch is padded to each GROUP's maximum, not the batch maximum
+        # (the reference vocodes one file at a time, hifi-gan/inference_e2e.py:47-56)
+        # (sorted and regrouped on the device: the only host data needed are the lengths)
+        order = sorted(range(len(lens)), key=lambda i: lens[i])
+        dev_order = torch.argsort(out_lens, stable=True)
+        mel_sorted = mel.index_select(0, dev_order)
+        len_sorted = out_lens.index_select(0, dev_order)
+        gsz = max(1, self.vocoder_group)
+        for g0 in range(0, len(order), gsz):
+            idx = order[g0:g0 + gsz]
+            gmax = max(1, max(lens[i] for i in idx))
+            sub = mel_sorted[g0:g0 + gsz, :gmax]
+            fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= len_sorted[g0:g0 + gsz].unsqueeze(1)
+            # per-utterance lengths go down to the vocoder: each utterance's samples are those of vocoding it alone
+            w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2), lengths=len_sorted[g0:g0 + gsz].clamp(min=1)).squeeze(1)
+            for k, i in enumerate(idx):
+                wavs[i] = w[k, : max(lens[i], 1) * hop]
+        return wavs
+
+    @staticmethod
+    def _assemble(ac: Dict[str, Tensor], lens: List[int], wavs: List[Optional[Tensor]]) -> List[Dict[str, Tensor]]:
+        mel, res = ac["mel"], []
         for b, n in enumerate(lens):
             feat = mel[b, :n] if n > 0 else mel.new_zeros(1, mel.shape[-1])              # zeros[1,80] when empty (:263)
-            item = {"tokens": dec["output_tokens"][b], "feature": feat}
+            item = {"tokens": ac["tokens"][b], "feature": feat}
             if wavs[b] is not None:
                 item["waveform"] = wavs[b]
             res.append(item)
         return res
+
+    @torch.no_grad()
+    def generate(self, model, sample: Dict, generate_waveform: bool = True) -> List[Dict[str, Tensor]]:
+        ac = self._acoustic(model, sample)
+        lens = ac["out_lens"].tolist()
+        wavs = self._vocode(ac["mel"], ac["out_lens"], lens) if generate_waveform else [None] * len(lens)
+        return self._assemble(ac, lens, wavs)
+
+    # ------------------------------------------------------------------------------------------------ pipelined over batches
+    def _issue_vocoder_of_pending(self):
+        ac, ev = self._pending
+        self._pending = None
+        ev.synchronize()                                   # the host needs the mel lengths of that batch
+        lens = ac["out_lens"].tolist()
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            least, _greatest = torch.cuda.Stream.priority_range()
+            self._side = torch.cuda.Stream(device=ac["mel"].device, priority=least)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            wavs = self._vocode(ac["mel"], ac["out_lens"], lens)
+            vev = torch.cuda.Event()
+            vev.record(self._side)
+        for t in (ac["mel"], ac["out_lens"]):
+            t.record_stream(self._side)                    # allocated on the main stream, read on the side stream
+        for w in wavs:
+            if w is not None:
+                w.record_stream(main)                      # and the other way round for the consumer
+        self._inflight = (self._assemble(ac, lens, wavs), vev)
+
+    @torch.no_grad()
+    def submit(self, model, sample: Dict) -> Optional[List[Dict[str, Tensor]]]:
+        """Feed the next batch; returns the finished results of the PREVIOUS batch (None for the first).  The current stream is made to
+        wait for their vocoder, so they can be used on it without further synchronisation."""
+        done = None
+        if self._pending is not None:
+            self._issue_vocoder_of_pending()               # vocoder(k-1) is queued before the long host-side issue of acoustic(k)
+            done = self._inflight
+        ac = self._acoustic(model, sample)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._pending = (ac, ev)
+        if done is None:
+            return None
+        self._inflight = None
+        torch.cuda.current_stream().wait_event(done[1])
+        return done[0]
+
+    @torch.no_grad()
+    def flush(self) -> Optional[List[Dict[str, Tensor]]]:
+        """Vocode and return the last submitted batch (None if nothing is pending)."""
+        if self._pending is None:
+            return None
+        self._issue_vocoder_of_pending()
+        res, vev = self._inflight
+        self._inflight = None
+        torch.cuda.current_stream().wait_event(vev)
+        return res
+
+    def generate_batches(self, model, samples):
+        """for results in generator.generate_batches(model, batch_iterable): ...  — same results as calling generate() per batch."""
+        for sample in samples:
+            out = self.submit(model, sample)
+            if out is not None:
+                yield out
+        out = self.flush()
+        if out is not None:
+            yield out
 
 
 MAX_WAV_VALUE = 32768.0          # hifi-gan/meldataset.py:13, inference_e2e.py:52

@@ -156,6 +156,38 @@ def test_generator_end_to_end():
         assert torch.isfinite(o["waveform"]).all()
 
 
+def test_generator_batch_pipeline_equals_one_batch_at_a_time():
+    """generator.generate_batches / submit / flush (vocoder of batch k-1 on a second stream under the acoustic model of batch k) returns,
+    batch by batch and in order, what generate() returns.  The library GEMMs of the acoustic model are not run-to-run deterministic
+    (two generate() calls differ by ~1e-6 in the mel, tools/gen_det_check.py), so: tokens identical, mel within 1e-5 of the
+    one-at-a-time run — and each returned waveform is, BIT FOR BIT, the vocoding of the returned mel alone on the main stream, which a
+    race between the streams (allocator reuse, the vocoder's cached workspace) would break."""
+    from daspeech_amd.generator import S2SNATGenerator
+    from daspeech_amd.models import HiFiGANGenerator
+    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
+    m = calibrate_synthetic_weights(small_model().eval())
+    voc = HiFiGANGenerator(conv_backend="hip").cuda().eval()
+    gen = S2SNATGenerator(voc, torch.zeros(80), torch.ones(80), vocoder_group=2)
+    batches = [make_s2st_batch(3, "cuda", seed=20 + i, min_frames=90 + 10 * i, max_frames=150) for i in range(4)]
+    want = [gen.generate(m, s) for s in batches]
+    torch.cuda.synchronize()
+    for rep in range(2):                               # twice: the side stream and the vocoder's cached buffers are reused
+        got = list(gen.generate_batches(m, batches))
+        assert len(got) == len(want)
+        for gb, wb in zip(got, want):
+            assert len(gb) == len(wb)
+            for g, w in zip(gb, wb):
+                assert torch.equal(g["tokens"], w["tokens"]) and g["feature"].shape == w["feature"].shape
+                torch.testing.assert_close(g["feature"], w["feature"], rtol=0, atol=1e-5)
+                torch.testing.assert_close(g["waveform"], w["waveform"], rtol=0, atol=1e-3)
+        torch.cuda.synchronize()
+        for gb in got:
+            for g in gb:
+                alone = voc(g["feature"].t().unsqueeze(0).contiguous())[0, 0]
+                assert torch.equal(alone, g["waveform"])
+    assert gen.flush() is None and gen.submit(m, batches[0]) is None and len(gen.flush()) == 3
+
+
 def test_split_gemm_inference_matches_torch_fp32_within_mel_tolerance():
     """The eval-mode inference path runs its Linear layers and FFT convolutions as fp32-accurate split GEMMs on the fp16 matrix cores
     (decode_ops.split_linear / SplitConv1d).  Same batch through the released architecture with the path on and off: same decoded
