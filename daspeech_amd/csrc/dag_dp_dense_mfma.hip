@@ -737,7 +737,7 @@ static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
     return check_launch("dag_loss_fwd(dense mfma)");
 }
 
-static int g_dm_depth = 0;
+static thread_local int g_dm_depth = 0;      // (diagnostic switches are per calling thread, like dp_path)
 void set_dm_depth(int v) { g_dm_depth = v; }
 
 int launch_dag_dense_mfma(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,

@@ -351,7 +351,7 @@ int k5_diag(unsigned int* out) {
 bool grad_dense_supported(int L, int TR);
 int launch_dag_grad_links_dense(const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, int, hipStream_t);
 
-static int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
+static thread_local int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
 void set_k5_path(int v) { g_k5_path = v; }
 
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,

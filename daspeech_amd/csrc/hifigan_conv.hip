@@ -96,6 +96,12 @@ __global__ __launch_bounds__(512) void hifigan_conv_kernel(HgParams p)
     const int m0 = blockIdx.y * MT;
     const int R = NT + (p.max_shift - p.min_shift);
     const _Float16* X = p.x + (size_t)b * p.T * CI;
+    // A tile whose outputs all lie past the sample's valid length is never read by anyone (every consumer clamps at ITS valid input
+    // length = this layer's valid output length): with per-sample lengths a padded batch costs the sum of the lengths, not B * max.
+    if (p.lens) {
+        const int Tb = hg_valid_len(p.lens, p.len_mul, b, p.T);
+        if (p.out_mode == DSP_HG_OUT_UPSAMPLE ? (t0 * p.up_u - p.up_pad >= Tb * p.up_u) : (t0 >= Tb)) return;
+    }
 
     // ---- stage lrelu(x) tile: rows t0+min_shift .. t0+NT-1+max_shift, zero outside [0,T) ----
     hg_stage_tile<CI, 6>(smem, X, hg_valid_len(p.lens, p.len_mul, b, p.T), t0 + p.min_shift, R, p.pre_slope, (p.dbg & 1) != 0, tid);
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(512) void hifigan_resunit_kernel(HgUnitParams p)
     const _Float16 slope = (_Float16)p.slope;
 
     const int Tb = hg_valid_len(p.lens, p.len_mul, b, p.T);
+    if (t0 >= Tb) return;                             // (see hifigan_conv_kernel: nobody reads past the valid length)
     hg_stage_tile<C, 6>(xin, X, Tb, t0 - 8 - h1, R1, p.slope, false, tid);
     __syncthreads();
 
@@ -450,6 +457,7 @@ __global__ __launch_bounds__(256) void hg_post_kernel(const _Float16* __restrict
     const _Float16* X = x + (size_t)b * T * C;
     const int Tb = hg_valid_len(lens, len_mul, b, T);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        if (t >= Tb) { wav[(size_t)b * T + t] = 0.f; continue; }       // past the utterance: silence (the layers above skipped it)
         float acc = bias;
         for (int k = 0; k < K; ++k) {
             const int tt = t + k - (K - 1) / 2;
