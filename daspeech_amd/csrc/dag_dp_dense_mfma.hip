@@ -200,7 +200,6 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         }
     const int lr = lane & 15, lq = lane >> 4;
     const bool prof = (p.dbg & 2) && sd == 0 && U == p.NJ - 1;
-    u64 pf_p[6] = {0, 0, 0, 0, 0, 0};
     u64 pf_ready = 0, pf_gemm = 0, pf_diag = 0, pf_last = prof ? __builtin_amdgcn_s_memtime() : 0;
     auto stamp = [&](u64& acc) { if (prof) { const u64 t = __builtin_amdgcn_s_memtime(); acc += t - pf_last; pf_last = t; } };
     for (int c = 0; c < nchunks; ++c) {
@@ -525,7 +524,6 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             };
             auto step = [&](auto SC, int V) {
                 constexpr int s = decltype(SC)::value;
-                stamp(pf_gemm);
                 if (V < U && !st_ok[s]) {
                     ensure_ready(V); prefetchA(SC, V);
                     // (consumed here, so that the wait for this re-request sits inside the branch: at the join the compiler must otherwise
@@ -534,17 +532,15 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 }
                 const bool live = V < U && stage_live(SC);
                 const int W = V + D, Wc = min(W, U - 1);
-                if (have && live && chunk_full && e_full(V)) { fused_step(SC, V, Wc); stamp(pf_p[1]); return; }      // (e_full(V) => e_full(Wc))
-                stamp(pf_p[0]);                                               // (DSP_DEBUG=prof) wait for the stage's loads
+                // (no per-step time stamps: one s_memtime + s_waitcnt costs 0.2 - 0.6 us under load, more than the step's own phases —
+                //  DSP_DEBUG=prof accounts per chunk: readiness waits / products / diagonal block)
+                if (have && live && chunk_full && e_full(V)) { fused_step(SC, V, Wc); return; }      // (e_full(V) => e_full(Wc))
                 if (have) mfma_issue(cur);
                 if (live) commit(SC, V, cur ^ 1);
-                stamp(pf_p[2]);
                 prefetchE(SC, Wc);
                 prefetchA(SC, Wc);
                 st_ok[s] = W <= ready_hi;
-                stamp(pf_p[3]);
                 if (have || live) __syncthreads();
-                stamp(pf_p[5]);
                 if (live) cur ^= 1;
                 have = live;
             };
@@ -690,8 +686,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         __syncthreads();
         stamp(pf_diag);
     }
-    if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks;
-                             for (int i = 0; i < 6; ++i) p.counters[44 + i] = (u32)(pf_p[i] >> 4); }
+    if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks; }
 }
 
 template <int D>
