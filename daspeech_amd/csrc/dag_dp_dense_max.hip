@@ -57,12 +57,12 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_ticket;
-    float* At = smem;                                  // [16][64]   source rows (previous DP row of block V), row-major
-    float* Wt = At + DX_TM * 64;                       // [64][65]   weights [k = source][n = column]
-    float* Sb = Wt + 64 * DX_WP;                       // [16]       block maximum per source row
-    float* Poff = Sb + DX_TM;                          // [16][64]   off-diagonal maxima of the tile
-    float* Vd = Poff + DX_TM * 64;                     // [64]       diagonal block: previous row
-    float* Md = Vd + 64;                               // [16][64]   the chunk's emissions
+    float* At = smem;                                  // [2][16][64]   source rows (previous DP row of block V), row-major
+    float* Wt = At + 2 * DX_TM * 64;                   // [2][64][65]   weights [k = source][n = column]
+    float* Sb = Wt + 2 * 64 * DX_WP;                   // [2][16]       block maximum per source row
+    float* Poff = Sb + 2 * DX_TM;                      // [16][64]      off-diagonal maxima of the tile
+    float* Vd = Poff + DX_TM * 64;                     // [64]          diagonal block: previous row
+    float* Md = Vd + 64;                               // [16][64]      the chunk's emissions
     int* RDY = reinterpret_cast<int*>(Md + DX_TM * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
@@ -82,33 +82,53 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
         for (int ul = tid; ul < DX_BW; ul += 256) { const int u = ub + ul; if (u < L) O[(size_t)t * L + u] = NEG_INF; }
     if (!valid) return;
     // weight of the transition v -> u (v < u): links[v][u-v-1]; unconditional load at a clamped address, masked afterwards
-    auto wraw = [&](int v, int u) -> float {
-        const int d = u - v - 1;
-        const bool ok = !(d < 0 || d >= TR || u >= L || v < 0);
-        const float raw = K[ok ? ((size_t)v * TR + d) : (size_t)0];
-        return ok ? raw : NEG_INF;
-    };
+    // (32-bit indices: dense_max_supported bounds L * TR)
+    auto w_ok = [&](int v, int u) -> bool { const int d = u - v - 1; return !(d < 0 || d >= TR || u >= L || v < 0); };
+    auto w_idx = [&](int v, int u) -> unsigned { return w_ok(v, u) ? (unsigned)(v * TR + (u - v - 1)) : 0u; };
     const int nchunks = (Tb + DX_TM - 1) / DX_TM;
 
     // ---- diagonal-block state of wave 0 (lane = column) and the seed row
     const int ul = lane, u = ub + lane;
     float Wcol[64];
-    float aprev = NEG_INF;
     if (wave == 0) {
+        // all 64 requests first, unguarded (a guarded load is an exec-masked block with its own s_waitcnt vmcnt(0): 64 serialized round
+        // trips at the head of every block's critical path — dag_dp_dense_mfma.hip found the same)
 #pragma unroll
-        for (int i = 0; i < 64; ++i) Wcol[i] = (i < ul) ? wraw(ub + i, u) : NEG_INF;
-        aprev = (u == 0) ? M[0] : NEG_INF;                                 // alpha_max[0,0] = match[0,0]   (dag_best_alignment.cu:72-74)
-        if (u < L) dx_st(O + u, aprev);
-        Vd[ul] = aprev;
-        const float bm = dx_wave_max(aprev);
+        for (int i = 0; i < 64; ++i) Wcol[i] = K[w_idx(ub + i, u)];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) Wcol[i] = w_ok(ub + i, u) ? Wcol[i] : NEG_INF;
+        const float a0 = (u == 0) ? M[0] : NEG_INF;                        // alpha_max[0,0] = match[0,0]   (dag_best_alignment.cu:72-74)
+        if (u < L) dx_st(O + u, a0);
+        Vd[ul] = a0;
+        const float bm = dx_wave_max(a0);
         if (lane == 0) dx_st(&S[U], bm);
     }
     __syncthreads();
 
-    const int n = tid & 63, mg = tid >> 6;             // product phase: column n of the block, rows 4 mg .. 4 mg + 3 of the chunk
+    // product phase: a thread owns column n of the block and rows 4 mg .. 4 mg + 3 of the chunk
+    const int n = tid & 63, mg = tid >> 6;
+    // loop-invariant offsets of the predicate-free loads (full tiles): weight element (it, e) = source row k = 16 mg + 4 it + e, column n
+    unsigned offW[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) offW[i] = (unsigned)((16 * mg + i) * (TR - 1) + ub + n - 1);          // links[vb + k][ub + n - vb - k - 1]
     for (int c = 0; c < nchunks; ++c) {
         const int tt0 = c * DX_TM;
         float acc[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        // the chunk's emissions, 4 per thread, requested now and parked in LDS after the products
+        float em[4];
+        {
+            const int m = tid >> 4, q4 = tid & 15, tt = tt0 + m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ue = ub + 4 * q4 + e;
+                const bool ok = tt >= 1 && tt < Tb && ue < L;
+                const float raw = M[ok ? (unsigned)(tt * L + ue) : 0u];
+                em[e] = ok ? raw : NEG_INF;
+            }
+        }
+        const bool chunk_full = tt0 >= 1 && tt0 + DX_TM <= Tb;
+        const unsigned offS = (unsigned)((tt0 + (tid & 15) - 1) * NJ), offA = (unsigned)((tt0 + (tid >> 4) - 1) * L + 4 * (tid & 15));
+        auto row_ok = [&](int m) -> bool { const int tt = tt0 + m; return tt >= 1 && tt < Tb; };
         if (U > 0) {
             const u32 want = p.tag_base + (u32)c + 1u;
             int ready_hi = -1;
@@ -132,87 +152,121 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
             };
             int Vmin = 0;
             { const int lim = ub - TR - DX_BW; if (lim >= 0) Vmin = lim / DX_BW + 1; }
-            float st_s = NEG_INF, st_a[4], st_w[16];
-            auto prefetch = [&](int V) {
-                const int vb = V * DX_BW;
-                if (tid < DX_TM) {
-                    const int tt = tt0 + tid;
-                    const bool ok = tt >= 1 && tt < Tb;
-                    const float sx = dx_ld(&S[ok ? ((size_t)(tt - 1) * NJ + V) : (size_t)0]);
-                    st_s = ok ? sx : NEG_INF;
-                }
-                {
-                    const int m = tid >> 4, q4 = tid & 15;                   // A: row m, source columns 4 q4 .. +3
-                    const int tt = tt0 + m;
+            // Two register stages of RAW loaded words (block maximum of row tid % 16, 4 alpha_max values of row tid / 16, 16 weights),
+            // unconditional requests, validity recomputed at conversion time, two LDS buffers and one barrier per source block, readiness
+            // waited for only at need — the pipeline of dag_dp_dense_mfma.hip (its header explains each point).
+            float st_s[2], st_a[2][4], st_w[2][16];
+            bool st_ok[2];
+            auto w_full = [&](int V) -> bool { return (ub + 63 < L) && (ub + 62 - V * DX_BW < TR); };
+            auto prefetchW = [&](int s, int V) {
+                if (w_full(V)) {
+                    const float* Kv = K + (size_t)(V * DX_BW) * (size_t)(TR - 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int v = vb + 4 * q4 + e;
-                        const bool ok = tt >= 1 && tt < Tb && v < L;
-                        const float raw = dx_ld(O + (ok ? ((size_t)(tt - 1) * L + v) : (size_t)0));
-                        st_a[e] = ok ? raw : NEG_INF;
-                    }
-                }
+                    for (int i = 0; i < 16; ++i) st_w[s][i] = Kv[offW[i]];
+                } else {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {                             // W: source row k = (tid >> 6) * 16 + 4 it + e, column n = tid & 63
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) st_w[4 * it + e] = wraw(vb + (tid >> 6) * 16 + 4 * it + e, ub + (tid & 63));
+                    for (int i = 0; i < 16; ++i) st_w[s][i] = K[w_idx(V * DX_BW + 16 * mg + i, ub + n)];
                 }
             };
-            if (Vmin < U) { ensure_ready(Vmin); prefetch(Vmin); }
-            for (int V = Vmin; V < U; ++V) {
-                if (tid < DX_TM) Sb[tid] = st_s;
-                __syncthreads();
-                bool any_live = false;
+            auto prefetchA = [&](int s, int V) {
+                const int vb = V * DX_BW;
+                if (chunk_full) {
+                    st_s[s] = dx_ld(S + offS + V);
+                    const float* Ov = O + vb;
 #pragma unroll
-                for (int m = 0; m < DX_TM; ++m) any_live |= (Sb[m] != NEG_INF);
-                if (any_live) {
-                    const int m = tid >> 4, q4 = tid & 15;
-                    *reinterpret_cast<v4f*>(At + m * 64 + 4 * q4) = (v4f){st_a[0], st_a[1], st_a[2], st_a[3]};
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) Wt[((tid >> 6) * 16 + 4 * it + e) * DX_WP + (tid & 63)] = st_w[4 * it + e];
+                    for (int e = 0; e < 4; ++e) st_a[s][e] = dx_ld(Ov + offA + e);
+                    return;
                 }
-                __syncthreads();
-                if (V + 1 < U) { ensure_ready(V + 1); prefetch(V + 1); }
-                if (any_live) {
-                    // (+, max) product: acc[r] = max_k ( A[4 mg + r][k] + W[k][n] )
+                {
+                    const int m = tid & 15;
+                    st_s[s] = dx_ld(&S[row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u]);
+                }
+                const int m = tid >> 4, q4 = tid & 15;                       // A: row m, source columns 4 q4 .. +3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = vb + 4 * q4 + e;
+                    st_a[s][e] = dx_ld(O + ((row_ok(m) && v < L) ? (unsigned)((tt0 + m - 1) * L + v) : 0u));
+                }
+            };
+            auto stage_live = [&](int s) -> bool { return __any(row_ok(tid & 15) && st_s[s] != NEG_INF); };   // lanes 0..15 of every wave: all 16 rows
+            auto commit = [&](int s, int V, int nb) {
+                const int vb = V * DX_BW;
+                if (tid < DX_TM) Sb[nb * DX_TM + tid] = row_ok(tid) ? st_s[s] : NEG_INF;
+                {
+                    const int m = tid >> 4, q4 = tid & 15;
+                    v4f a4;
+                    if (chunk_full) {                                    // (source columns of a block V < U are always inside the graph)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a4[e] = st_a[s][e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a4[e] = (row_ok(m) && (vb + 4 * q4 + e) < L) ? st_a[s][e] : NEG_INF;
+                    }
+                    *reinterpret_cast<v4f*>(At + nb * DX_TM * 64 + m * 64 + 4 * q4) = a4;
+                }
+                float* Wb = Wt + nb * 64 * DX_WP;
+                if (w_full(V)) {                                         // full tile: no predicates at all
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = st_w[s][i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = w_ok(vb + 16 * mg + i, ub + n) ? st_w[s][i] : NEG_INF;
+                }
+            };
+            auto product = [&](int nb) {       // (+, max) product: acc[r] = max_k ( A[4 mg + r][k] + W[k][n] )
+                const float* Ab = At + nb * DX_TM * 64; const float* Wb = Wt + nb * 64 * DX_WP;
 #pragma unroll 4
-                    for (int kk = 0; kk < 16; ++kk) {
-                        v4f a4[4];
+                for (int kk = 0; kk < 16; ++kk) {
+                    v4f a4[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a4[r] = *reinterpret_cast<const v4f*>(At + (4 * mg + r) * 64 + 4 * kk);      // broadcast
-                        const float w0 = Wt[(4 * kk) * DX_WP + n], w1 = Wt[(4 * kk + 1) * DX_WP + n];
-                        const float w2 = Wt[(4 * kk + 2) * DX_WP + n], w3 = Wt[(4 * kk + 3) * DX_WP + n];
+                    for (int r = 0; r < 4; ++r) a4[r] = *reinterpret_cast<const v4f*>(Ab + (4 * mg + r) * 64 + 4 * kk);      // broadcast
+                    const float w0 = Wb[(4 * kk) * DX_WP + n], w1 = Wb[(4 * kk + 1) * DX_WP + n];
+                    const float w2 = Wb[(4 * kk + 2) * DX_WP + n], w3 = Wb[(4 * kk + 3) * DX_WP + n];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[r] = fmaxf(fmaxf(acc[r], a4[r].x + w0), a4[r].y + w1);
-                            acc[r] = fmaxf(fmaxf(acc[r], a4[r].z + w2), a4[r].w + w3);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] = fmaxf(fmaxf(acc[r], a4[r].x + w0), a4[r].y + w1);
+                        acc[r] = fmaxf(fmaxf(acc[r], a4[r].z + w2), a4[r].w + w3);
                     }
                 }
-                __syncthreads();
+            };
+            int cur = 0; bool have = false;
+            auto step = [&](int s, int V) {
+                if (V < U && !st_ok[s]) {
+                    ensure_ready(V); prefetchA(s, V);
+                    asm volatile("" :: "v"(st_a[s][3]), "v"(st_a[s][0]), "v"(st_s[s]) : "memory");      // the wait for the re-request stays in this branch
+                }
+                const bool live = V < U && stage_live(s);
+                if (live) commit(s, V, cur ^ 1);
+                const int W = V + 2, Wc = min(W, U - 1);
+                prefetchW(s, Wc); prefetchA(s, Wc);
+                st_ok[s] = W <= ready_hi;
+                if (have) product(cur);
+                if (have || live) __syncthreads();
+                if (live) cur ^= 1;
+                have = live;
+            };
+            {
+                const int W0 = Vmin, W1 = min(Vmin + 1, U - 1);
+                prefetchW(0, W0); ensure_ready(Vmin); prefetchA(0, W0); st_ok[0] = W0 <= ready_hi;
+                prefetchW(1, W1); prefetchA(1, W1); st_ok[1] = (Vmin + 1) <= ready_hi;
             }
+            for (int Vb = Vmin; Vb < U; Vb += 2) { step(0, Vb); step(1, Vb + 1); }
+            if (have) product(cur);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) Poff[(4 * mg + r) * 64 + n] = acc[r];
+        *reinterpret_cast<v4f*>(Md + (tid >> 4) * 64 + 4 * (tid & 15)) = (v4f){em[0], em[1], em[2], em[3]};
         __syncthreads();
 
         // ================================================================ diagonal block, row by row (wave 0)
         if (wave == 0) {
-            {
-                float mrow[DX_TM];
-#pragma unroll
-                for (int m = 0; m < DX_TM; ++m) { const int tt = tt0 + m; mrow[m] = (tt >= 1 && tt < Tb && u < L) ? M[(size_t)tt * L + u] : NEG_INF; }
-#pragma unroll
-                for (int m = 0; m < DX_TM; ++m) Md[m * 64 + ul] = mrow[m];
-            }
+            const int m_lo = (tt0 == 0) ? 1 : 0, m_hi = min(DX_TM, Tb - tt0);
+            float n_po = Poff[m_lo * 64 + ul], n_m = Md[m_lo * 64 + ul];
 #pragma unroll 1
-            for (int m = 0; m < DX_TM; ++m) {
+            for (int m = m_lo; m < m_hi; ++m) {
                 const int tt = tt0 + m;
-                if (tt == 0) continue;
-                if (tt >= Tb) break;
-                float best = Poff[m * 64 + ul];
+                float best = n_po; const float mm = n_m;
+                { const int mn = min(m + 1, DX_TM - 1); n_po = Poff[mn * 64 + ul]; n_m = Md[mn * 64 + ul]; }       // next row's operands
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const v4f t4 = *reinterpret_cast<const v4f*>(Vd + 4 * q);
@@ -220,20 +274,17 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
                     best = fmaxf(fmaxf(best, t4.z + Wcol[4 * q + 2]), t4.w + Wcol[4 * q + 3]);
                 }
                 // cells outside t <= j < L_b have no live predecessor / only -inf links: -inf by the arithmetic alone
-                const float a = best + Md[m * 64 + ul];                       // mx + match   (dag_best_alignment.cu:120)
+                const float a = best + mm;                                     // mx + match   (dag_best_alignment.cu:120)
                 if (u < L) dx_st(O + (size_t)tt * L + u, a);
-                aprev = a;
                 Vd[ul] = a;                                                   // (this row's reads are done: same wave, program order)
                 const float bm = dx_wave_max(a);
                 if (lane == 0) dx_st(&S[(size_t)tt * NJ + U], bm);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog + U, p.tag_base + (u32)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
-    (void)aprev;
 }
 
 // K7 without a trace tensor: path[b][pos] = t along the chain of arg-max predecessors from (T_b-1, L_b-1), the arg-max recomputed from
@@ -261,9 +312,24 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_kernel(const float* _
             if (t == 0) break;
             const int lo = max(t - 1, pos - TR);
             float best = NEG_INF; int arg = 1 << 30;
-            for (int i = lo + tid; i < pos; i += 256) {                   // ascending i per thread, strict >: the thread's smallest index
-                const float v = A[(size_t)(t - 1) * L + i] + K[(size_t)i * TR + (pos - i - 1)];
-                if (v > best) { best = v; arg = i; }
+            // 8 predecessors per thread and pass, all 16 loads requested before the first compare (unconditional, clamped: a loop of
+            // guarded load -> compare pays one memory round trip per predecessor, and the hop is the back-trace's critical path)
+            const float* Arow = A + (size_t)(t - 1) * L;
+            for (int i0 = lo + tid; i0 < pos; i0 += 8 * 256) {
+                float av[8], kv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = i0 + 256 * e;
+                    const bool ok = i < pos;
+                    av[e] = Arow[ok ? i : 0];
+                    kv[e] = K[ok ? ((size_t)i * TR + (pos - i - 1)) : (size_t)0];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {                                 // ascending i per thread, strict >: the thread's smallest index
+                    const int i = i0 + 256 * e;
+                    const float v = (i < pos) ? av[e] + kv[e] : NEG_INF;
+                    if (v > best) { best = v; arg = i; }
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -287,7 +353,7 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_kernel(const float* _
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
-bool dense_max_supported(int L, int TR) { return TR > 64 && L >= 128 && (size_t)L * 4 <= 150 * 1024; }
+bool dense_max_supported(int L, int TR) { return TR > 64 && L >= 128 && (size_t)L * 4 <= 150 * 1024 && (long)L * TR < (1L << 31); }
 
 int launch_dag_dense_max(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                          float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
@@ -303,7 +369,7 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     if (rc) return rc;
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float*>(reinterpret_cast<char*>(area) + prog_bytes);
-    const size_t lds = (size_t)(DX_TM * 64 + 64 * DX_WP + DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4) * 4 + 64;
+    const size_t lds = (size_t)(2 * DX_TM * 64 + 2 * 64 * DX_WP + 2 * DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4) * 4 + 64;
     (void)hipFuncSetAttribute((const void*)dag_dense_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dag_dense_max_kernel, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");

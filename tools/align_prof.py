@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""dag_best_alignment only, at a dense shape (default C1), in a loop: for rocprofv3 --kernel-trace --stats (max-DP vs back-trace split)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from daspeech_amd import custom_ops as ops
+B, T, L, TR = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (4, 256, 2048, 2047)))
+g = torch.Generator(device="cuda").manual_seed(0)
+match = torch.randn(B, T, L, device="cuda", generator=g) * 2 - 6
+ol = torch.full((B,), L, device="cuda"); tl = torch.full((B,), T, device="cuda")
+i = torch.arange(L, device="cuda").view(1, L, 1); d = torch.arange(TR, device="cuda").view(1, 1, TR)
+links = torch.empty(B, L, TR, device="cuda")
+for b in range(B):
+    raw = torch.randn(1, L, TR, device="cuda", generator=g)
+    valid = (i + d + 1) < L
+    links[b:b + 1] = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1).masked_fill(~valid, float("-inf"))
+for _ in range(3): ops.dag_best_alignment(match, links, ol, tl)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): ops.dag_best_alignment(match, links, ol, tl)
+e1.record(); torch.cuda.synchronize()
+print(f"dag_best_alignment B={B} T={T} L={L} TR={TR}: {e0.elapsed_time(e1) / 10:.3f} ms")
