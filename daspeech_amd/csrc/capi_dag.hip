@@ -28,6 +28,7 @@ int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t
 bool dense_mfma_supported(int L, int TR);
 int launch_dag_dense_mfma(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 void set_dm_depth(int v);
+void set_dm_mt(int v);
 
 bool dense_max_supported(int L, int TR);
 int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
@@ -215,6 +216,7 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_depth")) { set_dm_depth(value); return DSP_OK; }
+    if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");
     return DSP_EINVAL;

@@ -10,7 +10,7 @@
 //     P[t][j] = sum_{I < J} 2^(s[t-1][I]) * ( A[t-1][I-block] . E[I-block][J-block] )[j]            <- OFF-DIAGONAL: plain GEMMs over 16 rows t
 //             + sum_{i in J, i < j} 2^(a2[t-1][i]) E[i][j]                                          <- DIAGONAL block: sequential in t
 //     a2[t][j] = log2 P[t][j] + match2[t][j]
-// For a column block J and a chunk of 16 rows all off-diagonal products need only rows of blocks I < J, which are complete when
+// For a column block J and a chunk of 16 MT rows (MT = 2) all off-diagonal products need only rows of blocks I < J, which are complete when
 // block J-1 has finished the same chunk — so block J runs one chunk behind block J-1 (a wavefront over (chunk, block)), and inside
 // a tile the [16 x 64] . [64 x 64] products run on v_mfma_f32_16x16x4_f32: exact f32 arithmetic (an fmaf chain), 1/16 of the VALU
 // work per term gone to the matrix pipe, one exp per matrix ELEMENT per chunk instead of one per term, and the transition matrix is
@@ -86,22 +86,20 @@ constexpr int DM_EP = 68;                   // pitch of a weight-tile row in LDS
 constexpr int DM_NG = 8;                    // diagonal block: exponent groups of 8 columns (a vertex 8 columns right of the DP's diagonal
                                             // already carries ~2^45 times the paths: 16-column groups pushed the diagonal under the guard)
 
-// One chunk = 16 rows (one MFMA M-tile: 32- and 64-row chunks halve / quarter the passes over the transition matrix but lengthen the
-// (chunk, block) wavefront — they lost the r02 sweep at every shape).  The products of a tile run as a software pipeline over the source
+// One chunk = MT MFMA M-tiles of 16 rows (default 2: see launch_dag_dense_mfma).  The products of a tile run as a software pipeline over the source
 // blocks: the register stage of block V + D is requested while block V is converted (exp2) into one of two LDS buffers under the MFMAs
 // of block V - 1, so a source block costs max(MFMA, conversion) instead of a memory round trip (2.2 us per block before: C1's last block
 // spent 1.08 of its 2.1 ms there, and C2 at TR = 4095 was bound by the same per-block latency on every CU).
-constexpr int DM_TM = 16;
+constexpr int DM_TM = 16;                   // rows of one MFMA M-tile; a chunk is MT of them
 constexpr int DM_AP = 68;                   // pitch of an A row (64 + 4, as DM_EP: fragment reads of 16 rows spread over all banks)
-constexpr int DM_AT = DM_TM * DM_AP;        // floats of one A buffer
 constexpr int DM_ET = 64 * DM_EP;           // floats of one E buffer
 
-template <int D, bool BETA>
+template <int D, int MT, bool BETA>
 __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_raw, int b, int U, int sd)
 {
-    constexpr int TM = DM_TM;
+    constexpr int TM = DM_TM * MT, AT = TM * DM_AP;            // rows per chunk, floats of one A buffer
     float* At = reinterpret_cast<float*>(smem_raw);            // [2][TM][4][16]   A fragment order: [m][k % 4][k / 4], row pitch DM_AP
-    float* Et = At + 2 * DM_AT;                                // [2][64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
+    float* Et = At + 2 * AT;                                // [2][64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
     float* Sb = Et + 2 * DM_ET;                                // [2][TM]          exponent of the source block per row
     float* Xd = Sb + 2 * TM;                                   // [8] (of 2 TM)    diagonal block: exponent of each 8-column group of the previous row
     float* Poff = Xd + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
@@ -212,9 +210,15 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         // Three parties follow the same rule on the same sequence of block exponents and so agree without talking: the thread that
         // converts row tid / 16 (Rm), the lanes that own rows 4 lq + r of the accumulators (R[r]), and threads < 16 (Rt, for the
         // diagonal wave, with the first live column FLt).
-        v4f pa = (v4f){0.f, 0.f, 0.f, 0.f}, pb = (v4f){0.f, 0.f, 0.f, 0.f};
-        float R[4] = {DM_SENT, DM_SENT, DM_SENT, DM_SENT};
-        float Rm = DM_SENT, Rt = DM_SENT, FLt = 1.0e9f;
+        v4f pa[MT], pb[MT];
+        float R[MT][4], Rm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            pa[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; pb[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; Rm[mt] = DM_SENT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[mt][r] = DM_SENT;
+        }
+        float Rt = DM_SENT, FLt = 1.0e9f;
         auto ref_rule = [](float& ref, float sx) -> float {        // returns log2 of the factor the row's sums take (0: none); selects only
             const bool livex = sx != DM_SENT, first = ref == DM_SENT;
             const bool jump = livex && !first && sx > ref + 60.f;
@@ -224,24 +228,29 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         };
         // the chunk's emissions [TM x 64], 4 per thread, requested now and parked in LDS after the products (unconditional loads at
         // clamped addresses: guarded ones compile to one exec-masked block and one memory round trip EACH — 16 us per chunk)
-        float em[4];
-        {
-            const int m = tid >> 4, q4 = tid & 15, tt = tt0 + m;
+        float em[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 16 * mt + (tid >> 4), q4 = tid & 15, tt = tt0 + m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ue = ub + 4 * q4 + e;
                 const bool ok = tt >= 1 && tt < Tb && ue < L;
                 const float raw = M[ok ? ((size_t)row(tt) * L + col(ue)) : (size_t)0];
-                em[e] = ok ? raw * DM_LOG2E : NEG_INF;
+                em[mt][e] = ok ? raw * DM_LOG2E : NEG_INF;
             }
         }
         const bool chunk_full = tt0 >= 1 && tt0 + TM <= Tb;            // every row of the chunk has a source row: no row predicates
-        const unsigned offS0 = (unsigned)((tt0 + (tid & 15) - 1) * NJ), offS1 = (unsigned)((tt0 + (tid >> 4) - 1) * NJ);
-        unsigned offA[4];
+        const unsigned offS0 = (unsigned)((tt0 + (tid & (TM - 1)) - 1) * NJ);
+        unsigned offS1[MT], offA[MT][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int srow = row(tt0 + (tid >> 4) - 1), q4 = tid & 15;
-            offA[e] = BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e);
+        for (int mt = 0; mt < MT; ++mt) {
+            offS1[mt] = (unsigned)((tt0 + 16 * mt + (tid >> 4) - 1) * NJ);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int srow = row(tt0 + 16 * mt + (tid >> 4) - 1), q4 = tid & 15;
+                offA[mt][e] = BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e);
+            }
         }
         if (U > 0) {
             // Source block V is usable for this chunk once progress[V] >= tag + c + 1 (then every block left of it is too).  Blocks are
@@ -278,7 +287,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             // request and its conversion D steps later (a select right behind the load would put the memory round trip back on every
             // step: that, not the MFMAs, was the 2.2 us per source block of the first version); the validity predicates are integer
             // functions of (V, thread) and are recomputed at conversion time.  All indices are 32-bit (dense_mfma_supported bounds them).
-            float st_s[D], st_sa[D], st_f[D], st_a[D][4], st_e[D][16];
+            float st_s[D], st_sa[D][MT], st_f[D], st_a[D][MT][4], st_e[D][16];
             // E element (it, e) of source block V: transition v -> u, address and validity
             auto e_vu = [&](int V, int it, int e, int& v, int& uu) {
                 const int vb = V * DM_BW;
@@ -322,33 +331,40 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 const int vb = V * DM_BW;
                 if (chunk_full) {
                     const float2* Sv = S + V;
-                    st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y); st_sa[s] = dm_ld(&Sv[offS1].x);
+                    st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y);
                     const float* Ov = O + (BETA ? (ub - DM_BW - vb) : vb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st_a[s][e] = dm_ld(Ov + offA[e]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        st_sa[s][mt] = dm_ld(&Sv[offS1[mt]].x);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(Ov + offA[mt][e]);
+                    }
                     return;
                 }
                 {
-                    const int m = tl & 15;
+                    const int m = tl & (TM - 1);
                     const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
                     st_s[s] = dm_ld(&S[si].x); st_f[s] = dm_ld(&S[si].y);
                 }
-                const int m = tl >> 4, q4 = tl & 15;                      // A: row m, source columns 4 q4 .. +3
-                {
-                    const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
-                    st_sa[s] = dm_ld(&S[si].x);
-                }
-                const int srow = row(tt0 + m - 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = vb + 4 * q4 + e;
-                    const unsigned idx = (row_ok(m) && v < L) ? (unsigned)(srow * L + col(v)) : 0u;
-                    st_a[s][e] = dm_ld(O + idx);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = 16 * mt + (tl >> 4), q4 = tl & 15;          // A: row m, source columns 4 q4 .. +3
+                    {
+                        const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
+                        st_sa[s][mt] = dm_ld(&S[si].x);
+                    }
+                    const int srow = row(tt0 + m - 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = vb + 4 * q4 + e;
+                        const unsigned idx = (row_ok(m) && v < L) ? (unsigned)(srow * L + col(v)) : 0u;
+                        st_a[s][mt][e] = dm_ld(O + idx);
+                    }
                 }
             };
             auto stage_live = [&](auto SC) -> bool {                     // lanes 0..15 of every wave hold the 16 rows: same vote in all waves
                 constexpr int s = decltype(SC)::value;
-                return __any(row_ok(tl & 15) && st_s[s] != DM_SENT);
+                return __any(row_ok(tl & (TM - 1)) && st_s[s] != DM_SENT);
             };
             // convert a register stage into LDS buffer nb: exponents, A = 2^(a2 - s), E = 2^(weight)
             auto commit = [&](auto SC, int V, int nb) {
@@ -361,20 +377,21 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     (void)ref_rule(Rt, sx);
                     FLt = fminf(FLt, (ok && st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
-                {
-                    const int m = tl >> 4, q4 = tl & 15;
-                    float* Ab = At + nb * DM_AT;
-                    if (chunk_full) {           // a dead row has exponent DM_SENT and 64 values -inf: 2^(-inf - ref) = 0 without a select
-                        (void)ref_rule(Rm, st_sa[s]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][e], DM_LOG2E, -Rm));
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = 16 * mt + (tl >> 4), q4 = tl & 15;
+                    float* Ab = At + nb * AT;
+                    if (chunk_full) {           // a dead row has exponent DM_SENT and 64 values -inf: 2^(-inf - ref) = 0 without a select
+                        (void)ref_rule(Rm[mt], st_sa[s][mt]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][mt][e], DM_LOG2E, -Rm[mt]));
                     } else {
-                        const float sx = row_ok(m) ? st_sa[s] : DM_SENT;
-                        (void)ref_rule(Rm, sx);
+                        const float sx = row_ok(m) ? st_sa[s][mt] : DM_SENT;
+                        (void)ref_rule(Rm[mt], sx);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const bool ok = sx != DM_SENT && (vb + 4 * q4 + e) < L;
-                            Ab[m * DM_AP + e * 16 + q4] = ok ? dm_exp2(st_a[s][e] * DM_LOG2E - Rm) : 0.f;       // [m][k % 4][k / 4]
+                            Ab[m * DM_AP + e * 16 + q4] = ok ? dm_exp2(st_a[s][mt][e] * DM_LOG2E - Rm[mt]) : 0.f;       // [m][k % 4][k / 4]
                         }
                     }
                 }
@@ -406,35 +423,38 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             };
             int cur = 0;                       // LDS buffer of the block whose products are pending
             bool have = false;
-            auto mfma_issue = [&](int nb) {    // 16 x (16x16x4): this wave's slice = columns 16*wave .. +15 of the block; two chains (40-cycle dependent latency)
-                const float* Ab = At + nb * DM_AT; const float* Eb = Et + nb * DM_ET;
-                // the rows' reference exponents follow the same rule as the converting threads' (ref_rule): a change rescales the sums
-                const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 4 * lq);
-                float sc[4]; bool resc = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[r], sx4[r]); resc |= sc[r] != 0.f; }
-                if (__any(resc)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[r] *= f; pb[r] *= f; }
-                }
-                float bf[16], af[16];
+            auto mfma_issue = [&](int nb) {    // 16 MT x (16x16x4): this wave's slice = columns 16*wave .. +15 of the block; two chains (40-cycle dependent latency)
+                const float* Ab = At + nb * AT; const float* Eb = Et + nb * DM_ET;
+                float bf[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const v4f t4 = *reinterpret_cast<const v4f*>(Eb + (16 * wg + lr) * DM_EP + lq * 16 + 4 * q);
                     bf[4 * q] = t4.x; bf[4 * q + 1] = t4.y; bf[4 * q + 2] = t4.z; bf[4 * q + 3] = t4.w;
-                    const v4f a4 = *reinterpret_cast<const v4f*>(Ab + lr * DM_AP + lq * 16 + 4 * q);
-                    af[4 * q] = a4.x; af[4 * q + 1] = a4.y; af[4 * q + 2] = a4.z; af[4 * q + 3] = a4.w;
                 }
 #pragma unroll
-                for (int kk = 0; kk < 16; kk += 2) {
-                    pa = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], pa, 0, 0, 0);
-                    pb = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], pb, 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    // the rows' reference exponents follow the same rule as the converting threads' (ref_rule): a change rescales the sums
+                    const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 16 * mt + 4 * lq);
+                    float sc[4]; bool resc = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[mt][r], sx4[r]); resc |= sc[r] != 0.f; }
+                    if (__any(resc)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
+                    }
+                    float af[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f a4 = *reinterpret_cast<const v4f*>(Ab + (16 * mt + lr) * DM_AP + lq * 16 + 4 * q);
+                        af[4 * q] = a4.x; af[4 * q + 1] = a4.y; af[4 * q + 2] = a4.z; af[4 * q + 3] = a4.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk += 2) {
+                        pa[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], pa[mt], 0, 0, 0);
+                        pb[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], pb[mt], 0, 0, 0);
+                    }
                 }
             };
-            // one pipeline step: products of the pending block || conversion of block V (stage s) || requests for block V + D.
-            // The loads are UNCONDITIONAL (a step past the last block re-requests block U-1 and drops it): s_waitcnt counts in order, so
-            // the compiler can only leave younger stages in flight at a conversion if every path issues the same number of loads —
-            // with the requests under `if (W < U)` it had to assume none and emitted vmcnt(0): no pipelining at any depth.
             // Readiness is never waited for AHEAD of need: a block beyond `ready_hi` when its stage is requested gets its (static) weights
             // requested anyway, and its alpha rows / exponents re-requested when its turn comes (st_ok).  Only the left neighbour(s) are
             // ever in that state, and waiting for them D blocks early would put D - 1 conversions + products behind the wait, on the
@@ -447,20 +467,20 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             auto fused_step = [&](auto SC, int V, int Wc) {
                 constexpr int s = decltype(SC)::value;
                 const int nb = cur, wb = cur ^ 1;
-                const u32 a_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(At + nb * DM_AT + lr * DM_AP + lq * 16);
+                const u32 a_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(At + nb * AT + lr * DM_AP + lq * 16);
                 const u32 e_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Et + nb * DM_ET + (16 * wg + lr) * DM_EP + lq * 16);
-                v4f fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;
-                asm volatile("ds_read_b128 %0, %8\n\t"
-                             "ds_read_b128 %4, %9\n\t"
-                             "ds_read_b128 %1, %8 offset:16\n\t"
-                             "ds_read_b128 %5, %9 offset:16\n\t"
-                             "ds_read_b128 %2, %8 offset:32\n\t"
-                             "ds_read_b128 %6, %9 offset:32\n\t"
-                             "ds_read_b128 %3, %8 offset:48\n\t"
-                             "ds_read_b128 %7, %9 offset:48"
-                             : "=&v"(fa0), "=&v"(fa1), "=&v"(fa2), "=&v"(fa3), "=&v"(fb0), "=&v"(fb1), "=&v"(fb2), "=&v"(fb3)
-                             : "v"(a_addr), "v"(e_addr) : "memory");
-                const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 4 * lq);
+                v4f fa[MT][4], fb0, fb1, fb2, fb3;
+                asm volatile("ds_read_b128 %0, %4\n\t" "ds_read_b128 %1, %4 offset:16\n\t" "ds_read_b128 %2, %4 offset:32\n\t" "ds_read_b128 %3, %4 offset:48"
+                             : "=&v"(fb0), "=&v"(fb1), "=&v"(fb2), "=&v"(fb3) : "v"(e_addr) : "memory");
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32 am = a_addr + (u32)(mt * 16 * DM_AP * 4);
+                    asm volatile("ds_read_b128 %0, %4\n\t" "ds_read_b128 %1, %4 offset:16\n\t" "ds_read_b128 %2, %4 offset:32\n\t" "ds_read_b128 %3, %4 offset:48"
+                                 : "=&v"(fa[mt][0]), "=&v"(fa[mt][1]), "=&v"(fa[mt][2]), "=&v"(fa[mt][3]) : "v"(am) : "memory");
+                }
+                v4f sx4[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sx4[mt] = *reinterpret_cast<const v4f*>(Sb + nb * TM + 16 * mt + 4 * lq);
                 // ---- alpha rows of block V -> A (buffer wb), exponents
                 const int vb = V * DM_BW;
                 if (tl < TM) {
@@ -469,22 +489,27 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     (void)ref_rule(Rt, sx);
                     FLt = fminf(FLt, (st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
-                {
-                    const int m = tl >> 4, q4 = tl & 15;
-                    float* Ab = At + wb * DM_AT;
-                    (void)ref_rule(Rm, st_sa[s]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][e], DM_LOG2E, -Rm));
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = 16 * mt + (tl >> 4), q4 = tl & 15;
+                    float* Ab = At + wb * AT;
+                    (void)ref_rule(Rm[mt], st_sa[s][mt]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][mt][e], DM_LOG2E, -Rm[mt]));
                 }
                 // ---- the pending block's rows: reference exponents (a change rescales the sums: rare)
-                float sc[4]; bool resc = false;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[r], sx4[r]); resc |= sc[r] != 0.f; }
-                if (__any(resc)) {
+                for (int mt = 0; mt < MT; ++mt) {
+                    float sc[4]; bool resc = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[r] *= f; pb[r] *= f; }
+                    for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[mt][r], sx4[mt][r]); resc |= sc[r] != 0.f; }
+                    if (__any(resc)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
+                    }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3) :: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                             "+v"(fa[MT - 1][0]), "+v"(fa[MT - 1][1]), "+v"(fa[MT - 1][2]), "+v"(fa[MT - 1][3]) :: "memory");
                 float* Eb = Et + wb * DM_ET;
                 auto convE = [&](int it) {
                     v4f w4;
@@ -501,23 +526,33 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 const float* Kv = K + (BETA ? (size_t)(ub - DM_BW - Wc * DM_BW) : (size_t)(Wc * DM_BW) * (size_t)(TR - 1));
                 const float2* Sv = S + Wc;
                 const float* Ov = O + (BETA ? (ub - DM_BW - Wc * DM_BW) : Wc * DM_BW);
-#define DM_MF(A_, B_, j_) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[j_], B_[j_], pa, 0, 0, 0); pb = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[j_ + 1], B_[j_ + 1], pb, 0, 0, 0);
-                DM_MF(fa0, fb0, 0) convE(0);
-                DM_MF(fa0, fb0, 2) convE(1);
-                DM_MF(fa1, fb1, 0) convE(2);
-                DM_MF(fa1, fb1, 2) convE(3);
-                DM_MF(fa2, fb2, 0)
+                // k-steps q = 0..3 (fragments fa[.][q], fb_q), two MFMAs per chain and step pair, every row tile of the chunk
+                auto mf = [&](int q, const v4f& fbq, int j) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        pa[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][q][j], fbq[j], pa[mt], 0, 0, 0);
+                        pb[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][q][j + 1], fbq[j + 1], pb[mt], 0, 0, 0);
+                    }
+                };
+                mf(0, fb0, 0); convE(0);
+                mf(0, fb0, 2); convE(1);
+                mf(1, fb1, 0); convE(2);
+                mf(1, fb1, 2); convE(3);
+                mf(2, fb2, 0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) st_e[s][i] = Kv[offE[i]];
-                DM_MF(fa2, fb2, 2)
+                mf(2, fb2, 2);
 #pragma unroll
                 for (int i = 8; i < 16; ++i) st_e[s][i] = Kv[offE[i]];
-                DM_MF(fa3, fb3, 0)
-                st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y); st_sa[s] = dm_ld(&Sv[offS1].x);
+                mf(3, fb3, 0);
+                st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) st_a[s][e] = dm_ld(Ov + offA[e]);
-                DM_MF(fa3, fb3, 2)
-#undef DM_MF
+                for (int mt = 0; mt < MT; ++mt) {
+                    st_sa[s][mt] = dm_ld(&Sv[offS1[mt]].x);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(Ov + offA[mt][e]);
+                }
+                mf(3, fb3, 2);
                 st_ok[s] = (V + D) <= ready_hi;
                 __syncthreads();
                 cur ^= 1;
@@ -528,7 +563,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     ensure_ready(V); prefetchA(SC, V);
                     // (consumed here, so that the wait for this re-request sits inside the branch: at the join the compiler must otherwise
                     //  assume "no younger loads behind the stage" on every path and emits vmcnt(0) for the common one too)
-                    asm volatile("" :: "v"(st_a[s][3]), "v"(st_a[s][0]), "v"(st_s[s]) : "memory");
+                    asm volatile("" :: "v"(st_a[s][MT - 1][3]), "v"(st_a[s][0][0]), "v"(st_s[s]) : "memory");
                 }
                 const bool live = V < U && stage_live(SC);
                 const int W = V + D, Wc = min(W, U - 1);
@@ -567,9 +602,12 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         stamp(pf_gemm);
         // ---- hand the tile's off-diagonal sums and the chunk's emissions to the diagonal wave
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Poff[(4 * lq + r) * 64 + 16 * wg + lr] = pa[r] + pb[r];
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Poff[(16 * mt + 4 * lq + r) * 64 + 16 * wg + lr] = pa[mt][r] + pb[mt][r];
+            *reinterpret_cast<v4f*>(Md + (16 * mt + (tid >> 4)) * 64 + 4 * (tid & 15)) = (v4f){em[mt][0], em[mt][1], em[mt][2], em[mt][3]};
+        }
         if (tid < TM) { Roff[tid] = Rt; FLo[tid] = FLt; }
-        *reinterpret_cast<v4f*>(Md + (tid >> 4) * 64 + 4 * (tid & 15)) = (v4f){em[0], em[1], em[2], em[3]};
         __syncthreads();
 
         // ================================================================ diagonal block: rows of the chunk in sequence (wave 0)
@@ -689,7 +727,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks; }
 }
 
-template <int D>
+template <int D, int MT>
 __global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -713,8 +751,8 @@ __global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
             for (int ul = tid; ul < DM_BW; ul += 256) { const int u = U * DM_BW + ul; if (u < L) O[(size_t)t * L + (is_beta ? (L - 1 - u) : u)] = NEG_INF; }
         return;
     }
-    if (is_beta) dense_mfma_body<D, true>(p, smem_raw, b, U, sd);
-    else dense_mfma_body<D, false>(p, smem_raw, b, U, sd);
+    if (is_beta) dense_mfma_body<D, MT, true>(p, smem_raw, b, U, sd);
+    else dense_mfma_body<D, MT, false>(p, smem_raw, b, U, sd);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -722,18 +760,20 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
 
 bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31); }
 
-template <int D>
+template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
-    const size_t lds = (size_t)(2 * DM_AT + 2 * DM_ET + 4 * DM_TM + DM_TM * 64 + 2 * DM_TM + 68 + 64 + 64 * 64 + DM_TM * 64) * 4 + 64;
-    auto k = dag_dense_mfma_kernel<D>;
+    constexpr int TM = DM_TM * MT;
+    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 4 * TM + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
+    auto k = dag_dense_mfma_kernel<D, MT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
     return check_launch("dag_loss_fwd(dense mfma)");
 }
 
-static thread_local int g_dm_depth = 0;      // (diagnostic switches are per calling thread, like dp_path)
+static thread_local int g_dm_depth = 0, g_dm_mt = 0;      // (diagnostic switches are per calling thread, like dp_path)
 void set_dm_depth(int v) { g_dm_depth = v; }
+void set_dm_mt(int v) { g_dm_mt = v; }
 
 int launch_dag_dense_mfma(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                           float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
@@ -753,9 +793,13 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     p.S = reinterpret_cast<float2*>(reinterpret_cast<char*>(area) + prog_bytes);
     const int nwg = ndir * B * NJ;
     const int depth = g_dm_depth ? g_dm_depth : 2;       // source blocks in flight per workgroup
-    if (depth <= 1) return launch_dm<1>(p, nwg, st);
-    if (depth == 2) return launch_dm<2>(p, nwg, st);
-    return launch_dm<3>(p, nwg, st);
+    // 16-row MFMA tiles per chunk: 2 (32-row chunks, one register stage) halves the source blocks per DP row and was faster or equal at
+    // every shape of the r02 sweep on the pipelined kernel (C1 1.53 / 1.53 ms, B=16 T=150 L=1024 0.79 / 0.71, C2 at TR = 4095 38.6 / 31.2
+    // for 16- / 32-row chunks; the pre-pipeline kernel had it the other way round: its blocks cost a memory round trip each)
+    const int mt = g_dm_mt ? g_dm_mt : 2;
+    if (mt >= 2) return launch_dm<1, 2>(p, nwg, st);     // (two stages of a 32-row chunk do not fit the register file: 18 spills)
+    if (depth <= 1) return launch_dm<1, 1>(p, nwg, st);
+    return launch_dm<2, 1>(p, nwg, st);                  // (three stages: 27 spills)
 }
 
 }  // namespace dsp

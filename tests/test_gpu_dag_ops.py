@@ -500,13 +500,14 @@ def test_dense_mfma_dp_matches_oracle(shape, masked):
     m.requires_grad_()
     try:
         res = {}
-        for path in (9, 1):                       # 9 = matrix-core kernel (also the auto choice), 1 = log-space row-sequential kernels
-            _lib.set_option("dp_path", path)
+        # 9 = matrix-core kernel (also the auto choice) with 32-row (default) and 16-row chunks, 1 = log-space row-sequential kernels
+        for path, mt in ((9, 0), (9, 1), (1, 0)):
+            _lib.set_option("dp_path", path); _lib.set_option("dm_mt", mt)
             loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
-            res[path] = (alpha.cpu().numpy(), beta.cpu().numpy(), loss.detach().cpu().numpy())
+            res[(path, mt)] = (alpha.cpu().numpy(), beta.cpu().numpy(), loss.detach().cpu().numpy())
     finally:
-        _lib.set_option("dp_path", 0)
+        _lib.set_option("dp_path", 0); _lib.set_option("dm_mt", 0)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
     b64 = orc.dag_beta(match, links, ol, tl, np.float64)
     for path, (a, b, ls) in res.items():

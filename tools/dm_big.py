@@ -18,8 +18,8 @@ alpha = torch.empty_like(match); beta = torch.empty_like(match)
 def run():
     assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), None, B, T, L, TR, None, 0, st) == 0
 ref = None
-for name, path, mt in (("mfma mt=2", 9, 2), ("mfma mt=4", 9, 4), ("mfma mt=3", 9, 3), ("mfma mt=1", 9, 1)):
-    _lib.set_option("dp_path", path); _lib.set_option("dm_depth", mt)
+for name, path, mt in (("mfma mt=2", 9, 2), ("mfma mt=1", 9, 1)):
+    _lib.set_option("dp_path", path); _lib.set_option("dm_mt", mt)
     run(); torch.cuda.synchronize(); t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"C2 TR=4095 {name}: alpha||beta {dt * 1e3:.2f} ms, status {_lib.last_launch_status()} exact-cells {_lib.last_fallback_count()}", flush=True)
     if ref is None: ref = (alpha.clone(), beta.clone())

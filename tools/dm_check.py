@@ -16,10 +16,10 @@ def check(B, T, L, TR, seed, mt=0, masked=False):
     t = lambda a: torch.from_numpy(a).cuda()
     m, k, o, tt = t(match), t(links), t(ol), t(tl)
     m.requires_grad_()
-    _lib.set_option("dp_path", 9); _lib.set_option("dm_depth", mt)
+    _lib.set_option("dp_path", 9); _lib.set_option("dm_mt", mt)
     loss, (a, b) = ops.dag_loss_with_alpha_beta(m, k, o, tt)
     st = _lib.last_launch_status(); fb = _lib.last_fallback_count()
-    _lib.set_option("dp_path", 0); _lib.set_option("dm_depth", 0)
+    _lib.set_option("dp_path", 0); _lib.set_option("dm_mt", 0)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
     a, b = a.cpu().numpy(), b.cpu().numpy()
     ok = np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)) and not np.isnan(a).any() and not np.isnan(b).any()
@@ -70,13 +70,13 @@ for (B, T, L, TR) in shapes:
     def run(a, b):
         assert lib.dsp_dag_loss_fwd(_lib.ptr(match), _lib.ptr(links), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(a), _lib.ptr(b), None, B, T, L, TR, None, 0, st) == 0
     res = {}
-    for name, path, mt in (("log-space dense", 1, 0), ("mfma mt=1", 9, 1), ("mfma mt=2", 9, 2), ("mfma mt=3", 9, 3), ("mfma mt=4", 9, 4)):
+    for name, path, mt in (("log-space dense", 1, 0), ("mfma mt=1", 9, 1), ("mfma mt=2", 9, 2)):
         if path == 1 and L >= 4096: _lib.set_option("dp_path", 1)
-        _lib.set_option("dp_path", path); _lib.set_option("dm_depth", mt)
+        _lib.set_option("dp_path", path); _lib.set_option("dm_mt", mt)
         tb = timeit(lambda: run(alpha, beta), n=3 if L >= 4096 else 5)
         res[name] = (alpha.clone(), beta.clone()) if L < 4096 else None
         print(f"B={B} T={T} L={L} TR={TR} {name}: alpha||beta {tb:.3f} ms, status {_lib.last_launch_status()} exact-cells {_lib.last_fallback_count()}", flush=True)
-    _lib.set_option("dp_path", 0); _lib.set_option("dm_depth", 0)
+    _lib.set_option("dp_path", 0); _lib.set_option("dm_mt", 0)
     if res["mfma mt=1"] is not None:
         for w in (0, 1):
             x, y = res["mfma mt=1"][w], res["log-space dense"][w]
