@@ -5,7 +5,7 @@
 // transition matrix — C1: 4.7 ms, C2 at TR = 4095: 119 ms) and, like dag_dp_maxstrip.hip does for banded graphs, the B*T*L int32 trace
 // tensor of the reference (dag_best_alignment.cu:39-130 keeps the arg-max of every cell; the back-trace reads T of them).
 //
-// Same decomposition as dag_dp_dense_mfma.hip: 64-column blocks, chunks of 16 rows, block U runs one chunk behind block U-1 (progress
+// Same decomposition as dag_dp_dense_mfma.hip: 64-column blocks, chunks of DX_TM rows, block U runs one chunk behind block U-1 (progress
 // words tagged with the launch epoch, tickets block-major).  The off-diagonal part of a tile is a [16 x 64] (+, max) [64 x 64] product —
 // there is no matrix-core form of it, so it runs on the VALU: a thread owns one column and four rows, the source rows are LDS
 // broadcasts, the weights LDS reads at unit stride.  No exponents, no guard: add and max are exact, so alpha_max is bit-identical to
@@ -33,7 +33,10 @@ struct DXParams {
     int B, T, L, TR, NJ;
 };
 
-constexpr int DX_BW = 64, DX_TM = 16, DX_WP = 65;      // weight tile pitch 65: a thread column walks k at a bank stride of 1
+// chunks of DX_MT x 16 rows.  32-row chunks (DX_MT = 2: a weight read serves 8 rows of a thread, the per-block overhead is paid half
+// as often) measured WORSE here except at the largest shape — C1 2.12 -> 2.32 ms, B=32 T=100 L=400 0.41 -> 0.45, C2 at TR=4095
+// 22.8 -> 22.1 — unlike the matrix-core kernel: the (+, max) product is VALU work proportional to the rows either way.
+constexpr int DX_BW = 64, DX_MT = 1, DX_TM = 16 * DX_MT, DX_WP = 65;      // weight tile pitch 65: a thread column walks k at a bank stride of 1
 constexpr u32 DX_SPIN_LIMIT = 1u << 24;
 
 // wave-wide maximum, wave-uniform result: 4 DPP steps inside the 16-lane rows, then the four rows through readlane
@@ -57,12 +60,12 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_ticket;
-    float* At = smem;                                  // [2][16][64]   source rows (previous DP row of block V), row-major
+    float* At = smem;                                  // [2][TM][64]   source rows (previous DP row of block V), row-major
     float* Wt = At + 2 * DX_TM * 64;                   // [2][64][65]   weights [k = source][n = column]
-    float* Sb = Wt + 2 * 64 * DX_WP;                   // [2][16]       block maximum per source row
-    float* Poff = Sb + 2 * DX_TM;                      // [16][64]      off-diagonal maxima of the tile
+    float* Sb = Wt + 2 * 64 * DX_WP;                   // [2][TM]       block maximum per source row
+    float* Poff = Sb + 2 * DX_TM;                      // [TM][64]      off-diagonal maxima of the tile
     float* Vd = Poff + DX_TM * 64;                     // [64]          diagonal block: previous row
-    float* Md = Vd + 64;                               // [16][64]      the chunk's emissions
+    float* Md = Vd + 64;                               // [TM][64]      the chunk's emissions
     int* RDY = reinterpret_cast<int*>(Md + DX_TM * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
@@ -113,21 +116,26 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
     for (int i = 0; i < 16; ++i) offW[i] = (unsigned)((16 * mg + i) * (TR - 1) + ub + n - 1);          // links[vb + k][ub + n - vb - k - 1]
     for (int c = 0; c < nchunks; ++c) {
         const int tt0 = c * DX_TM;
-        float acc[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        float acc[DX_MT][4];
+#pragma unroll
+        for (int mt = 0; mt < DX_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = NEG_INF;
         // the chunk's emissions, 4 per thread, requested now and parked in LDS after the products
-        float em[4];
-        {
-            const int m = tid >> 4, q4 = tid & 15, tt = tt0 + m;
+        float em[DX_MT][4];
+#pragma unroll
+        for (int mt = 0; mt < DX_MT; ++mt) {
+            const int m = 16 * mt + (tid >> 4), q4 = tid & 15, tt = tt0 + m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ue = ub + 4 * q4 + e;
                 const bool ok = tt >= 1 && tt < Tb && ue < L;
                 const float raw = M[ok ? (unsigned)(tt * L + ue) : 0u];
-                em[e] = ok ? raw : NEG_INF;
+                em[mt][e] = ok ? raw : NEG_INF;
             }
         }
         const bool chunk_full = tt0 >= 1 && tt0 + DX_TM <= Tb;
-        const unsigned offS = (unsigned)((tt0 + (tid & 15) - 1) * NJ), offA = (unsigned)((tt0 + (tid >> 4) - 1) * L + 4 * (tid & 15));
+        const unsigned offS = (unsigned)((tt0 + (tid & (DX_TM - 1)) - 1) * NJ), offA = (unsigned)((tt0 + (tid >> 4) - 1) * L + 4 * (tid & 15));      // (row tile mt: + 16 mt L)
         auto row_ok = [&](int m) -> bool { const int tt = tt0 + m; return tt >= 1 && tt < Tb; };
         if (U > 0) {
             const u32 want = p.tag_base + (u32)c + 1u;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
             // Two register stages of RAW loaded words (block maximum of row tid % 16, 4 alpha_max values of row tid / 16, 16 weights),
             // unconditional requests, validity recomputed at conversion time, two LDS buffers and one barrier per source block, readiness
             // waited for only at need — the pipeline of dag_dp_dense_mfma.hip (its header explains each point).
-            float st_s[2], st_a[2][4], st_w[2][16];
+            float st_s[2], st_a[2][DX_MT][4], st_w[2][16];
             bool st_ok[2];
             auto w_full = [&](int V) -> bool { return (ub + 63 < L) && (ub + 62 - V * DX_BW < TR); };
             auto prefetchW = [&](int s, int V) {
@@ -174,33 +182,39 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
                     st_s[s] = dx_ld(S + offS + V);
                     const float* Ov = O + vb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st_a[s][e] = dx_ld(Ov + offA + e);
+                    for (int mt = 0; mt < DX_MT; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dx_ld(Ov + offA + (unsigned)(16 * mt * L) + e);
                     return;
                 }
                 {
-                    const int m = tid & 15;
+                    const int m = tid & (DX_TM - 1);
                     st_s[s] = dx_ld(&S[row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u]);
                 }
-                const int m = tid >> 4, q4 = tid & 15;                       // A: row m, source columns 4 q4 .. +3
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = vb + 4 * q4 + e;
-                    st_a[s][e] = dx_ld(O + ((row_ok(m) && v < L) ? (unsigned)((tt0 + m - 1) * L + v) : 0u));
+                for (int mt = 0; mt < DX_MT; ++mt) {
+                    const int m = 16 * mt + (tid >> 4), q4 = tid & 15;       // A: row m, source columns 4 q4 .. +3
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = vb + 4 * q4 + e;
+                        st_a[s][mt][e] = dx_ld(O + ((row_ok(m) && v < L) ? (unsigned)((tt0 + m - 1) * L + v) : 0u));
+                    }
                 }
             };
-            auto stage_live = [&](int s) -> bool { return __any(row_ok(tid & 15) && st_s[s] != NEG_INF); };   // lanes 0..15 of every wave: all 16 rows
+            auto stage_live = [&](int s) -> bool { return __any(row_ok(tid & (DX_TM - 1)) && st_s[s] != NEG_INF); };   // lanes 0 .. DX_TM-1 of every wave: all rows
             auto commit = [&](int s, int V, int nb) {
                 const int vb = V * DX_BW;
                 if (tid < DX_TM) Sb[nb * DX_TM + tid] = row_ok(tid) ? st_s[s] : NEG_INF;
-                {
-                    const int m = tid >> 4, q4 = tid & 15;
+#pragma unroll
+                for (int mt = 0; mt < DX_MT; ++mt) {
+                    const int m = 16 * mt + (tid >> 4), q4 = tid & 15;
                     v4f a4;
                     if (chunk_full) {                                    // (source columns of a block V < U are always inside the graph)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a4[e] = st_a[s][e];
+                        for (int e = 0; e < 4; ++e) a4[e] = st_a[s][mt][e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a4[e] = (row_ok(m) && (vb + 4 * q4 + e) < L) ? st_a[s][e] : NEG_INF;
+                        for (int e = 0; e < 4; ++e) a4[e] = (row_ok(m) && (vb + 4 * q4 + e) < L) ? st_a[s][mt][e] : NEG_INF;
                     }
                     *reinterpret_cast<v4f*>(At + nb * DX_TM * 64 + m * 64 + 4 * q4) = a4;
                 }
@@ -213,19 +227,22 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
                     for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = w_ok(vb + 16 * mg + i, ub + n) ? st_w[s][i] : NEG_INF;
                 }
             };
-            auto product = [&](int nb) {       // (+, max) product: acc[r] = max_k ( A[4 mg + r][k] + W[k][n] )
+            auto product = [&](int nb) {       // (+, max) product: acc[mt][r] = max_k ( A[16 mt + 4 mg + r][k] + W[k][n] )
                 const float* Ab = At + nb * DX_TM * 64; const float* Wb = Wt + nb * 64 * DX_WP;
-#pragma unroll 4
+#pragma unroll 2
                 for (int kk = 0; kk < 16; ++kk) {
-                    v4f a4[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) a4[r] = *reinterpret_cast<const v4f*>(Ab + (4 * mg + r) * 64 + 4 * kk);      // broadcast
                     const float w0 = Wb[(4 * kk) * DX_WP + n], w1 = Wb[(4 * kk + 1) * DX_WP + n];
                     const float w2 = Wb[(4 * kk + 2) * DX_WP + n], w3 = Wb[(4 * kk + 3) * DX_WP + n];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[r] = fmaxf(fmaxf(acc[r], a4[r].x + w0), a4[r].y + w1);
-                        acc[r] = fmaxf(fmaxf(acc[r], a4[r].z + w2), a4[r].w + w3);
+                    for (int mt = 0; mt < DX_MT; ++mt) {
+                        v4f a4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a4[r] = *reinterpret_cast<const v4f*>(Ab + (16 * mt + 4 * mg + r) * 64 + 4 * kk);      // broadcast
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[mt][r] = fmaxf(fmaxf(acc[mt][r], a4[r].x + w0), a4[r].y + w1);
+                            acc[mt][r] = fmaxf(fmaxf(acc[mt][r], a4[r].z + w2), a4[r].w + w3);
+                        }
                     }
                 }
             };
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
             auto step = [&](int s, int V) {
                 if (V < U && !st_ok[s]) {
                     ensure_ready(V); prefetchA(s, V);
-                    asm volatile("" :: "v"(st_a[s][3]), "v"(st_a[s][0]), "v"(st_s[s]) : "memory");      // the wait for the re-request stays in this branch
+                    asm volatile("" :: "v"(st_a[s][DX_MT - 1][3]), "v"(st_a[s][0][0]), "v"(st_s[s]) : "memory");      // the wait for the re-request stays in this branch
                 }
                 const bool live = V < U && stage_live(s);
                 if (live) commit(s, V, cur ^ 1);
@@ -254,8 +271,11 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
             if (have) product(cur);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Poff[(4 * mg + r) * 64 + n] = acc[r];
-        *reinterpret_cast<v4f*>(Md + (tid >> 4) * 64 + 4 * (tid & 15)) = (v4f){em[0], em[1], em[2], em[3]};
+        for (int mt = 0; mt < DX_MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Poff[(16 * mt + 4 * mg + r) * 64 + n] = acc[mt][r];
+            *reinterpret_cast<v4f*>(Md + (16 * mt + (tid >> 4)) * 64 + 4 * (tid & 15)) = (v4f){em[mt][0], em[mt][1], em[mt][2], em[mt][3]};
+        }
         __syncthreads();
 
         // ================================================================ diagonal block, row by row (wave 0)
