@@ -100,9 +100,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     constexpr int TM = DM_TM * MT, AT = TM * DM_AP;            // rows per chunk, floats of one A buffer
     float* At = reinterpret_cast<float*>(smem_raw);            // [2][TM][4][16]   A fragment order: [m][k % 4][k / 4], row pitch DM_AP
     float* Et = At + 2 * AT;                                // [2][64][4][16]   B fragment order: [n][k % 4][k / 4], row pitch DM_EP
-    float* Sb = Et + 2 * DM_ET;                                // [2][TM]          exponent of the source block per row
+    float* Sb = Et + 2 * DM_ET;                                // [2][TM]          (unused since the rescale factors are published: SCb)
     float* Xd = Sb + 2 * TM;                                   // [8] (of 2 TM)    diagonal block: exponent of each 8-column group of the previous row
-    float* Poff = Xd + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
+    float* SCb = Xd + 2 * TM;                                  // [2][TM]          log2 of the factor a row's sums take before this block (0: none)
+    float* Poff = SCb + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
     float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
     float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
@@ -182,7 +183,14 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     __syncthreads();
 
     // loop-invariant 32-bit thread offsets of the fast-path loads (see prefetchE): element (it, e) of a source block, relative to the
-    // block's uniform base
+    // block's uniform base — in BYTES, added to a uniform pointer: that is the shape the compiler turns into  global_load v, voffset, s[base]
+    // (no 64-bit VGPR address pair per load; an element index it scales in 64 bits first)
+    // The empty asm keeps the 32-bit offset a value DEFINED IN THE BLOCK of the load: hoisted out of the loop as a zero-extended 64-bit
+    // pair (LICM does that), instruction selection no longer sees  base + zext(offset)  and emits a 64-bit VALU add per load again.
+    auto at_f = [](const float* base, unsigned byte_off) -> const float* {
+        asm volatile("" : "+v"(byte_off));
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+    };
     unsigned offE[16];
 #pragma unroll
     for (int it = 0; it < 4; ++it)
@@ -190,10 +198,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         for (int e = 0; e < 4; ++e) {
             if (!BETA) {
                 const int n = tid & 63, g = (tid >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4, cc = 4 * (kk0 + e) + kq;
-                offE[4 * it + e] = (unsigned)(cc * (TR - 1) + ub + n - 1);                    // links[vb + cc][ub + n - vb - cc - 1]
+                offE[4 * it + e] = 4u * (unsigned)(cc * (TR - 1) + ub + n - 1);               // links[vb + cc][ub + n - vb - cc - 1], BYTES
             } else {
                 const int e0 = tid + 256 * it, hi = e0 >> 4, cc = 4 * (e0 & 15) + e;
-                offE[4 * it + e] = (unsigned)((L - 1 - ub - hi) * TR + hi + 63 - cc);         // links[L-1-u][u - vb - cc - 1], base K + ub - 64 - vb
+                offE[4 * it + e] = 4u * (unsigned)((L - 1 - ub - hi) * TR + hi + 63 - cc);    // links[L-1-u][u - vb - cc - 1], base K + ub - 64 - vb, BYTES
             }
         }
     const int lr = lane & 15, lq = lane >> 4;
@@ -207,17 +215,14 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         // matrix pipe's latency every step).  Row m is scaled by ONE reference exponent: that of its first live source block, moved
         // (and the sums rescaled) only when a block's exponent exceeds it by more than 60 binades — A <= 2^60, E <= 1, <= 4096 terms:
         // the sums stay under 2^72.  Blocks far below the reference flush to zero exactly as they would against a running maximum.
-        // Three parties follow the same rule on the same sequence of block exponents and so agree without talking: the thread that
-        // converts row tid / 16 (Rm), the lanes that own rows 4 lq + r of the accumulators (R[r]), and threads < 16 (Rt, for the
-        // diagonal wave, with the first live column FLt).
+        // Two parties follow the same rule on the same sequence of block exponents and so agree without talking: the thread that
+        // converts row tid / 16 (Rm) and thread `row` < TM (Rt, for the diagonal wave, with the first live column FLt) — which also
+        // publishes the rescale factor of its row with the block (SCb), so the lanes that own the accumulators only test it
+        // (evaluating the rule for their 4 MT rows cost ~10 instructions per row and block).
         v4f pa[MT], pb[MT];
-        float R[MT][4], Rm[MT];
+        float Rm[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            pa[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; pb[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; Rm[mt] = DM_SENT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[mt][r] = DM_SENT;
-        }
+        for (int mt = 0; mt < MT; ++mt) { pa[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; pb[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; Rm[mt] = DM_SENT; }
         float Rt = DM_SENT, FLt = 1.0e9f;
         auto ref_rule = [](float& ref, float sx) -> float {        // returns log2 of the factor the row's sums take (0: none); selects only
             const bool livex = sx != DM_SENT, first = ref == DM_SENT;
@@ -241,15 +246,15 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             }
         }
         const bool chunk_full = tt0 >= 1 && tt0 + TM <= Tb;            // every row of the chunk has a source row: no row predicates
-        const unsigned offS0 = (unsigned)((tt0 + (tid & (TM - 1)) - 1) * NJ);
+        const unsigned offS0 = 8u * (unsigned)((tt0 + (tid & (TM - 1)) - 1) * NJ);              // (bytes, as offE)
         unsigned offS1[MT], offA[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            offS1[mt] = (unsigned)((tt0 + 16 * mt + (tid >> 4) - 1) * NJ);
+            offS1[mt] = 8u * (unsigned)((tt0 + 16 * mt + (tid >> 4) - 1) * NJ);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int srow = row(tt0 + 16 * mt + (tid >> 4) - 1), q4 = tid & 15;
-                offA[mt][e] = BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e);
+                offA[mt][e] = 4u * (BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e));
             }
         }
         if (U > 0) {
@@ -312,7 +317,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 if (e_full(V)) {
                     const float* Kv = K + (BETA ? (size_t)(ub - DM_BW - V * DM_BW) : (size_t)(V * DM_BW) * (size_t)(TR - 1));
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) st_e[s][i] = Kv[offE[i]];
+                    for (int i = 0; i < 16; ++i) st_e[s][i] = *at_f(Kv, offE[i]);
                     return;
                 }
 #pragma unroll
@@ -330,14 +335,14 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 constexpr int s = decltype(SC)::value;
                 const int vb = V * DM_BW;
                 if (chunk_full) {
-                    const float2* Sv = S + V;
-                    st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y);
+                    const float* Sv = reinterpret_cast<const float*>(S + V);
+                    st_s[s] = dm_ld(at_f(Sv, offS0)); st_f[s] = dm_ld(at_f(Sv, offS0 + 4u));
                     const float* Ov = O + (BETA ? (ub - DM_BW - vb) : vb);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        st_sa[s][mt] = dm_ld(&Sv[offS1[mt]].x);
+                        st_sa[s][mt] = dm_ld(at_f(Sv, offS1[mt]));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(Ov + offA[mt][e]);
+                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(at_f(Ov, offA[mt][e]));
                     }
                     return;
                 }
@@ -373,8 +378,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 if (tl < TM) {
                     const bool ok = row_ok(tl);
                     const float sx = ok ? st_s[s] : DM_SENT;
-                    Sb[nb * TM + tl] = sx;
-                    (void)ref_rule(Rt, sx);
+                    SCb[nb * TM + tl] = ref_rule(Rt, sx);
                     FLt = fminf(FLt, (ok && st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
 #pragma unroll
@@ -433,14 +437,11 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    // the rows' reference exponents follow the same rule as the converting threads' (ref_rule): a change rescales the sums
-                    const v4f sx4 = *reinterpret_cast<const v4f*>(Sb + nb * TM + 16 * mt + 4 * lq);
-                    float sc[4]; bool resc = false;
+                    // a row whose reference exponent moved with this block has its sums rescaled first (rare)
+                    const v4f sc4 = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
+                    if (__any(sc4.x != 0.f || sc4.y != 0.f || sc4.z != 0.f || sc4.w != 0.f)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[mt][r], sx4[r]); resc |= sc[r] != 0.f; }
-                    if (__any(resc)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
+                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc4[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
                     }
                     float af[16];
 #pragma unroll
@@ -478,15 +479,14 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     asm volatile("ds_read_b128 %0, %4\n\t" "ds_read_b128 %1, %4 offset:16\n\t" "ds_read_b128 %2, %4 offset:32\n\t" "ds_read_b128 %3, %4 offset:48"
                                  : "=&v"(fa[mt][0]), "=&v"(fa[mt][1]), "=&v"(fa[mt][2]), "=&v"(fa[mt][3]) : "v"(am) : "memory");
                 }
-                v4f sx4[MT];
+                v4f sc4[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) sx4[mt] = *reinterpret_cast<const v4f*>(Sb + nb * TM + 16 * mt + 4 * lq);
+                for (int mt = 0; mt < MT; ++mt) sc4[mt] = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
                 // ---- alpha rows of block V -> A (buffer wb), exponents
                 const int vb = V * DM_BW;
                 if (tl < TM) {
                     const float sx = st_s[s];
-                    Sb[wb * TM + tl] = sx;
-                    (void)ref_rule(Rt, sx);
+                    SCb[wb * TM + tl] = ref_rule(Rt, sx);
                     FLt = fminf(FLt, (st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
 #pragma unroll
@@ -497,15 +497,13 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][mt][e], DM_LOG2E, -Rm[mt]));
                 }
-                // ---- the pending block's rows: reference exponents (a change rescales the sums: rare)
+                // ---- the pending block's rows: a moved reference exponent rescales the sums first (rare)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    float sc[4]; bool resc = false;
+                    const v4f c4 = sc4[mt];
+                    if (__any(c4.x != 0.f || c4.y != 0.f || c4.z != 0.f || c4.w != 0.f)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { sc[r] = ref_rule(R[mt][r], sx4[mt][r]); resc |= sc[r] != 0.f; }
-                    if (__any(resc)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
+                        for (int r = 0; r < 4; ++r) { const float f = dm_exp2(c4[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
@@ -524,7 +522,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     }
                 };
                 const float* Kv = K + (BETA ? (size_t)(ub - DM_BW - Wc * DM_BW) : (size_t)(Wc * DM_BW) * (size_t)(TR - 1));
-                const float2* Sv = S + Wc;
+                const float* Sv = reinterpret_cast<const float*>(S + Wc);
                 const float* Ov = O + (BETA ? (ub - DM_BW - Wc * DM_BW) : Wc * DM_BW);
                 // k-steps q = 0..3 (fragments fa[.][q], fb_q), two MFMAs per chain and step pair, every row tile of the chunk
                 auto mf = [&](int q, const v4f& fbq, int j) {
@@ -540,17 +538,17 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 mf(1, fb1, 2); convE(3);
                 mf(2, fb2, 0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) st_e[s][i] = Kv[offE[i]];
+                for (int i = 0; i < 8; ++i) st_e[s][i] = *at_f(Kv, offE[i]);
                 mf(2, fb2, 2);
 #pragma unroll
-                for (int i = 8; i < 16; ++i) st_e[s][i] = Kv[offE[i]];
+                for (int i = 8; i < 16; ++i) st_e[s][i] = *at_f(Kv, offE[i]);
                 mf(3, fb3, 0);
-                st_s[s] = dm_ld(&Sv[offS0].x); st_f[s] = dm_ld(&Sv[offS0].y);
+                st_s[s] = dm_ld(at_f(Sv, offS0)); st_f[s] = dm_ld(at_f(Sv, offS0 + 4u));
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    st_sa[s][mt] = dm_ld(&Sv[offS1[mt]].x);
+                    st_sa[s][mt] = dm_ld(at_f(Sv, offS1[mt]));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(Ov + offA[mt][e]);
+                    for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dm_ld(at_f(Ov, offA[mt][e]));
                 }
                 mf(3, fb3, 2);
                 st_ok[s] = (V + D) <= ready_hi;
@@ -735,12 +733,14 @@ __global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
     const int tid = threadIdx.x;
     if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
     __syncthreads();
-    const u32 ticket = s_ticket;
+    // (readfirstlane: the ticket comes out of LDS and the divisions run on the VALU, so without it the block index, the sample and every
+    //  base pointer derived from them live in VGPRs — each "scalar base + thread offset" load then needs a 64-bit VALU add)
+    const u32 ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     const int per = p.ndir * p.B;
-    const int U = (int)(ticket / per);               // block-major: a workgroup only waits for smaller tickets
-    const int rem = (int)(ticket % per);
+    const int U = __builtin_amdgcn_readfirstlane((int)(ticket / per));               // block-major: a workgroup only waits for smaller tickets
+    const int rem = __builtin_amdgcn_readfirstlane((int)(ticket % per));
     const bool is_beta = (p.alpha == nullptr) || (p.ndir == 2 && rem >= p.B);
-    const int b = rem % p.B;
+    const int b = __builtin_amdgcn_readfirstlane(rem % p.B);
     const int sd = ((p.ndir == 2 && rem >= p.B) ? 1 : 0) * p.B + b;
     const int T = p.T, L = p.L;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
@@ -764,7 +764,7 @@ template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
     constexpr int TM = DM_TM * MT;
-    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 4 * TM + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
+    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
     auto k = dag_dense_mfma_kernel<D, MT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
