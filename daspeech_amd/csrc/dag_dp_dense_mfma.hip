@@ -103,7 +103,8 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     float* Sb = Et + 2 * DM_ET;                                // [2][TM]          (unused since the rescale factors are published: SCb)
     float* Xd = Sb + 2 * TM;                                   // [8] (of 2 TM)    diagonal block: exponent of each 8-column group of the previous row
     float* SCb = Xd + 2 * TM;                                  // [2][TM]          log2 of the factor a row's sums take before this block (0: none)
-    float* Poff = SCb + 2 * TM;                                // [TM][64]         off-diagonal sums of the tile
+    float* SCf = SCb + 2 * TM;                                 // [2] (of 4)       1 if any row of the block rescales, else 0
+    float* Poff = SCf + 4;                                     // [TM][64]         off-diagonal sums of the tile
     float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
     float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
@@ -378,7 +379,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 if (tl < TM) {
                     const bool ok = row_ok(tl);
                     const float sx = ok ? st_s[s] : DM_SENT;
-                    SCb[nb * TM + tl] = ref_rule(Rt, sx);
+                    const float sc = ref_rule(Rt, sx);
+                    SCb[nb * TM + tl] = sc;
+                    const bool anysc = __any(sc != 0.f);                 // (threads < TM <= 64: all in wave 0)
+                    if (tl == 0) SCf[nb] = anysc ? 1.f : 0.f;
                     FLt = fminf(FLt, (ok && st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
 #pragma unroll
@@ -437,9 +441,9 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    // a row whose reference exponent moved with this block has its sums rescaled first (rare)
-                    const v4f sc4 = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
-                    if (__any(sc4.x != 0.f || sc4.y != 0.f || sc4.z != 0.f || sc4.w != 0.f)) {
+                    // a row whose reference exponent moved with this block has its sums rescaled first (rare: one flag per block)
+                    if (SCf[nb] != 0.f) {
+                        const v4f sc4 = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = dm_exp2(sc4[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
                     }
@@ -479,14 +483,15 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     asm volatile("ds_read_b128 %0, %4\n\t" "ds_read_b128 %1, %4 offset:16\n\t" "ds_read_b128 %2, %4 offset:32\n\t" "ds_read_b128 %3, %4 offset:48"
                                  : "=&v"(fa[mt][0]), "=&v"(fa[mt][1]), "=&v"(fa[mt][2]), "=&v"(fa[mt][3]) : "v"(am) : "memory");
                 }
-                v4f sc4[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) sc4[mt] = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
+                const float scf = SCf[nb];
                 // ---- alpha rows of block V -> A (buffer wb), exponents
                 const int vb = V * DM_BW;
                 if (tl < TM) {
                     const float sx = st_s[s];
-                    SCb[wb * TM + tl] = ref_rule(Rt, sx);
+                    const float sc = ref_rule(Rt, sx);
+                    SCb[wb * TM + tl] = sc;
+                    const bool anysc = __any(sc != 0.f);
+                    if (tl == 0) SCf[wb] = anysc ? 1.f : 0.f;
                     FLt = fminf(FLt, (st_f[s] < 64.f) ? (float)vb + st_f[s] : 1.0e9f);
                 }
 #pragma unroll
@@ -498,10 +503,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     for (int e = 0; e < 4; ++e) Ab[m * DM_AP + e * 16 + q4] = dm_exp2(fmaf(st_a[s][mt][e], DM_LOG2E, -Rm[mt]));
                 }
                 // ---- the pending block's rows: a moved reference exponent rescales the sums first (rare)
+                if (scf != 0.f) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const v4f c4 = sc4[mt];
-                    if (__any(c4.x != 0.f || c4.y != 0.f || c4.z != 0.f || c4.w != 0.f)) {
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const v4f c4 = *reinterpret_cast<const v4f*>(SCb + nb * TM + 16 * mt + 4 * lq);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = dm_exp2(c4[r]); pa[mt][r] *= f; pb[mt][r] *= f; }
                     }
@@ -764,7 +769,7 @@ template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
     constexpr int TM = DM_TM * MT;
-    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
+    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
     auto k = dag_dense_mfma_kernel<D, MT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
