@@ -110,8 +110,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
     int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]              broadcast slot of the readiness poll
     float* A2d = Vd + 68;                                      // [64]             diagonal block: previous row, exact log2 values
-    float* Wd = A2d + 64;                                      // [64][64]         diagonal block: log2 weights [source i][column], -inf for i >= column
-    float* Md = Wd + 64 * 64;                                  // [TM][64]         diagonal block: the chunk's emissions
+    float* Md = A2d + 64;                                      // [TM][64]         diagonal block: the chunk's emissions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tl = tid, wg = wave;
     const int T = p.T, L = p.L, TR = p.TR, NJ = p.NJ;
@@ -173,7 +172,6 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         for (int i = 0; i < 32; ++i) { Ec[i].x = wlog2(ub + 2 * i, u); Ec[i].y = wlog2(ub + 2 * i + 1, u); }
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            Wd[(2 * i) * 64 + ul] = Ec[i].x; Wd[(2 * i + 1) * 64 + ul] = Ec[i].y;           // kept for the in-block exact redo of near-diagonal cells
             Ec[i].x = dm_exp2(Ec[i].x); Ec[i].y = dm_exp2(Ec[i].y);
         }
         // seed row
@@ -682,7 +680,8 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                         if (flag) {
                             float mx = NEG_INF, sum = 0.f;
                             for (int i = flp - ub; i < ul; ++i) {
-                                const float x = A2d[i] + Wd[i * 64 + ul];
+                                const float x = A2d[i] + wlog2(ub + i, u);        // (the log2 weight again from memory: a rare path, and a 16 KB
+                                                                                  //  LDS copy of it would cost the second workgroup per CU)
                                 const float nm = fmaxf(mx, x);
                                 if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
                                 mx = nm;
@@ -760,6 +759,39 @@ __global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
     else dense_mfma_body<D, MT, false>(p, smem_raw, b, U, sd);
 }
 
+// The same kernel limited to 256 VGPRs, so that TWO workgroups share a CU (LDS: 70 KB each): with one wave per SIMD every instruction
+// and every wait of the in-order stream is exposed; a second workgroup fills them.  110 VGPRs spill to scratch for the
+// 32-row chunk and it is still the faster build at every shape (C2 at TR = 4095: 27.5 -> 21.6 ms), results bit-identical.
+template <int D, int MT>
+__global__ __launch_bounds__(256, 2) void dag_dense_mfma_kernel_occ2(DMParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ u32 s_ticket;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
+    __syncthreads();
+    // (readfirstlane: the ticket comes out of LDS and the divisions run on the VALU, so without it the block index, the sample and every
+    //  base pointer derived from them live in VGPRs — each "scalar base + thread offset" load then needs a 64-bit VALU add)
+    const u32 ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    const int per = p.ndir * p.B;
+    const int U = __builtin_amdgcn_readfirstlane((int)(ticket / per));               // block-major: a workgroup only waits for smaller tickets
+    const int rem = __builtin_amdgcn_readfirstlane((int)(ticket % per));
+    const bool is_beta = (p.alpha == nullptr) || (p.ndir == 2 && rem >= p.B);
+    const int b = __builtin_amdgcn_readfirstlane(rem % p.B);
+    const int sd = ((p.ndir == 2 && rem >= p.B) ? 1 : 0) * p.B + b;
+    const int T = p.T, L = p.L;
+    const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
+    const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    if (!valid) {                                    // invalid sample: -inf everywhere, no trap; its other blocks do the same, nobody waits
+        float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * L;
+        for (int t = 0; t < T; ++t)
+            for (int ul = tid; ul < DM_BW; ul += 256) { const int u = U * DM_BW + ul; if (u < L) O[(size_t)t * L + (is_beta ? (L - 1 - u) : u)] = NEG_INF; }
+        return;
+    }
+    if (is_beta) dense_mfma_body<D, MT, true>(p, smem_raw, b, U, sd);
+    else dense_mfma_body<D, MT, false>(p, smem_raw, b, U, sd);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
@@ -769,7 +801,7 @@ template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
     constexpr int TM = DM_TM * MT;
-    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + 64 * 64 + TM * 64) * 4 + 64;
+    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + TM * 64) * 4 + 64;
     auto k = dag_dense_mfma_kernel<D, MT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
@@ -802,7 +834,15 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     // every shape of the r02 sweep on the pipelined kernel (C1 1.53 / 1.53 ms, B=16 T=150 L=1024 0.79 / 0.71, C2 at TR = 4095 38.6 / 31.2
     // for 16- / 32-row chunks; the pre-pipeline kernel had it the other way round: its blocks cost a memory round trip each)
     const int mt = g_dm_mt ? g_dm_mt : 2;
-    if (mt >= 2) return launch_dm<1, 2>(p, nwg, st);     // (two stages of a 32-row chunk do not fit the register file: 18 spills)
+    if (mt >= 2 && g_dm_depth != 9) {                    // default: 32-row chunks, one stage, two workgroups per CU
+        constexpr int TM = DM_TM * 2;
+        const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + TM * 64) * 4 + 64;
+        auto k = dag_dense_mfma_kernel_occ2<1, 2>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
+        return check_launch("dag_loss_fwd(dense mfma)");
+    }
+    if (mt >= 2) return launch_dm<1, 2>(p, nwg, st);     // (dm_depth 9: the one-workgroup-per-CU build of the same kernel, for comparison)
     if (depth <= 1) return launch_dm<1, 1>(p, nwg, st);
     return launch_dm<2, 1>(p, nwg, st);                  // (three stages: 27 spills)
 }
