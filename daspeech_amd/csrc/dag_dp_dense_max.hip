@@ -56,7 +56,7 @@ __device__ __forceinline__ float dx_wave_max(float v) {
 __device__ __forceinline__ float dx_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dx_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
+__device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_ticket;
@@ -307,6 +307,12 @@ __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p)
     }
 }
 
+// Two builds of the same body: 256 VGPRs (31 spilled) so that two workgroups share a CU — the faster one when there are more workgroups
+// than CUs (C2 at TR = 4095: 22.8 -> 18.2 ms) — and the unconstrained one for launches that put at most one workgroup on a CU anyway
+// (C1: 2.18 vs 2.25 ms).
+__global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p) { dag_dense_max_body(p); }
+__global__ __launch_bounds__(256, 2) void dag_dense_max_kernel_occ2(DXParams p) { dag_dense_max_body(p); }
+
 // K7 without a trace tensor: path[b][pos] = t along the chain of arg-max predecessors from (T_b-1, L_b-1), the arg-max recomputed from
 // alpha_max and the links for the one cell per row the chain visits.  Tie rule: smallest predecessor index among equal maxima.
 __global__ __launch_bounds__(256) void dag_dense_backtrace_kernel(const float* __restrict__ alpha, const float* __restrict__ links,
@@ -390,8 +396,12 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float*>(reinterpret_cast<char*>(area) + prog_bytes);
     const size_t lds = (size_t)(2 * DX_TM * 64 + 2 * 64 * DX_WP + 2 * DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4) * 4 + 64;
-    (void)hipFuncSetAttribute((const void*)dag_dense_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dag_dense_max_kernel, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    auto k = (B * NJ > ncu) ? dag_dense_max_kernel_occ2 : dag_dense_max_kernel;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");
     if (rc) return rc;
     const size_t lds2 = (size_t)L * 4;
