@@ -480,7 +480,8 @@ def test_alignment_large_graph_properties(L):
 
 # ---------------------------------------------------------------------------------------------- dense window on the f32 matrix cores
 DENSE_SHAPES = [(3, 24, 200, 199), (2, 40, 256, 255), (4, 33, 130, 129), (2, 20, 500, 100), (2, 70, 400, 399), (1, 9, 1024, 1023),
-                (3, 18, 192, 191), (2, 50, 640, 639)]
+                (3, 18, 192, 191), (2, 50, 640, 639),
+                (44, 10, 448, 447)]       # 308 workgroups per direction: more than CUs, so the two-workgroups-per-CU builds run
 
 
 @pytest.mark.parametrize("masked", [False, True])
