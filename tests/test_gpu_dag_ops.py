@@ -682,3 +682,54 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
     finally:
         _lib.set_option("dp_path", 0)
     assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == 1          # no B*T*L trace tensor for dense windows either
+
+
+def _relink(links, ol, seed):
+    """masked log-softmax transitions for edited lengths (make_dag_inputs' rule)"""
+    B, L, TR = links.shape
+    for bb in range(B):
+        i = np.arange(L)[:, None]; d = np.arange(TR)[None, :]
+        valid = (i + d + 1) < ol[bb]
+        raw = np.where(valid, np.random.default_rng(seed + bb).standard_normal((L, TR)), -np.inf)
+        mx = np.max(np.where(valid, raw, -1e30), axis=-1, keepdims=True)
+        e = np.where(valid, np.exp(raw - mx), 0.0); ssum = e.sum(-1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            links[bb] = np.where(valid, raw - mx - np.log(np.where(ssum > 0, ssum, 1.0)), -np.inf).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 130, 129), (1, 2, 128, 127), (3, 40, 129, 65), (2, 5, 193, 192), (2, 33, 257, 200), (3, 17, 320, 66),
+                                   (2, 64, 128, 127), (1, 31, 4160, 4159)])
+def test_dense_kernels_edge_shapes(shape):
+    """The three dense-window kernel families (forward DP, block-product gradient, max-plus alignment) at the edges of their support:
+    T = 1 (the end is unreachable: -inf loss, as the reference's), T = 2, L = 128 and windows of 65 / 66, L not a multiple of the
+    64-column block, a graph barely longer than its target, a one-vertex one-token sample, L > 4096 — against the fp64 / f32 oracle."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(23 + L + T, B, T, L, TR, ragged=T > 1)
+    if B > 1 and T > 2:
+        ol[0] = max(int(tl[0]), min(L, int(tl[0]) + 3))
+    if B > 2:
+        tl[2] = 1; ol[2] = 1
+    if (B > 1 and T > 2) or B > 2:
+        _relink(links, ol, L)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_(); k.requires_grad_()
+    loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    assert _lib.last_launch_status() == 0
+    fin = torch.isfinite(loss)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    assert np.array_equal(fin.cpu().numpy(), np.isfinite(b64[:, 0, 0]))
+    a, b = alpha.cpu().numpy(), beta.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
+    assert not np.isnan(a).any() and not np.isnan(b).any()
+    fa, fb = np.isfinite(a64), np.isfinite(b64)
+    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T + 1e-4)
+    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T + 1e-4)
+    if fin.any():
+        gm, gk = torch.autograd.grad(loss[fin].sum(), [m, k])
+        gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+        np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
+    if fin.all():
+        path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+        np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
