@@ -109,6 +109,23 @@ class VariancePredictor(nn.Module):
         self.proj = nn.Linear(hidden, 1)
 
     def forward(self, x: Tensor) -> Tensor:
+        from .. import decode_ops as _dops
+        c1, c2 = self.conv1[0], self.conv2[0]
+        if (_dops.SPLIT_GEMM and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                and not torch.is_autocast_enabled() and c1.weight.dtype == torch.float32 and x.is_contiguous()):
+            # eval, fp32: both convolutions on the matrix cores at fp32 accuracy (operand splitting), channels-last, no transposes
+            # (MIOpen runs these small k=3 convolutions as one im2col + GEMM PER SAMPLE: ~190 launches and 2 ms per batch of 32)
+            key = (c1.weight.data_ptr(), c1.weight._version, c2.weight.data_ptr(), c2.weight._version)
+            if getattr(self, "_split_key", None) != key:
+                ok = all(c.stride == (1,) and c.dilation == (1,) and c.groups == 1 and c.padding == ((c.kernel_size[0] - 1) // 2,) for c in (c1, c2))
+                ok = ok and all(ci in (128, 256, 512) or ci % 512 == 0 for ci in (c1.in_channels, c2.in_channels))
+                ok = ok and all(c.out_channels % 4 == 0 for c in (c1, c2))
+                self._split = (_dops.SplitConv1d(c1.weight, c1.bias), _dops.SplitConv1d(c2.weight, c2.bias)) if ok else None
+                self._split_key = key
+            if self._split is not None:
+                h = _dops.layer_norm(self._split[0](x, relu=True), self.ln1)
+                h = _dops.layer_norm(self._split[1](h, relu=True), self.ln2)
+                return self.proj(h).squeeze(2)
         x = self.ln1(self.conv1(x.transpose(1, 2)).transpose(1, 2))
         x = self.ln2(self.conv2(x.transpose(1, 2)).transpose(1, 2))
         return self.proj(x).squeeze(2)
