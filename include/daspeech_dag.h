@@ -135,7 +135,9 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   log-space dense, 2 = banded 2-column log-space strips, 4 = strip2 (2 vertices per lane), 5 = strip4g (exp-space, one exponent per
  *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment),
  *   9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
- *   cross-check the families.
+ *   cross-check the families.  "k5_path": 0 = auto, 1 = tiled log-space grad_links kernel, 2 = exp-space (TR <= 32) / block products
+ *   (TR > 64).  "dm_mt" 1|2: rows per chunk of the dense kernel in MFMA row tiles (default 2 = 32 rows), "dm_depth" 1|2: its register
+ *   stages in flight with dm_mt 1 (9 with dm_mt 2: the one-workgroup-per-CU build), "force_generic", "dm_*" affect speed only.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);
