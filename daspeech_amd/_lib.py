@@ -140,6 +140,12 @@ def last_fallback_count() -> int:
     return int(load().dsp_dag_last_fallback_count())
 
 
+def last_dense_gave_up() -> bool:
+    """True when the launch inspected by last_launch_status() was a dense-window matrix-core DP that gave up on its batch (exact-redo
+    budget spent) and left the result to its stand-by log-space kernels (dag_dp_dense_mfma.hip, `aborted`)."""
+    return bool(load().dsp_dag_debug_words()[2])
+
+
 def debug_fallback_cells():
     """(sample, row, column, S) of the first fallback cells of the launch inspected by last_launch_status()."""
     import struct

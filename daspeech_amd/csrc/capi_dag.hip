@@ -29,6 +29,9 @@ bool dense_mfma_supported(int L, int TR);
 int launch_dag_dense_mfma(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 void set_dm_depth(int v);
 void set_dm_mt(int v);
+void set_dm_budget(int v);
+size_t dense_rows_gated_bytes(int B, int L, int ndir);
+bool dense_rows_gated_supported(int L);
 
 bool dense_max_supported(int L, int TR);
 int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
@@ -72,7 +75,11 @@ extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
         halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
     } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
-        halo = align256((size_t)2 * B * NJ * 4) + (size_t)2 * B * T * NJ * 8;
+        halo = align256((size_t)2 * B * NJ * 4) + align256((size_t)2 * B * T * NJ * 8);
+        // ... and its stand-by log-space kernels (a batch whose transitions exp space cannot hold): hand-off rows + the re-laid-out
+        // ("incoming") copy of the transition matrix
+        if (dense_mfma_supported(L, TR) && dense_rows_gated_supported(L))
+            return align256(256 + halo + dense_rows_gated_bytes(B, L, 2)) + align256((size_t)B * L * TR * 4) + 1024;
     }
     return align256(256 + halo) + 512;
 }
@@ -217,6 +224,7 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_depth")) { set_dm_depth(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
+    if (name && !strcmp(name, "dm_budget")) { set_dm_budget(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");
     return DSP_EINVAL;

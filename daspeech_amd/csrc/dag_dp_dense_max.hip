@@ -49,8 +49,9 @@ __device__ __forceinline__ float dx_wave_max(float v) {
                  "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
                  "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
-    return fmaxf(fmaxf(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-                 fmaxf(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    // (the readlane builtin is typed int -> int: a float argument would be CONVERTED — -inf became -2^31, and no dead block was ever skipped)
+    auto rl = [](float x, int l) -> float { return __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); };
+    return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
 }
 
 __device__ __forceinline__ float dx_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <algorithm>
 
 namespace dsp {
 
@@ -43,12 +44,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct DMParams {
     const float* match; const float* links; const int64_t* out_len; const int64_t* tgt_len;
     float* alpha; float* beta;
-    u32* counters;            // [0] ticket, [1] error word, [2] exact-fallback cells
+    u32* counters;            // [0] ticket, [1] error word, [2] exact-fallback cells, [3] abort flag, [4] predecessors visited by the exact redo
     u32* progress;            // [ndir * B][NJ]        tag_base + chunks completed
     float2* S;                // [ndir * B][T][NJ]     (.x block exponent or DM_SENT, .y first live column of the block (0..63) or 64)
     u32 tag_base;
     int B, T, L, TR, NJ, ndir;
     int dbg;                  // 2 = DSP_DEBUG=prof: cycle accounting of one workgroup (counters[40..47])
+    u32 exact_budget;         // predecessors the exact redo may visit before the launch gives up: see launch_dag_dense_mfma
 };
 
 constexpr int DM_BW = 64;                   // column block
@@ -60,6 +62,8 @@ constexpr u32 DM_SPIN_LIMIT = 1u << 24;
 __device__ __forceinline__ float dm_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dm_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float dm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// (the builtin is typed int -> int: a float argument would be CONVERTED, i.e. truncated to an integer value)
+__device__ __forceinline__ float dm_readlane(float v, int l) { return __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
 
 // maximum over aligned groups of 8 lanes, result in every lane of the group (v_max_f32 with a DPP source; 2 wait states behind the write)
 __device__ __forceinline__ float dm_max8(float v) {
@@ -108,7 +112,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
     float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
-    int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]              broadcast slot of the readiness poll
+    int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]              [0] broadcast slot of the readiness poll, [1] "the launch gave up"
     float* A2d = Vd + 68;                                      // [64]             diagonal block: previous row, exact log2 values
     float* Md = A2d + 64;                                      // [TM][64]         diagonal block: the chunk's emissions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,7 +162,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         ref = dm_prefmax_groups(xs);
         const u64 lv = __ballot(a2 != NEG_INF);
         fl_prev = lv ? (ub + (int)__builtin_ctzll(lv)) : (1 << 30);
-        const float sblk = __builtin_amdgcn_readlane(ref, 63);
+        const float sblk = dm_readlane(ref, 63);
         if (lane == 0) {
             dm_st(&S[(size_t)tt * NJ + U].x, sblk);
             dm_st(&S[(size_t)tt * NJ + U].y, lv ? (float)__builtin_ctzll(lv) : 64.f);
@@ -175,6 +179,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             Ec[i].x = dm_exp2(Ec[i].x); Ec[i].y = dm_exp2(Ec[i].y);
         }
         // seed row
+        if (lane == 0) RDY[1] = 0;
         const bool seed = (u == u0) && u < L;
         const float m0 = seed ? M[(size_t)row(0) * L + col(u)] * DM_LOG2E : NEG_INF;
         row_end(m0, 0);
@@ -207,7 +212,13 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     const bool prof = (p.dbg & 2) && sd == 0 && U == p.NJ - 1;
     u64 pf_ready = 0, pf_gemm = 0, pf_diag = 0, pf_last = prof ? __builtin_amdgcn_s_memtime() : 0;
     auto stamp = [&](u64& acc) { if (prof) { const u64 t = __builtin_amdgcn_s_memtime(); acc += t - pf_last; pf_last = t; } };
-    for (int c = 0; c < nchunks; ++c) {
+    // Giving up.  Data the exp-space products cannot represent (transitions weaker than 2^-126 everywhere: every sum is exactly zero
+    // and every cell takes the exact log-space redo) would make this kernel many times slower than the row-sequential log-space one
+    // (r02: 12.5 ms against 0.7 ms on a training batch with such links).  The redo row events are counted; past the launch's budget a
+    // flag goes up (counters[3]), every workgroup sees it at its next poll / chunk and returns, and the log-space kernels queued
+    // behind this launch — which return at once while the flag is down — compute the whole result instead.
+    bool aborted = false;
+    for (int c = 0; c < nchunks && !aborted; ++c) {
         const int tt0 = c * TM;
         // ================================================================ off-diagonal products: source blocks V < U
         // The tile's sums stay in the MFMA accumulators across ALL source blocks (reading them back per block stalls the wave for the
@@ -274,12 +285,17 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                         const u64 okm = __ballot((int)(pv - want) >= 0);
                         const int npref = (~okm) ? (int)__builtin_ctzll(~okm) : 64;        // complete blocks in a row from ready_hi + 1
                         if (ready_hi + npref >= V) { if (lane == 0) RDY[0] = ready_hi + npref; break; }
+                        if (__hip_atomic_load(&p.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {       // nobody will publish any more
+                            if (lane == 0) { RDY[0] = U; RDY[1] = 1; }
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(2);
                         if (++spins > DM_SPIN_LIMIT) { if (lane == 0) { atomicOr(&p.counters[1], 4u); RDY[0] = U; } break; }
                     }
                 }
                 __syncthreads();
                 ready_hi = RDY[0];
+                aborted |= RDY[1] != 0;
                 __syncthreads();
                 stamp(pf_ready);
             };
@@ -612,8 +628,20 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         __syncthreads();
 
         // ================================================================ diagonal block: rows of the chunk in sequence (wave 0)
-        if (wave == 0) {
+        if (wave == 0 && !aborted) {
             const int m_lo = (tt0 == 0) ? 1 : 0, m_hi = min(TM, Tb - tt0);
+            bool gave_up = false;
+            // the exact redo's accounts: kept in registers and posted (one atomic each, plus a look at the give-up flag) once 256
+            // predecessors have been visited or the chunk ends — the everyday redo next to the diagonal must not pay a memory round
+            // trip per row, it sits on the critical path of every block to its right
+            u32 loc_vis = 0, loc_cells = 0;
+            auto post = [&]() {
+                u32 ev = 0;
+                if (lane == 0) { ev = atomicAdd(&p.counters[4], loc_vis); atomicAdd(&p.counters[2], loc_cells); }
+                ev = (u32)__builtin_amdgcn_readfirstlane((int)ev);
+                if (ev + loc_vis >= p.exact_budget || __hip_atomic_load(&p.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = true;
+                loc_vis = 0; loc_cells = 0;
+            };
             // this row's LDS operands are requested one row ahead
             float n_m2 = Md[m_lo * 64 + ul], n_ro = Roff[m_lo], n_flo = FLo[m_lo], n_po = Poff[m_lo * 64 + ul];
             const u32 vd_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)Vd;
@@ -673,57 +701,69 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 if (!in_graph || !has_pred) a2 = NEG_INF;
                 if (BETA && (L - 1 - u) < row(tt)) { a2 = NEG_INF; flag = false; }          // K3 only visits columns j >= t (dag_loss.cu loop bounds)
                 if (__any(flag)) {
-                    // (a) every live predecessor inside this block (the DP's diagonal runs through it: the cells next to the diagonal are
-                    //     tens of binades per column under their right-hand neighbours, beyond any shared exponent): a handful of terms,
-                    //     summed in log space from the exact row and the log weights in LDS, all flagged lanes at once
-                    if (flp >= ub) {
-                        if (flag) {
-                            float mx = NEG_INF, sum = 0.f;
-                            for (int i = flp - ub; i < ul; ++i) {
-                                const float x = A2d[i] + wlog2(ub + i, u);        // (the log2 weight again from memory: a rare path, and a 16 KB
-                                                                                  //  LDS copy of it would cost the second workgroup per CU)
+                    const u64 fm = __ballot(flag);
+                    if (fm) {
+                        // Exact log-space redo of ALL flagged columns of the row at once: the previous row is walked once, 64 columns per
+                        // coalesced load (this block's own part from LDS: the exact row), and only its LIVE columns left of the last flagged
+                        // one are visited — each flagged lane adds that predecessor's term (its own transition weight: one gather per
+                        // lane and live predecessor).  The everyday customers are the cells next to the DP's diagonal (tens of binades per
+                        // column under their right-hand neighbours, beyond any shared exponent: a handful of predecessors); the expensive
+                        // ones are rows whose sums underflow wholesale — they are what the launch's budget counts (one unit per visited
+                        // predecessor).  One column at a time, each with its own wave-wide scan over the whole row, this was 13.5 ms of
+                        // a training step's 0.3 ms forward (r02: 263 k such cells per batch).
+                        float mx = NEG_INF, sum = 0.f;
+                        u32 visited = 0;
+                        const int v_first = __builtin_amdgcn_readfirstlane(flp);
+                        const int u_hi = ub + 63 - (int)__builtin_clzll(fm);                               // last flagged column
+                        const float* prow = O + (size_t)row(tt - 1) * L;
+                        for (int v0 = v_first - (v_first & 63); v0 < u_hi; v0 += 64) {        // (chunks aligned with the column blocks)
+                            const int v = v0 + lane;
+                            float pv;
+                            if (v0 >= ub) pv = A2d[lane];                                                  // this block: exact log2 values of the previous row
+                            else pv = (v >= 0 && v < L) ? dm_ld(prow + col(v)) * DM_LOG2E : NEG_INF;
+                            if (v < v_first || v >= u_hi) pv = NEG_INF;                                    // (no flagged column has it as a predecessor)
+                            u64 lm = __ballot(pv != NEG_INF);
+                            visited += (u32)__builtin_popcountll(lm);
+                            while (lm) {
+                                const int kq = (int)__builtin_ctzll(lm); lm &= lm - 1;
+                                const float av = dm_readlane(pv, kq);
+                                const int vv = v0 + kq;
+                                const float x = (flag && vv < u) ? av + wlog2(vv, u) : NEG_INF;                 // (-inf outside the window)
                                 const float nm = fmaxf(mx, x);
                                 if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
                                 mx = nm;
                             }
-                            a2 = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx + m2);
-                            flag = false;
                         }
-                    }
-                    u64 fm = __ballot(flag);
-                    while (fm) {                 // (b) exact log-space redo, one flagged column at a time, the wave scans its predecessors
-                        const int fu_l = (int)__builtin_ctzll(fm); fm &= fm - 1;
-                        const int fu = ub + fu_l;
-                        const int v_lo = max(__builtin_amdgcn_readfirstlane(flp), fu - TR);
-                        float mx = NEG_INF, sum = 0.f;
-                        for (int v = v_lo + lane; v < fu; v += 64) {
-                            const float x = dm_ld(O + (size_t)row(tt - 1) * L + col(v)) * DM_LOG2E + wlog2(v, fu);
-                            const float nm = fmaxf(mx, x);
-                            if (nm != NEG_INF) sum = sum * dm_exp2(mx - nm) + dm_exp2(x - nm);
-                            mx = nm;
+                        if (flag) a2 = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx + m2);
+                        // diagnostics: the first flagged cells of the launch (sample | dir, step, column, the distrusted sum) — slots by row event
+                        if (lane == 0 && loc_cells == 0) {
+                            const u32 slot = __hip_atomic_load(&p.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (slot < 14) {
+                                const int fu_l = (int)__builtin_ctzll(fm);
+                                p.counters[8 + 4 * slot] = (u32)sd | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)tt; p.counters[10 + 4 * slot] = (u32)(ub + fu_l);
+                                p.counters[11 + 4 * slot] = __float_as_uint(dm_readlane(P, fu_l));
+                            }
                         }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const float m2o = __shfl_xor(mx, o, 64), s2o = __shfl_xor(sum, o, 64);
-                            const float nm = fmaxf(mx, m2o);
-                            sum = (nm == NEG_INF) ? 0.f : sum * dm_exp2(mx - nm) + s2o * dm_exp2(m2o - nm);
-                            mx = nm;
-                        }
-                        const float exact = (mx == NEG_INF) ? NEG_INF : (__builtin_amdgcn_logf(sum) + mx);
-                        if (lane == fu_l) a2 = exact + m2;
-                        if (lane == fu_l) {      // diagnostics: first flagged cells of the launch (sample | dir, step, column, the distrusted sum)
-                            const u32 slot = atomicAdd(&p.counters[2], 1u);
-                            if (slot < 14) { p.counters[8 + 4 * slot] = (u32)sd | (BETA ? 0x100u : 0u); p.counters[9 + 4 * slot] = (u32)tt; p.counters[10 + 4 * slot] = (u32)fu; p.counters[11 + 4 * slot] = __float_as_uint(P); }
-                        }
+                        loc_vis += visited; loc_cells += (u32)__builtin_popcountll(fm);
+                        if (loc_vis >= 256u) post();
                     }
                 }
                 row_end(a2, tt);
+                if (gave_up) break;
             }
+            if (loc_cells && !gave_up) post();
             // ---- publish the chunk: everything above was stored write-through; drain, then the progress word
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(prog + U, p.tag_base + (u32)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gave_up) {
+                if (lane == 0) { __hip_atomic_store(&p.counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); RDY[1] = 1; }
+            } else {
+                if (lane == 0) __hip_atomic_store(prog + U, p.tag_base + (u32)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (one look per chunk, so that workgroups which never wait — the first blocks — stop as well)
+                if (__hip_atomic_load(&p.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && lane == 0) RDY[1] = 1;
+            }
         }
         __syncthreads();
+        aborted |= RDY[1] != 0;
         stamp(pf_diag);
     }
     if (prof && tid == 0) { p.counters[40] = (u32)(pf_ready >> 4); p.counters[41] = (u32)(pf_gemm >> 4); p.counters[42] = (u32)(pf_diag >> 4); p.counters[43] = (u32)nchunks; }
@@ -733,10 +773,11 @@ template <int D, int MT>
 __global__ __launch_bounds__(256) void dag_dense_mfma_kernel(DMParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ u32 s_ticket;
+    __shared__ u32 s_ticket, s_gone;
     const int tid = threadIdx.x;
-    if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
+    if (tid == 0) { s_ticket = atomicAdd(&p.counters[0], 1u); s_gone = __hip_atomic_load(&p.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __syncthreads();
+    if (s_gone) return;                              // the launch gave up (see `aborted` in the body): the log-space kernels behind it do the work
     // (readfirstlane: the ticket comes out of LDS and the divisions run on the VALU, so without it the block index, the sample and every
     //  base pointer derived from them live in VGPRs — each "scalar base + thread offset" load then needs a 64-bit VALU add)
     const u32 ticket = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -766,10 +807,11 @@ template <int D, int MT>
 __global__ __launch_bounds__(256, 2) void dag_dense_mfma_kernel_occ2(DMParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ u32 s_ticket;
+    __shared__ u32 s_ticket, s_gone;
     const int tid = threadIdx.x;
-    if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
+    if (tid == 0) { s_ticket = atomicAdd(&p.counters[0], 1u); s_gone = __hip_atomic_load(&p.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __syncthreads();
+    if (s_gone) return;                              // the launch gave up (see `aborted` in the body): the log-space kernels behind it do the work
     // (readfirstlane: the ticket comes out of LDS and the divisions run on the VALU, so without it the block index, the sample and every
     //  base pointer derived from them live in VGPRs — each "scalar base + thread offset" load then needs a 64-bit VALU add)
     const u32 ticket = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -792,8 +834,35 @@ __global__ __launch_bounds__(256, 2) void dag_dense_mfma_kernel_occ2(DMParams p)
     else dense_mfma_body<D, MT, false>(p, smem_raw, b, U, sd);
 }
 
+// Can exp space hold this batch's transitions at all?  A finite weight under 2^-126 converts to an exact zero; its term is lost, and with
+// A values of up to 2^60 (the rows' reference exponents only move in jumps of 60 binades) the lost term can be 2^24 times LARGER than a
+// sum the 2^-90 guard still trusts (r02: 2 cells of a 6 x 40 x 330 batch with -100 ... -400 nat transitions off by 3.4 nats).  Batches
+// without such weights cannot lose a term that way — log_softmax outputs of trained models stay far above e^-86 — so one streaming pass
+// over the transition matrix certifies the fast path; a batch that fails it raises the give-up flag before the DP kernel starts and
+// goes to the stand-by log-space kernels as a whole.
+__global__ __launch_bounds__(256) void dag_links_weak_kernel(const float* __restrict__ links, size_t n, u32* flag)
+{
+    constexpr float WEAK = -86.0f;                    // nats; exp2(w log2 e) flushes to zero under -87.3
+    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+    bool weak = false;
+    const size_t head = min(n, (size_t)((16 - ((uintptr_t)links & 15)) & 15) / 4);              // elements before the first 16-byte boundary
+    const size_t n4 = (n - head) / 4;
+    const v4f* L4 = reinterpret_cast<const v4f*>(links + head);
+    for (size_t i = gtid; i < n4; i += gsz) {
+        const v4f x = L4[i];
+        weak |= (x.x < WEAK && x.x != NEG_INF) | (x.y < WEAK && x.y != NEG_INF) | (x.z < WEAK && x.z != NEG_INF) | (x.w < WEAK && x.w != NEG_INF);
+    }
+    if (gtid < head) { const float x = links[gtid]; weak |= x < WEAK && x != NEG_INF; }
+    if (gtid < n - head - 4 * n4) { const float x = links[head + 4 * n4 + gtid]; weak |= x < WEAK && x != NEG_INF; }
+    if (__any(weak) && (threadIdx.x & 63) == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
+size_t dense_rows_gated_bytes(int B, int L, int ndir);
+bool dense_rows_gated_supported(int L);
+int launch_dag_dense_rows_gated(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int,
+                                unsigned int*, unsigned long long*, unsigned int, const unsigned int*, hipStream_t);
 
 bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31); }
 
@@ -808,9 +877,10 @@ static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
     return check_launch("dag_loss_fwd(dense mfma)");
 }
 
-static thread_local int g_dm_depth = 0, g_dm_mt = 0;      // (diagnostic switches are per calling thread, like dp_path)
+static thread_local int g_dm_depth = 0, g_dm_mt = 0, g_dm_budget = 0;      // (diagnostic switches are per calling thread, like dp_path)
 void set_dm_depth(int v) { g_dm_depth = v; }
 void set_dm_mt(int v) { g_dm_mt = v; }
+void set_dm_budget(int v) { g_dm_budget = v; }          // 0 = auto, -1 = no stand-by (never give up), n > 0 = that many visited predecessors
 
 int launch_dag_dense_mfma(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                           float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
@@ -822,12 +892,29 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NJ = NJ; p.ndir = ndir;
     { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; }
     const size_t prog_bytes = ((size_t)ndir * B * NJ * sizeof(u32) + 255) / 256 * 256;
-    const size_t s_bytes = (size_t)ndir * B * T * NJ * sizeof(float2);
+    const size_t s_bytes = ((size_t)ndir * B * T * NJ * sizeof(float2) + 255) / 256 * 256;
+    // the stand-by log-space kernels (see `aborted` in the kernel).  A predecessor visited by the exact redo costs about one memory
+    // latency, roughly what a DP row of a block costs when nothing is flagged: the launch may visit one per (row, block) pair on average
+    // before it hands the batch over (ordinary batches: a handful per row next to the diagonal)
+    const bool standby = g_dm_budget >= 0 && dense_rows_gated_supported(L);
+    const size_t gran_bytes = standby ? dense_rows_gated_bytes(B, L, ndir) : 0;
+    p.exact_budget = !standby ? 0xFFFFFFFFu : g_dm_budget > 0 ? (u32)g_dm_budget : (u32)(4096 + (size_t)ndir * B * T * NJ);
     u64* area = nullptr;
-    int rc = banded_acquire_ws(st, prog_bytes + s_bytes, T, &p.counters, &area, &p.tag_base);
+    int rc = banded_acquire_ws(st, prog_bytes + s_bytes + gran_bytes, T, &p.counters, &area, &p.tag_base);
     if (rc) return rc;
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float2*>(reinterpret_cast<char*>(area) + prog_bytes);
+    u64* gran = reinterpret_cast<u64*>(reinterpret_cast<char*>(area) + prog_bytes + s_bytes);
+    if (standby) {
+        const size_t n = (size_t)B * L * TR;
+        const unsigned g = (unsigned)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(dag_links_weak_kernel, dim3(g), dim3(256), 0, st, links, n, p.counters + 3);
+        if ((rc = check_launch("dag_loss_fwd(dense mfma, transition range)"))) return rc;
+    }
+    auto then_standby = [&](int rc0) -> int {
+        if (rc0 || !standby) return rc0;
+        return launch_dag_dense_rows_gated(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, p.counters, gran, p.tag_base, p.counters + 3, st);
+    };
     const int nwg = ndir * B * NJ;
     const int depth = g_dm_depth ? g_dm_depth : 2;       // source blocks in flight per workgroup
     // 16-row MFMA tiles per chunk: 2 (32-row chunks, one register stage) halves the source blocks per DP row and was faster or equal at
@@ -840,11 +927,11 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
         auto k = dag_dense_mfma_kernel_occ2<1, 2>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
-        return check_launch("dag_loss_fwd(dense mfma)");
+        return then_standby(check_launch("dag_loss_fwd(dense mfma)"));
     }
-    if (mt >= 2) return launch_dm<1, 2>(p, nwg, st);     // (dm_depth 9: the one-workgroup-per-CU build of the same kernel, for comparison)
-    if (depth <= 1) return launch_dm<1, 1>(p, nwg, st);
-    return launch_dm<2, 1>(p, nwg, st);                  // (three stages: 27 spills)
+    if (mt >= 2) return then_standby(launch_dm<1, 2>(p, nwg, st));     // (dm_depth 9: the one-workgroup-per-CU build of the same kernel, for comparison)
+    if (depth <= 1) return then_standby(launch_dm<1, 1>(p, nwg, st));
+    return then_standby(launch_dm<2, 1>(p, nwg, st));                  // (three stages: 27 spills)
 }
 
 }  // namespace dsp

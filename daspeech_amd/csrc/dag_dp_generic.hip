@@ -246,13 +246,19 @@ static const float* transposed_links(const float* links, int B, int L, int TR, h
 // — for alpha / max-alpha from the "incoming" copy IN[b][j][d-1] = links[b][j-d][d-1] built by dag_incoming_links_kernel, for
 // beta straight from links[b][j][:].  One online (max, sum) per lane, a wave shuffle reduction per column, one coalesced row
 // store per DP row.
-__global__ __launch_bounds__(256) void dag_incoming_links_kernel(const float* __restrict__ links, float* __restrict__ in, int L, int TR)
+// `gate` (both kernels below): when given, the launch is a stand-by — it returns at once unless the word is non-zero.  That is how the
+// matrix-core DP (dag_dp_dense_mfma.hip) hands a batch it gave up on to these log-space kernels without a host round trip.
+__global__ __launch_bounds__(256) void dag_incoming_links_kernel(const float* __restrict__ links, float* __restrict__ in, int L, int TR,
+                                                                 const unsigned int* gate)
 {
-    const int b = blockIdx.z, j = blockIdx.y;
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const int b = blockIdx.z;
     const float* src = links + (size_t)b * L * TR;
-    float* dst = in + ((size_t)b * L + j) * TR;
-    for (int d = blockIdx.x * blockDim.x + threadIdx.x + 1; d <= TR; d += gridDim.x * blockDim.x)
-        dst[d - 1] = (j - d >= 0) ? src[(size_t)(j - d) * TR + (d - 1)] : NEG_INF;
+    for (int j = blockIdx.y; j < L; j += gridDim.y) {
+        float* dst = in + ((size_t)b * L + j) * TR;
+        for (int d = blockIdx.x * blockDim.x + threadIdx.x + 1; d <= TR; d += gridDim.x * blockDim.x)
+            dst[d - 1] = (j - d >= 0) ? src[(size_t)(j - d) * TR + (d - 1)] : NEG_INF;
+    }
 }
 
 template <int MODE>      // 0: log-sum (alpha, or beta when blockIdx.y == 1 / alpha == nullptr); 1: max + trace (alpha direction)
@@ -260,8 +266,9 @@ __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
     const float* __restrict__ match, const float* __restrict__ links, const float* __restrict__ incoming,
     const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
     float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ trace, int B, int T, int L, int TR,
-    unsigned int* __restrict__ row_count, unsigned long long* __restrict__ gran, unsigned int tag_base)
+    unsigned int* __restrict__ row_count, unsigned long long* __restrict__ gran, unsigned int tag_base, const unsigned int* gate)
 {
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;        // stand-by launch, not needed
     // gridDim.z = NS workgroups share one (sample, direction): workgroup s takes every NS-th group of NW*4 columns of a row
     // (interleaved: the work per column grows with the column index), writes its cells straight to the output row in HBM,
     // and publishes them in a tagged hand-off row from which all NS workgroups re-read the complete row into LDS.
@@ -415,11 +422,12 @@ __global__ __launch_bounds__(DP_THREADS) void dag_dense_kernel(
 static std::mutex g_in_mutex;
 static std::unordered_map<unsigned long long, std::pair<void*, size_t>> g_in;
 
-static const float* incoming_links(const float* links, int B, int L, int TR, hipStream_t st)
+static const float* incoming_links(const float* links, int B, int L, int TR, hipStream_t st, const unsigned int* gate = nullptr)
 {
     int gx0 = (TR + 255) / 256; if (gx0 > 8) gx0 = 8;
+    const int gy = gate ? (L < 128 ? L : 128) : L;              // a stand-by launch keeps its (normally idle) grid small
     if (void* c = caller_ws_take((size_t)B * L * TR * sizeof(float))) {
-        hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx0, L, B), dim3(256), 0, st, links, (float*)c, L, TR);
+        hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx0, gy, B), dim3(256), 0, st, links, (float*)c, L, TR, gate);
         return (const float*)c;
     }
     std::lock_guard<std::mutex> lock(g_in_mutex);
@@ -433,8 +441,7 @@ static const float* incoming_links(const float* links, int B, int L, int TR, hip
         if (hipMalloc(&e.first, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         e.second = need;
     }
-    int gx = (TR + 255) / 256; if (gx > 8) gx = 8;
-    hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx, L, B), dim3(256), 0, st, links, (float*)e.first, L, TR);
+    hipLaunchKernelGGL(dag_incoming_links_kernel, dim3(gx0, gy, B), dim3(256), 0, st, links, (float*)e.first, L, TR, gate);
     return (const float*)e.first;
 }
 
@@ -487,7 +494,7 @@ int launch_dag_fwd_generic(const float* match, const float* links, const int64_t
             int rcw = banded_acquire_ws(st, (size_t)B * ndir * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);
             if (rcw) return rcw;
             hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir, NS), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
-                               alpha, beta, (int32_t*)nullptr, B, T, L, TR, cnt, gran, tag_base);
+                               alpha, beta, (int32_t*)nullptr, B, T, L, TR, cnt, gran, tag_base, (const unsigned int*)nullptr);
             return check_launch("dag_loss_fwd(dense)");
         }
     }
@@ -496,6 +503,26 @@ int launch_dag_fwd_generic(const float* match, const float* links, const int64_t
     hipLaunchKernelGGL(dag_logsum_generic_kernel, dim3(B, ndir), dim3(DP_THREADS), lds, st, match, lk, out_len, tgt_len,
                        alpha, beta, B, T, L, TR, sR, sD, sB);
     return check_launch("dag_loss_fwd(generic)");
+}
+
+// The log-space row kernels as a stand-by behind the matrix-core DP (see `gate` above).  The caller owns the status words (`cnt`: the
+// error word is shared with its own kernel) and the hand-off rows (`gran`, dense_rows_gated_bytes()).  false = no stand-by possible for
+// this shape (the DP row does not fit the LDS, or no room for the re-laid-out transition copy): the caller then never gives up.
+size_t dense_rows_gated_bytes(int B, int L, int ndir) { return (size_t)B * ndir * 2 * L * sizeof(unsigned long long); }
+bool dense_rows_gated_supported(int L) { return 2 * (size_t)L * sizeof(float) <= 160 * 1024; }
+int launch_dag_dense_rows_gated(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                float* alpha, float* beta, int B, int T, int L, int TR,
+                                unsigned int* cnt, unsigned long long* gran, unsigned int tag_base, const unsigned int* gate, hipStream_t st)
+{
+    const size_t lds = 2 * (size_t)L * sizeof(float);
+    const int ndir = (alpha && beta) ? 2 : 1;
+    const float* in = alpha ? incoming_links(links, B, L, TR, st, gate) : links;
+    if (!in) { set_error("dag_loss_fwd: no memory for the stand-by log-space path (B*L*TR*4 bytes)"); return DSP_ENOSPC; }
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int NS = dense_slices(dag_dense_kernel<0>, lds, B * ndir, L);
+    hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir, NS), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
+                       alpha, beta, (int32_t*)nullptr, B, T, L, TR, cnt, gran, tag_base, gate);
+    return check_launch("dag_loss_fwd(dense, stand-by)");
 }
 
 int launch_pick_loss(const float* alpha, const float* beta, const int64_t* out_len, const int64_t* tgt_len, float* loss,
@@ -523,7 +550,7 @@ int launch_max_alpha_generic(const float* match, const float* links, const int64
             int rcw = banded_acquire_ws(st, (size_t)B * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);
             if (rcw) return rcw;
             hipLaunchKernelGGL(dag_dense_kernel<1>, dim3(B, 1, NS), dim3(DP_THREADS), lds3, st, match, links, in, out_len, tgt_len,
-                               alpha, (float*)nullptr, trace, B, T, L, TR, cnt, gran, tag_base);
+                               alpha, (float*)nullptr, trace, B, T, L, TR, cnt, gran, tag_base, (const unsigned int*)nullptr);
             return check_launch("dag_best_alignment(dense)");
         }
     }

@@ -733,3 +733,61 @@ def test_dense_kernels_edge_shapes(shape):
     if fin.all():
         path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
         np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
+
+
+def _weak_links(seed, B, L, TR, ol, scale):
+    """log_softmax of logits with a large spread: most transitions are far weaker than 2^-126 (exp space holds them as exact zeros)."""
+    rng = np.random.default_rng(seed)
+    raw = (rng.standard_normal((B, L, TR)) * scale).astype(np.float32)
+    i = np.arange(L)[None, :, None]; d = np.arange(TR)[None, None, :]
+    valid = (i + d + 1) < ol[:, None, None]
+    mx = np.max(np.where(valid, raw, -1e30), axis=-1, keepdims=True)
+    e = np.where(valid, np.exp(raw - mx), 0.0); ssum = e.sum(-1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(valid, raw - mx - np.log(np.where(ssum > 0, ssum, 1.0)), -np.inf).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(6, 40, 330, 329), (3, 70, 600, 599)])
+def test_dense_dp_hands_unrepresentable_batches_to_the_log_space_kernels(shape):
+    """Batches the exp-space products are the wrong tool for, with forced emissions as GLAT's (nat_dag_loss.py:130-132).  "weak":
+    transitions of -100 ... -400 nats, exact zeros in exp space — the range check ahead of the DP kernel raises the give-up flag and the
+    stand-by log-space kernels queued behind it produce the result.  "mild": every weight representable (>= -60 nats) but most sums
+    under the guard — the DP counts its exact-redo row events and gives up past its budget (auto: either outcome; 16: gives up; -1: no
+    stand-by, every flagged row redone in place).  A benign batch with a budget of one event goes through the same hand-over.  Same
+    answer as the fp64 oracle every time."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(5 + L, B, T, L, TR)
+    weak = _weak_links(7 + L, B, L, TR, ol, 60.0)
+    rng = np.random.default_rng(L)
+    forced = match.copy()
+    for b in range(B):                                    # forced emissions: one live vertex per glanced target position
+        for t in rng.choice(int(tl[b]), size=max(1, int(tl[b]) // 4), replace=False):
+            j = int(rng.integers(t, int(ol[b]) - (int(tl[b]) - 1 - t)))
+            forced[b, t, :] = -np.inf; forced[b, t, j] = 0.0
+    mild = np.where(np.isneginf(weak), weak, np.maximum(weak, -60.0)).astype(np.float32)       # representable, but most sums still underflow
+    cases = {"weak": (forced, weak, 0, True), "mild": (forced, mild, 0, "auto"), "mild, budget 16": (forced, mild, 16, True),
+             "mild, no stand-by": (forced, mild, -1, False), "benign, budget 1": (match, links, 1, None)}
+    try:
+        for name, (mm, kk, budget, expect_gave_up) in cases.items():
+            _lib.set_option("dm_budget", budget)
+            m, k, o, t = to_dev(mm, kk, ol, tl)
+            m.requires_grad_()
+            loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+            assert _lib.last_launch_status() == 0, name
+            gave_up, cells = _lib.last_dense_gave_up(), _lib.last_fallback_count()
+            if expect_gave_up is None:
+                assert gave_up == (cells > 0), (name, cells)
+            elif expect_gave_up != "auto":                  # (auto: 256 + 1/32 of the launch's (row, block) pairs — either outcome is right)
+                assert gave_up == expect_gave_up, (name, cells)
+            a64 = orc.dag_alpha(mm, kk, ol, tl, np.float64); b64 = orc.dag_beta(mm, kk, ol, tl, np.float64)
+            a, b = alpha.cpu().numpy(), beta.cpu().numpy()
+            assert not np.isnan(a).any() and not np.isnan(b).any(), name
+            assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), name
+            fa, fb = np.isfinite(a64), np.isfinite(b64)
+            np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T + 1e-4, err_msg=name)
+            np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T + 1e-4, err_msg=name)
+            l64 = -b64[:, 0, 0]          # (criterion convention checked elsewhere; here: loss finite where beta[0, 0] is)
+            assert np.array_equal(torch.isfinite(loss).cpu().numpy(), np.isfinite(l64)), name
+    finally:
+        _lib.set_option("dm_budget", 0)

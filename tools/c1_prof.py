@@ -15,6 +15,9 @@ for b in range(B):
     valid = (i + d + 1) < L
     links[b:b + 1] = torch.log_softmax(raw.masked_fill(~valid, float("-inf")).masked_fill(~valid.any(-1, keepdim=True), 0.0), -1).masked_fill(~valid, float("-inf"))
 links.requires_grad_()
+from daspeech_amd import _lib
+if os.environ.get("DSP_SO"): _lib.SO_PATH = os.path.abspath(os.environ["DSP_SO"])
+if os.environ.get("DM_BUDGET"): _lib.set_option("dm_budget", int(os.environ["DM_BUDGET"]))
 def step():
     loss = ops.dag_loss(match, links, ol, tl)
     return torch.autograd.grad(loss.sum(), [match, links])
