@@ -87,7 +87,8 @@ int dsp_logsoftmax_gather_bwd_lazy(void* logits_inout, int dtype,
  *   workspace: dsp_dag_workspace_bytes(B,T,L,TR) bytes of device scratch owned by the CALLER (the reference allocates its scratch
  *   per call with ATen, dag_loss.cu:154,339-340).  It is zeroed on `stream` by the call itself and nothing about it outlives the call
  *   except the status words read by dsp_dag_last_launch_status — so the launch (memset + kernels) can be captured in a hipGraph.
- *   workspace == NULL (or too small) selects a library-owned grow-only buffer per (device, stream) instead: not capturable. */
+ *   workspace == NULL (or too small) selects a library-owned grow-only buffer per (device, stream) instead: not capturable.
+ *   For dense windows (TR > 64) the size includes the stand-by log-space path's scratch (a B*L*TR*4-byte re-laid-out copy of links). */
 size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR);
 int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                      float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
@@ -138,6 +139,9 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   cross-check the families.  "k5_path": 0 = auto, 1 = tiled log-space grad_links kernel, 2 = exp-space (TR <= 32) / block products
  *   (TR > 64).  "dm_mt" 1|2: rows per chunk of the dense kernel in MFMA row tiles (default 2 = 32 rows), "dm_depth" 1|2: its register
  *   stages in flight with dm_mt 1 (9 with dm_mt 2: the one-workgroup-per-CU build), "force_generic", "dm_*" affect speed only.
+ *   "dm_budget": the dense kernel hands a batch exp space cannot hold (finite transitions under e^-86, or more exact-redo work than
+ *   one visited predecessor per (row, 64-column block)) to log-space stand-by kernels queued behind it — 0 = auto, n > 0 = that many
+ *   visited predecessors, -1 = no stand-by (diagnostics only: such batches are then slow and their weakest terms unguarded).
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);
