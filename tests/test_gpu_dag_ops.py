@@ -788,6 +788,15 @@ def test_dense_dp_hands_unrepresentable_batches_to_the_log_space_kernels(shape):
             np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T + 1e-4, err_msg=name)
             np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T + 1e-4, err_msg=name)
             l64 = -b64[:, 0, 0]          # (criterion convention checked elsewhere; here: loss finite where beta[0, 0] is)
-            assert np.array_equal(torch.isfinite(loss).cpu().numpy(), np.isfinite(l64)), name
+            fin = torch.isfinite(loss)
+            assert np.array_equal(fin.cpu().numpy(), np.isfinite(l64)), name
+            # the gradient kernels (block products in exp space, dag_grad_dense.hip) see the same alpha / beta whichever kernel made them
+            if fin.any():
+                k.requires_grad_()
+                loss2 = ops().dag_loss(m, k, o, t)
+                gm, gk = torch.autograd.grad(loss2[fin].sum(), [m, k])
+                gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, mm, kk, ol, tl, np.float64)
+                np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7, err_msg=name)
+                np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7, err_msg=name)
     finally:
         _lib.set_option("dm_budget", 0)
