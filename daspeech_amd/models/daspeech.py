@@ -48,7 +48,50 @@ class Conv1dSubsampler(nn.Module):
             lens = ((lens.float() - 1) / 2 + 1).floor().long()
         return lens
 
+    @staticmethod
+    def _fold_stride2(conv: nn.Conv1d):
+        """A stride-2 Conv1d(C, Cout, K, padding=K//2) over x[B,T,C] is a stride-1 "same" convolution over the frame PAIRS
+        x2[t'] = (x[2t'], x[2t'+1]) (2C channels, zero frame appended to an odd T): y[t] = sum_k w[k] x[2t+k-p] and 2t+k-p = 2(t+a)+r
+        puts tap k on pair t+a, half r.  Returns (weight [Cout, Cp, K'], Cp): Cp = 2C rounded up to what the matrix-core kernel
+        takes (zero weights on the padding channels and on the half-taps the original does not have)."""
+        w = conv.weight.detach().float()
+        Cout, C, K = w.shape
+        p = K // 2
+        amin, amax = (0 - p) // 2, (K - 1 - p) // 2
+        A = max(-amin, amax)
+        C2 = 2 * C
+        Cp = next(c for c in (128, 256, 512) if c >= C2) if C2 <= 512 else (C2 + 511) // 512 * 512
+        wf = torch.zeros(Cout, Cp, 2 * A + 1, dtype=torch.float32, device=w.device)
+        for k in range(K):
+            a, r = (k - p) // 2, (k - p) % 2
+            wf[:, r * C:(r + 1) * C, a + A] = w[:, :, k]
+        return wf, Cp
+
     def forward(self, x: Tensor, lens: Tensor):
+        if (decode_ops.SPLIT_GEMM and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                and not torch.is_autocast_enabled() and self.conv_layers[0].weight.dtype == torch.float32):
+            # eval, fp32: the two stride-2 convolutions on the matrix cores at fp32 accuracy (operand splitting), channels-last, as
+            # stride-1 convolutions over frame pairs.  MIOpen has no fp32 solver for the first one (80 input channels, stride 2) and
+            # runs its naive kernel: 4.0 ms per batch of 32 — a sixth of the whole S2ST batch (profiles/r02g_s2st_kernel_stats.csv)
+            key = tuple((c.weight.data_ptr(), c.weight._version) for c in self.conv_layers)
+            if getattr(self, "_split_key", None) != key:
+                ok = all(c.stride == (2,) and c.dilation == (1,) and c.groups == 1 and c.kernel_size[0] % 2 == 1
+                         and c.padding == (c.kernel_size[0] // 2,) and c.out_channels % 4 == 0 for c in self.conv_layers)
+                self._split = None
+                if ok:
+                    self._split = []
+                    for c in self.conv_layers:
+                        wf, Cp = self._fold_stride2(c)
+                        self._split.append((decode_ops.SplitConv1d(wf, c.bias), Cp))
+                self._split_key = key
+            if self._split is not None:
+                for conv, Cp in self._split:
+                    B, T, C = x.shape
+                    if T % 2: x = F.pad(x, (0, 0, 0, 1))
+                    x2 = x.reshape(B, (T + 1) // 2, 2 * C)
+                    if Cp != 2 * C: x2 = F.pad(x2, (0, Cp - 2 * C))
+                    x = F.glu(conv(x2.contiguous()), dim=-1)
+                return x, self.out_lengths(lens)
         x = x.transpose(1, 2)                        # B x C x T
         for conv in self.conv_layers:
             x = F.glu(conv(x), dim=1)
