@@ -598,6 +598,49 @@ def test_dense_window_full_size_c1_and_readme_shape(shape):
         assert score <= float(loss[b]) + 1e-3 * abs(float(loss[b]))
 
 
+def test_dense_window_full_size_c2_tr4095():
+    """BASELINE configs[1] with the README's `--max-transition-length 99999` (C2: B=32, T=512, L=4096, TR=4095 — a 2.1 GB transition
+    tensor) at FULL size on the HIP ops, through size-independent properties: loss = beta[0,0] = alpha[T_b-1, L_b-1]; the matrix-core
+    DP agrees with the row-sequential log-space DP cell by cell; grad_match is a distribution over the vertices for every target row,
+    grad_links counts T_b - 1 transitions per utterance; the Viterbi path is a valid monotone alignment scoring no more than the
+    marginal and exactly what the max-DP's own end cell says."""
+    from daspeech_amd import _lib
+    match, links, o, t = _c2_inputs(4095)
+    B, T, L = match.shape
+    m = match.requires_grad_(); k = links.requires_grad_()
+    loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    assert _lib.last_launch_status() == 0 and torch.isfinite(loss).all() and not _lib.last_dense_gave_up()
+    ar = torch.arange(B, device=m.device)
+    torch.testing.assert_close(alpha[ar, t - 1, o - 1], loss, rtol=3e-6, atol=2e-5 * T)
+    try:
+        _lib.set_option("dp_path", 1)
+        loss_l, (alpha_l, beta_l) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    finally:
+        _lib.set_option("dp_path", 0)
+    assert torch.equal(torch.isneginf(alpha), torch.isneginf(alpha_l)) and torch.equal(torch.isneginf(beta), torch.isneginf(beta_l))
+    fa = torch.isfinite(alpha_l); fb = torch.isfinite(beta_l)
+    torch.testing.assert_close(alpha[fa], alpha_l[fa], rtol=6e-6, atol=4e-5 * T)
+    torch.testing.assert_close(beta[fb], beta_l[fb], rtol=6e-6, atol=4e-5 * T)
+    del alpha_l, beta_l, fa, fb
+    gm, gk = torch.autograd.grad(loss.sum(), [m, k])
+    assert torch.isfinite(gm).all() and torch.isfinite(gk).all()
+    want = (torch.arange(T, device=m.device).unsqueeze(0) < t.unsqueeze(1)).float()
+    # (alpha, beta and Z are ~ -4.5e3 here: one fp32 ulp of them is 4.9e-4, a posterior exp(alpha + beta - match - Z) carries a few)
+    torch.testing.assert_close(gm.sum(-1), want, rtol=0, atol=2e-2)
+    torch.testing.assert_close(gk.sum((1, 2)), (t - 1).float(), rtol=5e-3, atol=0)
+    del gm, gk
+    with torch.no_grad():
+        path = ops().dag_best_alignment(match.detach(), links.detach(), o, t)
+        on = path >= 0
+        assert (on.sum(1) == t).all() and (path[:, 0] == 0).all() and (path[ar, o - 1] == t - 1).all()
+        for b in range(B):
+            pos = on[b].nonzero().flatten()
+            assert torch.equal(path[b, pos], torch.arange(int(t[b]), device=m.device))
+            score = match[b, torch.arange(int(t[b]), device=m.device), pos].double().sum() + \
+                links[b, pos[:-1], pos[1:] - pos[:-1] - 1].double().sum()
+            assert float(score) <= float(loss[b]) + 1e-3 * abs(float(loss[b]))
+
+
 def test_workspace_sizes_are_reported_and_library_scratch_still_works():
     """The ABI is honest about memory: dsp_dag_workspace_bytes / dsp_dag_alignment_workspace_bytes are non-zero, the Python operators
     pass a torch-allocated workspace, and a caller that passes NULL still gets correct results from the library's own scratch."""
