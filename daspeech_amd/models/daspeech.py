@@ -394,6 +394,12 @@ class S2TConformerDAGModel(nn.Module):
                 logits, links, _ = self.decode_graph(prev_output_tokens, enc)
                 prev_output_tokens, tgt_tokens, glat_info = glat_function(self, logits, tgt_tokens, prev_output_tokens, glat, links=links)
                 logits = None
+            # Under torch.autocast the first pass has just filled the autocast cache with low-precision copies of the decoder's
+            # weights made WITHOUT gradient history; pass 2 would reuse them and no gradient would reach the decoder's Linear layers
+            # or the link predictor (r02: 86 of 695 parameters never trained under `--fp16`-style autocast).  The reference runs a
+            # pure fp16 model under fairseq's FP16Optimizer and has no such cache.
+            if torch.is_autocast_enabled() and torch.is_grad_enabled():
+                torch.clear_autocast_cache()
         logits, links, feats = self.decode_graph(prev_output_tokens, enc)
         ret = {"word_ins": {"out": logits, "tgt": tgt_tokens, "mask": tgt_tokens.ne(self.pad) if tgt_tokens is not None else None,
                             "nll_loss": True, "features": feats},
