@@ -267,7 +267,14 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
             const long wgs128 = (long)((T + 127) / 128) * ((M + 255) / 256) * B;
             return wgs128 >= 256 ? cs_launch<256, 256, 128, 8, 1>(p, st) : cs_launch<256, 256, 64, 8, 1>(p, st);
         }
-        case 512: return cs_launch<512, 256, 64, 8, 1>(p, st);
+        case 512: {
+            // launches that would leave CUs idle with 64-frame tiles (the Conformer's 2048 -> 256 on 4.4 k positions: 69 workgroups)
+            // take 32-frame tiles, two workgroups per CU: 52.7 -> 36.7 us; where the 64-frame tiles fill the chip they are 10-20 % faster
+            // (at 192 workgroups the 64-frame tiles still win: 34.3 vs 38.9 us for 1024 -> 256 on 10.6 k positions; 128-channel tiles: no gain)
+            const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B;
+            if (ntaps <= 9 && wgs64 < 128) return cs_launch<512, 256, 32, 8, 1>(p, st);
+            return cs_launch<512, 256, 64, 8, 1>(p, st);
+        }
         case 128: return cs_launch<128, 128, 256, 4, 2>(p, st);
     }
     set_error("conv1d_split: unsupported slice width %d (128, 256, 512; wider inputs are nslices slices)", CI);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from daspeech_amd.decode_ops import SplitConv1d
 torch.manual_seed(0)
-for (pos, cin, cout, k) in [(35072, 512, 2048, 1), (35072, 2048, 512, 1), (10560, 256, 1024, 9), (10560, 1024, 256, 1), (4384, 256, 2048, 1), (4384, 2048, 256, 1)]:
+for (pos, cin, cout, k) in [(35072, 512, 2048, 1), (35072, 2048, 512, 1), (10560, 256, 1024, 9), (10560, 1024, 256, 9), (10560, 1024, 256, 1), (4384, 256, 2048, 1), (4384, 2048, 256, 1)]:
     B = 32; T = pos // B
     x = torch.randn(B, T, cin, device="cuda")
     w = torch.randn(cout, cin, k, device="cuda") / (cin * k) ** 0.5; b = torch.randn(cout, device="cuda") * 0.1
