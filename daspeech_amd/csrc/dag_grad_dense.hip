@@ -57,15 +57,17 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
     if (dmin >= TR) return;                                             // entirely outside the window: no such entries in the compact layout
     const float z2 = b00 * GD_LOG2E, go = g_out[b];
     const int nt = dead ? 0 : (Tb - 1);                                  // t = 0 .. T_b - 2
-    const bool logmode = (I == J) || dmax >= TR;
+    bool logmode = (I == J) || dmax >= TR;
 
-    // element (i, j) of the pair -> grad entry; zero where the reference leaves its zero-initialised output (i >= L_b or j >= L_b) or Z = -inf
+    // element (i, j) of the pair -> grad entry; zero where the reference leaves its zero-initialised output (i >= L_b or j >= L_b) or Z = -inf.
+    // The link meets the sum in the LOG domain: e^link * sum is 0 * (large) for a transition weaker than e^-87 although the entry — the
+    // posterior of that transition — can be anything up to 1 (r02 fuzzing: NaN = 0 * inf and lost entries on batches with such links).
     auto store = [&](int i, int j, float sum) {
         const int d = j - i - 1;
         if (i >= L || j >= L || d < 0 || d >= TR) return;
         const bool ok = !dead && i < Lb && j < Lb;
         float v = 0.f;
-        if (ok) { const float lk = K[(size_t)i * TR + d]; v = (lk == NEG_INF) ? 0.f : go * __expf(lk) * sum; }
+        if (ok) { const float lk = K[(size_t)i * TR + d]; v = (lk == NEG_INF) ? 0.f : go * __builtin_amdgcn_exp2f(lk * GD_LOG2E + __builtin_amdgcn_logf(sum)); }
         G[(size_t)i * TR + d] = v;
     };
 
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
         float sa[4], sbv[4];
+        bool clamped = false;                    // an A value hit the 2^100 clamp: the bound "A <= 1 / (weakest link into j*)" says a
+                                                 // transition weaker than 2^-100 enters this pair — exp space cannot hold its terms
         auto prefetch = [&](int t0) {
             const int t = t0 + r;
             const bool okr = t < nt;
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
             const bool rdead = bm == NEG_INF;
             const float sb = rdead ? 0.f : ceilf(bm);
             const float sh = sb - z2;
+            clamped |= !rdead && fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])) + sh > 100.f;
             v4f a4, b4;
             a4.x = rdead ? 0.f : __builtin_amdgcn_exp2f(fminf(sa[0] + sh, 100.f)); a4.y = rdead ? 0.f : __builtin_amdgcn_exp2f(fminf(sa[1] + sh, 100.f));
             a4.z = rdead ? 0.f : __builtin_amdgcn_exp2f(fminf(sa[2] + sh, 100.f)); a4.w = rdead ? 0.f : __builtin_amdgcn_exp2f(fminf(sa[3] + sh, 100.f));
@@ -117,17 +122,29 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
                 }
             }
         }
+        if (__syncthreads_or(clamped)) {
+            logmode = true;                      // ... the whole pair again, term by term
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) store(ib + 16 * wave + 4 * lq + rr, jb + 16 * s + lr, acc[s][rr]);
-    } else {
+                for (int rr = 0; rr < 4; ++rr) store(ib + 16 * wave + 4 * lq + rr, jb + 16 * s + lr, acc[s][rr]);
+        }
+    }
+    if (logmode) {
         // diagonal / window-edge pair: term by term in log space, rows staged through LDS (log2 domain), 16 elements per thread:
         // thread -> column j = jb + (tid & 63), rows i = ib + (tid >> 6) * 16 + e
-        float sum[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+        // (every term exp(alpha + beta + link - Z) is a probability: the link rides in the exponent, nothing can overflow)
+        float sum[16], lk2[16];
         const int jl = tid & 63, ig = tid >> 6;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sum[e] = 0.f;
+            const int i = ib + ig * 16 + e, j = jb + jl, d = j - i - 1;
+            const bool ok = i < L && j < L && d >= 0 && d < TR;
+            const float lk = K[ok ? ((size_t)i * TR + d) : (size_t)0];
+            lk2[e] = ok ? lk * GD_LOG2E : NEG_INF;
+        }
         for (int t0 = 0; t0 < nt; t0 += 16) {
             __syncthreads();
             {
@@ -144,11 +161,15 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
             for (int rr = 0; rr < rows; ++rr) {
                 const float bv = Bs[rr * 64 + jl];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sum[e] += __builtin_amdgcn_exp2f(As[rr * 64 + ig * 16 + e] + bv);         // exp2(-inf) = 0
+                for (int e = 0; e < 16; ++e) sum[e] += __builtin_amdgcn_exp2f((As[rr * 64 + ig * 16 + e] + bv) + lk2[e]);         // exp2(-inf) = 0
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) store(ib + ig * 16 + e, jb + jl, sum[e]);
+        for (int e = 0; e < 16; ++e) {
+            const int i = ib + ig * 16 + e, j = jb + jl, d = j - i - 1;
+            if (i >= L || j >= L || d < 0 || d >= TR) continue;
+            G[(size_t)i * TR + d] = (!dead && i < Lb && j < Lb) ? go * sum[e] : 0.f;
+        }
     }
 }
 

@@ -843,3 +843,32 @@ def test_dense_dp_hands_unrepresentable_batches_to_the_log_space_kernels(shape):
                 np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7, err_msg=name)
     finally:
         _lib.set_option("dm_budget", 0)
+
+
+@pytest.mark.parametrize("shape", [(3, 53, 838, 837), (2, 78, 551, 83), (1, 51, 144, 143)])
+def test_dense_grad_links_with_unrepresentable_transitions(shape):
+    """grad_links on the dense-window block products (dag_grad_dense.hip) when most transitions are weaker than fp32 can hold as a
+    factor (log-softmax outputs scaled x40 and renormalised: -100 ... -900 nats).  The entry is the posterior of its transition —
+    anything up to 1 — so the link has to meet the sum in the log domain (e^link * sum was 0 * inf = NaN, r02 fuzzing), and a block
+    pair whose scaled alpha overflows the 2^100 clamp is redone term by term.  Against the fp64 oracle; no NaN."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(77 + L, B, T, L, TR)
+    fin_l = np.isfinite(links)
+    links = np.where(fin_l, links * 40.0, links)
+    mx = np.max(np.where(fin_l, links, -1e30), -1, keepdims=True)
+    ssum = np.where(fin_l, np.exp(links - mx), 0).sum(-1, keepdims=True)
+    links = np.where(fin_l, links - mx - np.log(np.where(ssum > 0, ssum, 1)), links).astype(np.float32)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_(); k.requires_grad_()
+    loss = ops().dag_loss(m, k, o, t)
+    assert _lib.last_launch_status() == 0
+    fin = torch.isfinite(loss)
+    assert fin.any()
+    gm, gk = torch.autograd.grad(loss[fin].sum(), [m, k])
+    assert not torch.isnan(gk).any() and not torch.isnan(gm).any()
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    assert np.array_equal(fin.cpu().numpy(), np.isfinite(b64[:, 0, 0]))
+    gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=3e-3, atol=2e-7)
+    np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=3e-3, atol=2e-7)

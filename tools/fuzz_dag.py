@@ -16,16 +16,28 @@ rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
 bad = 0
 for case in range(n):
-    B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32]))
-    L = int(rng.integers(2, 1500)); 
-    if rng.random() < 0.6: L = max(4, L // 4 * 4)
-    TR = min(TR, L - 1) if L > 1 else 1
-    Tmin = max(2, (L - 1 + TR - 1) // TR + 1) if rng.random() < 0.8 else 2      # mostly reachable ends
-    T = int(min(L, rng.integers(Tmin, Tmin + 40)))
+    dense = len(sys.argv) > 3 and sys.argv[3] == "dense"          # dense windows (TR > 64: the matrix-core kernels and their stand-by path)
+    if dense:
+        B = int(rng.integers(1, 7)); L = int(rng.integers(66, 900))
+        TR = int(rng.choice([L - 1, L - 1, int(rng.integers(65, L))]))
+        T = int(min(L, rng.integers(2, 90)))
+    else:
+        B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32]))
+        L = int(rng.integers(2, 1500));
+        if rng.random() < 0.6: L = max(4, L // 4 * 4)
+        TR = min(TR, L - 1) if L > 1 else 1
+        Tmin = max(2, (L - 1 + TR - 1) // TR + 1) if rng.random() < 0.8 else 2      # mostly reachable ends
+        T = int(min(L, rng.integers(Tmin, Tmin + 40)))
     if T < 2 or TR < 1: continue
     match, links, ol, tl = make_dag_inputs(int(rng.integers(1 << 30)), B, T, L, TR, match_scale=float(rng.choice([0.5, 2.0, 6.0])))
-    if rng.random() < 0.5:        # peaked transitions
-        links = np.where(np.isfinite(links), links * float(rng.choice([2.0, 4.0])), links)
+    if dense and rng.random() < 0.3:        # forced emissions (GLAT): one live vertex on a few target rows
+        for bb in range(B):
+            for tt in rng.choice(int(tl[bb]), size=max(1, int(tl[bb]) // 5), replace=False):
+                lo, hi = int(tt), int(ol[bb]) - (int(tl[bb]) - 1 - int(tt))
+                if hi > lo:
+                    j = int(rng.integers(lo, hi)); match[bb, tt, :] = -np.inf; match[bb, tt, j] = 0.0
+    if rng.random() < 0.5:        # peaked transitions (dense: up to weights exp space cannot hold)
+        links = np.where(np.isfinite(links), links * float(rng.choice([2.0, 4.0, 12.0, 40.0] if dense else [2.0, 4.0])), links)
         mx = np.max(np.where(np.isfinite(links), links, -1e30), -1, keepdims=True)
         ssum = np.where(np.isfinite(links), np.exp(links - mx), 0).sum(-1, keepdims=True)
         links = np.where(np.isfinite(links), links - mx - np.log(np.where(ssum > 0, ssum, 1)), links).astype(np.float32)
@@ -56,5 +68,8 @@ for case in range(n):
         assert np.array_equal(path, ref), "Viterbi path"
     except Exception as e:       # noqa
         bad += 1
-        print("FAIL", tag, "->", str(e).splitlines()[0][:200])
+        import traceback
+        where = [l for l in traceback.format_exc().splitlines() if "fuzz_dag.py" in l][-1:]
+        print("FAIL", tag, "gave up" if _lib.last_dense_gave_up() else "", "->", " | ".join(l.strip() for l in str(e).splitlines() if l.strip())[:400], where)
+    if dense: print(tag, "gave up" if _lib.last_dense_gave_up() else "", flush=True)
 print(f"{n} cases, {bad} failures")
