@@ -161,6 +161,8 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
             };
             int Vmin = 0;
             { const int lim = ub - TR - DX_BW; if (lim >= 0) Vmin = lim / DX_BW + 1; }
+            // ... that can hold a live vertex: at step tt nothing left of column tt is reachable (dag_dp_dense_mfma.hip, same rule)
+            if (tt0 >= 1) Vmin = max(Vmin, (tt0 - 1) / DX_BW);
             // Two register stages of RAW loaded words (block maximum of row tid % 16, 4 alpha_max values of row tid / 16, 16 weights),
             // unconditional requests, validity recomputed at conversion time, two LDS buffers and one barrier per source block, readiness
             // waited for only at need — the pipeline of dag_dp_dense_mfma.hip (its header explains each point).
@@ -263,7 +265,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 if (live) cur ^= 1;
                 have = live;
             };
-            {
+            if (Vmin < U) {
                 const int W0 = Vmin, W1 = min(Vmin + 1, U - 1);
                 prefetchW(0, W0); ensure_ready(Vmin); prefetchA(0, W0); st_ok[0] = W0 <= ready_hi;
                 prefetchW(1, W1); prefetchA(1, W1); st_ok[1] = (Vmin + 1) <= ready_hi;

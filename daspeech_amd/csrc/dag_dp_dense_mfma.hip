@@ -302,6 +302,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             // first source block inside the transition window
             int Vmin = 0;
             { const int lim = ub - TR - DM_BW; if (lim >= 0) Vmin = lim / DM_BW + 1; }
+            // ... that can hold a live vertex: nothing left of column u0 + tt is reachable at step tt, so in every source row of this chunk
+            // (steps >= tt0 - 1) the blocks left of the one holding column u0 + tt0 - 1 are dead.  They are not requested at all (the
+            // liveness vote would only drop them after their tile was loaded: 12 % of C2's products at TR = 4095)
+            if (tt0 >= 1) Vmin = max(Vmin, (u0 + tt0 - 1) / DM_BW);
             // register stage of a block: RAW loaded words only — exponent (row tl % 16: LDS copy + liveness vote; row tl / 16: this thread's
             // A row) and first-live per source row, 4 alpha values and 16 link values per thread.  Nothing touches a stage between its
             // request and its conversion D steps later (a select right behind the load would put the memory round trip back on every
@@ -604,10 +608,12 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 prefetchA(SC, Wc);
                 st_ok[s] = W <= ready_hi;
             };
+            if (Vmin < U) {
             fill(std::integral_constant<int, 0>{});
             if constexpr (D > 1) fill(std::integral_constant<int, 1>{});
             if constexpr (D > 2) fill(std::integral_constant<int, 2>{});
             if constexpr (D > 3) fill(std::integral_constant<int, 3>{});
+            }
             for (int Vb = Vmin; Vb < U; Vb += D) {
                 step(std::integral_constant<int, 0>{}, Vb);
                 if constexpr (D > 1) step(std::integral_constant<int, 1>{}, Vb + 1);

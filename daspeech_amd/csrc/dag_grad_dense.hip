@@ -31,8 +31,14 @@ __device__ __forceinline__ float gd_max16(float v) {          // maximum over th
     return v;
 }
 
+// Two passes over the same grid.  PASS 0: the block products (48 VGPRs, 8 waves per SIMD).  A pair whose scaled alpha hits the 2^100
+// clamp cannot be done in exp space; it leaves a marker (a NaN with a payload no arithmetic produces) in its first entry.  PASS 1:
+// the term-by-term log-space form for the diagonal / window-edge pairs and for marked pairs; every other workgroup returns at once.
+// (One kernel holding both forms needed 105 VGPRs — half the occupancy, C2 at TR = 4095: 5.6 -> 7.1 ms.)
+constexpr unsigned GD_REDO_MARK = 0x7FC0DA65u;
 // grid: (NJ * (NJ + 1) / 2 block pairs I <= J, B); 256 threads
-__global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
+template <int PASS>
+__global__ __launch_bounds__(256, PASS == 0 ? 8 : 4) void dag_grad_links_dense_kernel(
     const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ links,
     const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len, float* __restrict__ g_links, int B, int T, int L, int TR, int NJ)
 {
@@ -57,7 +63,10 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
     if (dmin >= TR) return;                                             // entirely outside the window: no such entries in the compact layout
     const float z2 = b00 * GD_LOG2E, go = g_out[b];
     const int nt = dead ? 0 : (Tb - 1);                                  // t = 0 .. T_b - 2
-    bool logmode = (I == J) || dmax >= TR;
+    const bool structural = (I == J) || dmax >= TR;
+    float* mark = G + (size_t)ib * TR + (jb - ib - 1);                  // entry (ib, jb) of an off-diagonal pair inside the window
+    if (PASS == 0 && structural) return;
+    if (PASS == 1 && !structural && __float_as_uint(*mark) != GD_REDO_MARK) return;
 
     // element (i, j) of the pair -> grad entry; zero where the reference leaves its zero-initialised output (i >= L_b or j >= L_b) or Z = -inf.
     // The link meets the sum in the LOG domain: e^link * sum is 0 * (large) for a transition weaker than e^-87 although the entry — the
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
     };
 
     const int r = tid >> 4, c4 = tid & 15;                               // staging: row r of the chunk, columns 4 c4 .. +3
-    if (!logmode) {
+    if (PASS == 0) {
         const int lr = lane & 15, lq = lane >> 4;
         v4f acc[4];
 #pragma unroll
@@ -123,15 +132,14 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
             }
         }
         if (__syncthreads_or(clamped)) {
-            logmode = true;                      // ... the whole pair again, term by term
+            if (tid == 0) *mark = __uint_as_float(GD_REDO_MARK);        // ... the whole pair again, term by term, in pass 1
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) store(ib + 16 * wave + 4 * lq + rr, jb + 16 * s + lr, acc[s][rr]);
         }
-    }
-    if (logmode) {
+    } else {
         // diagonal / window-edge pair: term by term in log space, rows staged through LDS (log2 domain), 16 elements per thread:
         // thread -> column j = jb + (tid & 63), rows i = ib + (tid >> 6) * 16 + e
         // (every term exp(alpha + beta + link - Z) is a probability: the link rides in the exponent, nothing can overflow)
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(256) void dag_grad_links_dense_kernel(
             }
             __syncthreads();
             const int rows = min(16, nt - t0);
+#pragma unroll 2
             for (int rr = 0; rr < rows; ++rr) {
                 const float bv = Bs[rr * 64 + jl];
 #pragma unroll
@@ -180,9 +189,13 @@ int launch_dag_grad_links_dense(const float* g_out, const float* alpha, const fl
 {
     const int NJ = (L + 63) / 64;
     const long npairs = (long)NJ * (NJ + 1) / 2;
-    hipLaunchKernelGGL(dag_grad_links_dense_kernel, dim3((unsigned)npairs, (unsigned)B), dim3(256), 0, st,
+    hipLaunchKernelGGL(dag_grad_links_dense_kernel<0>, dim3((unsigned)npairs, (unsigned)B), dim3(256), 0, st,
                        g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR, NJ);
-    return check_launch("dag_loss_bwd(grad_links, dense block products)");
+    int rc = check_launch("dag_loss_bwd(grad_links, dense block products)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dag_grad_links_dense_kernel<1>, dim3((unsigned)npairs, (unsigned)B), dim3(256), 0, st,
+                       g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR, NJ);
+    return check_launch("dag_loss_bwd(grad_links, dense log-space pairs)");
 }
 
 }  // namespace dsp
