@@ -33,6 +33,15 @@ for case in range(n):
             if not torch.equal(a, b):
                 w = (a != b).nonzero()[:3].tolist() if a.shape == b.shape else "shape"
                 raise AssertionError(f"output {k_} differs at {w}: shapes {tuple(a.shape)} / {tuple(b.shape)}; quantised={bool((raw * 4 == torch.round(raw * 4)).all())}; out_len={out_len.tolist()}")
+        if L <= 260:                                  # lookahead / greedy against the numpy oracle (oracle/graph_oracle.py)
+            import numpy as np
+            from oracle import graph_oracle as gorc
+            prev = np.full((B, L), 3, np.int64); prev[np.arange(L)[None] >= out_len.numpy()[:, None]] = pad
+            for strat in ("lookahead", "greedy"):
+                want = gorc.forward_decoder(logits.numpy(), links.numpy(), feats.numpy(), prev, strat, pad, beta, vb)
+                got2 = decode_ops.graph_decode(logits.cuda(), links.cuda(), feats.cuda(), out_len.cuda(), pad, beta, strat)
+                for k_, (a, b) in enumerate(zip(got2, want)):
+                    assert np.array_equal(a.cpu().numpy(), b), f"{strat}: output {k_} differs"
     except Exception as e:   # noqa
         bad += 1; print("FAIL", tag, "->", str(e).splitlines()[0][:200] if str(e) else repr(e))
 print(f"{n} cases, {bad} failures")
