@@ -12,7 +12,13 @@ int launch_dag_bwd_generic(const float*, const float*, const float*, const float
 bool banded_supported(int L, int TR);
 void caller_ws_begin(void* p, size_t n);
 void caller_ws_end();
-struct CallerWsScope { CallerWsScope(void* p, size_t n) { caller_ws_begin(p, n); } ~CallerWsScope() { caller_ws_end(); } };
+void status_begin(hipStream_t st);
+void status_end(hipStream_t st);
+struct CallerWsScope {
+    hipStream_t st;
+    CallerWsScope(void* p, size_t n, hipStream_t s) : st(s) { caller_ws_begin(p, n); status_begin(st); }
+    ~CallerWsScope() { status_end(st); caller_ws_end(); }
+};
 void set_k5_path(int v);
 int k5_diag(unsigned int* out);
 int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
@@ -108,7 +114,7 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
                                 float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
                                 void* workspace, size_t workspace_bytes, dsp_stream_t stream)
 {
-    CallerWsScope ws_scope(workspace, workspace_bytes);
+    CallerWsScope ws_scope(workspace, workspace_bytes, as_stream(stream));
     int rc = check_dims("dag_loss_fwd", B, T, L, TR);
     if (rc) return rc;
     if (B == 0) return DSP_OK;
@@ -150,14 +156,15 @@ extern "C" int dsp_dag_best_alignment(const float* match, const float* links, co
                                       float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                                       dsp_stream_t stream)
 {
-    return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);      // library scratch
+    CallerWsScope ws_scope(nullptr, 0, as_stream(stream));                                                       // library scratch
+    return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);
 }
 
 extern "C" int dsp_dag_best_alignment_ws(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                                          float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                                          void* workspace, size_t workspace_bytes, dsp_stream_t stream)
 {
-    CallerWsScope ws_scope(workspace, workspace_bytes);
+    CallerWsScope ws_scope(workspace, workspace_bytes, as_stream(stream));
     return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);
 }
 
@@ -200,6 +207,7 @@ extern "C" int dsp_dag_max_alpha(const float* match, const float* links, const i
     if (rc) return rc;
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace) { set_error("dag_max_alpha: null pointer"); return DSP_EINVAL; }
+    CallerWsScope ws_scope(nullptr, 0, as_stream(stream));
     return launch_max_alpha_generic(match, links, out_len, tgt_len, alpha_max, trace, B, T, L, TR, as_stream(stream));
 }
 

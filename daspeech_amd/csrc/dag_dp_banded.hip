@@ -275,7 +275,7 @@ void* caller_ws_take(size_t n)
     return r;
 }
 
-struct BandedWS { void* base = nullptr; size_t bytes = 0; u32 tag_base = 0; void* last_status = nullptr; };
+struct BandedWS { void* base = nullptr; size_t bytes = 0; u32 tag_base = 0; void* last_status = nullptr; void* status_copy = nullptr; bool in_caller = false; };
 static std::mutex g_ws_mutex;
 static std::unordered_map<u64, BandedWS> g_ws;       // key: (device << 48) ^ stream
 
@@ -311,7 +311,8 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
         *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(c) + 256);
         *tag_base = 0;
         std::lock_guard<std::mutex> lock(g_ws_mutex);
-        g_ws[ws_key(st)].last_status = c;
+        BandedWS& w = g_ws[ws_key(st)];
+        w.last_status = c; w.in_caller = true;
         return DSP_OK;
     }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -329,8 +330,35 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
     *halo = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws->base) + 256);
     *tag_base = ws->tag_base;
     ws->tag_base += (u32)T + 1u;
-    ws->last_status = ws->base;
+    ws->last_status = ws->base; ws->in_caller = false;
     return DSP_OK;
+}
+
+// The status words of the last launch on a stream (dsp_dag_last_launch_status).  An entry point opens a call with status_begin — a launch
+// whose kernels keep no status words (the generic row kernels) must read as "clean", not as whatever an earlier launch left (r02 fuzzing:
+// a freed caller workspace re-used for an alpha table read back as status 0xFF800000, -inf) — and closes it with status_end, which moves
+// status words that live in CALLER memory into a 256-byte library buffer on the launch stream: the caller may free its workspace as soon
+// as the call returns.  (The buffer is allocated on first use outside a stream capture; without it the status reads as clean.)
+void status_begin(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws.find(ws_key(st));
+    if (it != g_ws.end()) { it->second.last_status = nullptr; it->second.in_caller = false; }
+}
+void status_end(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws.find(ws_key(st));
+    if (it == g_ws.end() || !it->second.in_caller || !it->second.last_status) return;
+    BandedWS& w = it->second;
+    if (!w.status_copy) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs != hipStreamCaptureStatusNone || hipMalloc(&w.status_copy, 256) != hipSuccess) { (void)hipGetLastError(); w.status_copy = nullptr; }
+    }
+    if (w.status_copy && hipMemcpyAsync(w.status_copy, w.last_status, 256, hipMemcpyDeviceToDevice, st) == hipSuccess) w.last_status = w.status_copy;
+    else { (void)hipGetLastError(); w.last_status = nullptr; }
+    w.in_caller = false;
 }
 
 // mode 0: alpha and/or beta (logsum); mode 1: max-alpha + trace

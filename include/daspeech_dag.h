@@ -86,7 +86,8 @@ int dsp_logsoftmax_gather_bwd_lazy(void* logits_inout, int dtype,
  *   Cells the recurrence never reaches are -inf.  Unreachable ends give loss = -inf (no device assert).
  *   workspace: dsp_dag_workspace_bytes(B,T,L,TR) bytes of device scratch owned by the CALLER (the reference allocates its scratch
  *   per call with ATen, dag_loss.cu:154,339-340).  It is zeroed on `stream` by the call itself and nothing about it outlives the call
- *   except the status words read by dsp_dag_last_launch_status — so the launch (memset + kernels) can be captured in a hipGraph.
+ *   (the status words dsp_dag_last_launch_status reads are moved to a 256-byte library buffer on `stream` before the call returns: the
+ *   workspace may be released, stream-ordered, at once) — so the launch (memset + kernels + that copy) can be captured in a hipGraph.
  *   workspace == NULL (or too small) selects a library-owned grow-only buffer per (device, stream) instead: not capturable.
  *   For dense windows (TR > 64) the size includes the stand-by log-space path's scratch (a B*L*TR*4-byte re-laid-out copy of links). */
 size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR);
