@@ -18,9 +18,10 @@ bad = 0
 for case in range(n):
     dense = len(sys.argv) > 3 and sys.argv[3] == "dense"          # dense windows (TR > 64: the matrix-core kernels and their stand-by path)
     if dense:
-        B = int(rng.integers(1, 7)); L = int(rng.integers(66, 900))
+        big = len(sys.argv) > 4 and sys.argv[4] == "big"           # several 32-row chunks, tens of column blocks
+        B = int(rng.integers(1, 7 if not big else 4)); L = int(rng.integers(66, 900 if not big else 2600))
         TR = int(rng.choice([L - 1, L - 1, int(rng.integers(65, L))]))
-        T = int(min(L, rng.integers(2, 90)))
+        T = int(min(L, rng.integers(2, 90 if not big else 200)))
     else:
         B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32] if not (len(sys.argv) > 3 and sys.argv[3] == "mid") else [33, 40, 48, 63, 64, 64]))
         L = int(rng.integers(2, 1500));
@@ -37,7 +38,7 @@ for case in range(n):
                 if hi > lo:
                     j = int(rng.integers(lo, hi)); match[bb, tt, :] = -np.inf; match[bb, tt, j] = 0.0
     if rng.random() < 0.5:        # peaked transitions (dense: up to weights exp space cannot hold)
-        links = np.where(np.isfinite(links), links * float(rng.choice([2.0, 4.0, 12.0, 40.0] if (dense or len(sys.argv) > 4) else [2.0, 4.0])), links)
+        links = np.where(np.isfinite(links), links * float(rng.choice([2.0, 4.0, 12.0, 40.0] if (dense or (len(sys.argv) > 4 and sys.argv[4] == "weak")) else [2.0, 4.0])), links)
         mx = np.max(np.where(np.isfinite(links), links, -1e30), -1, keepdims=True)
         ssum = np.where(np.isfinite(links), np.exp(links - mx), 0).sum(-1, keepdims=True)
         links = np.where(np.isfinite(links), links - mx - np.log(np.where(ssum > 0, ssum, 1)), links).astype(np.float32)
