@@ -345,17 +345,34 @@ void status_begin(hipStream_t st)
     auto it = g_ws.find(ws_key(st));
     if (it != g_ws.end()) { it->second.last_status = nullptr; it->second.in_caller = false; }
 }
+static bool status_buffer(BandedWS& w, hipStream_t st)          // (caller holds g_ws_mutex)
+{
+    if (!w.status_copy) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs != hipStreamCaptureStatusNone || hipMalloc(&w.status_copy, 256) != hipSuccess) { (void)hipGetLastError(); w.status_copy = nullptr; }
+    }
+    return w.status_copy != nullptr;
+}
+// the same move, carried out by a kernel the call launches anyway (dag_pick_loss_kernel): true = the caller's kernel copies 64 words src -> dst
+bool status_export(hipStream_t st, const u32** src, u32** dst)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws.find(ws_key(st));
+    if (it == g_ws.end() || !it->second.in_caller || !it->second.last_status) return false;
+    BandedWS& w = it->second;
+    if (!status_buffer(w, st)) return false;
+    *src = reinterpret_cast<const u32*>(w.last_status); *dst = reinterpret_cast<u32*>(w.status_copy);
+    w.last_status = w.status_copy; w.in_caller = false;
+    return true;
+}
 void status_end(hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     auto it = g_ws.find(ws_key(st));
     if (it == g_ws.end() || !it->second.in_caller || !it->second.last_status) return;
     BandedWS& w = it->second;
-    if (!w.status_copy) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
-        if (cs != hipStreamCaptureStatusNone || hipMalloc(&w.status_copy, 256) != hipSuccess) { (void)hipGetLastError(); w.status_copy = nullptr; }
-    }
+    (void)status_buffer(w, st);
     if (w.status_copy && hipMemcpyAsync(w.status_copy, w.last_status, 256, hipMemcpyDeviceToDevice, st) == hipSuccess) w.last_status = w.status_copy;
     else { (void)hipGetLastError(); w.last_status = nullptr; }
     w.in_caller = false;

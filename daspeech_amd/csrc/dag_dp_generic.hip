@@ -110,9 +110,13 @@ __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
 }
 
 // loss[b] = beta[b,0,0] (with beta) or alpha[b,T_b-1,L_b-1]      (dag_loss.py:107-110)
+// (st_src / st_dst: the launch's 64 status words move from caller memory to the library's status buffer on the way — see status_end in
+//  dag_dp_banded.hip; a separate 256-byte device-to-device copy costs 5 us, 1 % of the C2 forward)
 __global__ void dag_pick_loss_kernel(const float* alpha, const float* beta, const int64_t* out_len,
-                                     const int64_t* tgt_len, float* loss, int B, int T, int L)
+                                     const int64_t* tgt_len, float* loss, int B, int T, int L,
+                                     const unsigned int* st_src, unsigned int* st_dst)
 {
+    if (st_src && blockIdx.x == 0 && threadIdx.x < 64) st_dst[threadIdx.x] = st_src[threadIdx.x];
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (beta) { loss[b] = beta[(size_t)b * T * L]; return; }
@@ -525,10 +529,13 @@ int launch_dag_dense_rows_gated(const float* match, const float* links, const in
     return check_launch("dag_loss_fwd(dense, stand-by)");
 }
 
+bool status_export(hipStream_t st, const unsigned int** src, unsigned int** dst);
 int launch_pick_loss(const float* alpha, const float* beta, const int64_t* out_len, const int64_t* tgt_len, float* loss,
                      int B, int T, int L, hipStream_t st)
 {
-    hipLaunchKernelGGL(dag_pick_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, st, alpha, beta, out_len, tgt_len, loss, B, T, L);
+    const unsigned int* ssrc = nullptr; unsigned int* sdst = nullptr;
+    (void)status_export(st, &ssrc, &sdst);
+    hipLaunchKernelGGL(dag_pick_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, st, alpha, beta, out_len, tgt_len, loss, B, T, L, ssrc, sdst);
     return check_launch("dag_pick_loss");
 }
 
