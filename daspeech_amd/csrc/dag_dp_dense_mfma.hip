@@ -26,8 +26,10 @@
 // Exactness.  Within a source block all cells are predecessors of every cell of a later block, so scaling a block's row by its own
 // maximum loses only terms 126 binades under the largest one of that block; the per-block partial products are combined against a
 // running maximum of the block exponents (as an online soft-max would).  In the diagonal block the 64 previous values carry one
-// exponent per 16 columns and a column only uses the groups that hold predecessors of it.  A result below 2^-90 of its reference on a
-// cell that has a live predecessor is recomputed exactly in log space (wave-cooperative scan of the predecessors).
+// exponent per 8 columns and a column only uses the groups that hold predecessors of it.  A result below 2^-90 of its reference on a
+// cell that has a live predecessor is recomputed exactly in log space (all flagged columns of the row at once, one lane each, over the
+// live predecessors).  That guard assumes no finite transition flushes to zero in exp space: a range check ahead of the kernel
+// (dag_links_weak_kernel) and a budget on the redo work hand batches for which it does not hold to stand-by log-space kernels (`aborted`).
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
