@@ -257,15 +257,20 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 em[mt][e] = ok ? raw * DM_LOG2E : NEG_INF;
             }
         }
-        const bool chunk_full = tt0 >= 1 && tt0 + TM <= Tb;            // every row of the chunk has a source row: no row predicates
-        const unsigned offS0 = 8u * (unsigned)((tt0 + (tid & (TM - 1)) - 1) * NJ);              // (bytes, as offE)
+        // Rows of the chunk without a source row (step 0 of the first chunk: the seed row; steps >= T_b of the last one) take their
+        // operands from the nearest real step instead — valid, published rows — and compute sums nobody reads (the diagonal wave walks
+        // m_lo .. m_hi only; a row of a product depends on that row of A alone).  So EVERY chunk runs without row predicates: before,
+        // the first and a ragged last chunk took the predicated path (the training shapes, T <= 100: half of their chunks).
+        constexpr bool chunk_full = true;
+        auto src_step = [&](int m) -> int { return min(max(tt0 + m - 1, 0), Tb - 1); };
+        const unsigned offS0 = 8u * (unsigned)(src_step(tid & (TM - 1)) * NJ);              // (bytes, as offE)
         unsigned offS1[MT], offA[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            offS1[mt] = 8u * (unsigned)((tt0 + 16 * mt + (tid >> 4) - 1) * NJ);
+            offS1[mt] = 8u * (unsigned)(src_step(16 * mt + (tid >> 4)) * NJ);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int srow = row(tt0 + 16 * mt + (tid >> 4) - 1), q4 = tid & 15;
+                const int srow = row(src_step(16 * mt + (tid >> 4))), q4 = tid & 15;
                 offA[mt][e] = 4u * (BETA ? (unsigned)(srow * L + L - 1 - 4 * q4 - e - (ub - DM_BW)) : (unsigned)(srow * L + 4 * q4 + e));
             }
         }
