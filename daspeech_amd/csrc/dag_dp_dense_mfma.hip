@@ -202,11 +202,13 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            // (columns past the graph — the ragged last block — take the last real column's weights: in-bounds addresses, and a product's
+            //  column depends on that column of E alone, so the sums nobody reads are the only ones affected)
             if (!BETA) {
-                const int n = tid & 63, g = (tid >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4, cc = 4 * (kk0 + e) + kq;
+                const int n = min(tid & 63, L - 1 - ub), g = (tid >> 6) * 4 + it, kq = g & 3, kk0 = (g >> 2) * 4, cc = 4 * (kk0 + e) + kq;
                 offE[4 * it + e] = 4u * (unsigned)(cc * (TR - 1) + ub + n - 1);               // links[vb + cc][ub + n - vb - cc - 1], BYTES
             } else {
-                const int e0 = tid + 256 * it, hi = e0 >> 4, cc = 4 * (e0 & 15) + e;
+                const int e0 = tid + 256 * it, hi = min(e0 >> 4, L - 1 - ub), cc = 4 * (e0 & 15) + e;
                 offE[4 * it + e] = 4u * (unsigned)((L - 1 - ub - hi) * TR + hi + 63 - cc);    // links[L-1-u][u - vb - cc - 1], base K + ub - 64 - vb, BYTES
             }
         }
@@ -334,10 +336,10 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 }
             };
             auto e_ok = [&](int v, int uu) -> bool { return (uu - v - 1) < TR && uu < L; };          // (v < ub <= uu: the distance is >= 0)
-            // Fast path (every block pair of a dense window except the graph's last, ragged block): all 64 x 64 transitions exist, so
+            // Fast path (every block pair of a dense window; the ragged last block by the clamped columns of offE): all transitions exist, so
             // the loads are  uniform base (scalar, moves with V) + loop-invariant 32-bit thread offset  and the conversion has no
             // predicates — the predicated version below spends ~450 VALU/SALU instructions per source block, 3x the MFMA time.
-            auto e_full = [&](int V) -> bool { return (ub + 63 < L) && (ub + 62 - V * DM_BW < TR); };
+            auto e_full = [&](int V) -> bool { return min(ub + 63, L - 1) - 1 - V * DM_BW < TR; };            // largest distance of the pair
             auto prefetchE = [&](auto SC, int V) {
                 constexpr int s = decltype(SC)::value;
                 if (e_full(V)) {
