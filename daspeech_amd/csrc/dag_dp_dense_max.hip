@@ -114,7 +114,10 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
     // loop-invariant offsets of the predicate-free loads (full tiles): weight element (it, e) = source row k = 16 mg + 4 it + e, column n
     unsigned offW[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) offW[i] = (unsigned)((16 * mg + i) * (TR - 1) + ub + n - 1);          // links[vb + k][ub + n - vb - k - 1]
+    for (int i = 0; i < 16; ++i) offW[i] = (unsigned)((16 * mg + i) * (TR - 1) + ub + min(n, L - 1 - ub) - 1);          // links[vb + k][ub + n - vb - k - 1]
+    // (columns past the graph — the ragged last block — take the last real column's weights: in-bounds, and a column of the product
+    //  depends on that column of the weights alone; rows without a source step likewise take the nearest real step's: dag_dp_dense_mfma.hip)
+    static_assert(DX_MT == 1, "the clamped row offsets below assume one row tile per chunk");
     for (int c = 0; c < nchunks; ++c) {
         const int tt0 = c * DX_TM;
         float acc[DX_MT][4];
@@ -135,8 +138,9 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 em[mt][e] = ok ? raw : NEG_INF;
             }
         }
-        const bool chunk_full = tt0 >= 1 && tt0 + DX_TM <= Tb;
-        const unsigned offS = (unsigned)((tt0 + (tid & (DX_TM - 1)) - 1) * NJ), offA = (unsigned)((tt0 + (tid >> 4) - 1) * L + 4 * (tid & 15));      // (row tile mt: + 16 mt L)
+        constexpr bool chunk_full = true;
+        auto src_step = [&](int m) -> int { return min(max(tt0 + m - 1, 0), Tb - 1); };
+        const unsigned offS = (unsigned)(src_step(tid & (DX_TM - 1)) * NJ), offA = (unsigned)(src_step(tid >> 4) * L + 4 * (tid & 15));
         auto row_ok = [&](int m) -> bool { const int tt = tt0 + m; return tt >= 1 && tt < Tb; };
         if (U > 0) {
             const u32 want = p.tag_base + (u32)c + 1u;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
             // waited for only at need — the pipeline of dag_dp_dense_mfma.hip (its header explains each point).
             float st_s[2], st_a[2][DX_MT][4], st_w[2][16];
             bool st_ok[2];
-            auto w_full = [&](int V) -> bool { return (ub + 63 < L) && (ub + 62 - V * DX_BW < TR); };
+            auto w_full = [&](int V) -> bool { return min(ub + 63, L - 1) - 1 - V * DX_BW < TR; };            // largest distance of the pair
             auto prefetchW = [&](int s, int V) {
                 if (w_full(V)) {
                     const float* Kv = K + (size_t)(V * DX_BW) * (size_t)(TR - 1);
