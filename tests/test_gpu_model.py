@@ -95,15 +95,28 @@ def test_nat_dag_loss_criterion_contract():
     s = make_s2st_batch(3, "cuda", seed=6, min_frames=100, max_frames=150)
     s["target"] = s["target_text"]
     s["update_num"] = 5
-    losses = []
+    losses, grads = [], []
     for torch_ops in (False, True):
         crit = NATDAGLoss(glat_p="0.5", glance_strategy="number-random", torch_dag_loss=torch_ops, torch_dag_best_alignment=torch_ops,
                           torch_dag_logsoftmax_gather=torch_ops)
+        crit.train()                                 # (the criterion's training flag: the DAG branch with gradients; the model stays in eval)
         torch.manual_seed(123)
+        m.zero_grad(set_to_none=True)
         loss, sample_size, log = crit(m, s)
         assert sample_size == 1 and torch.isfinite(loss) and "dag-loss" in log and "dag_nll-loss" in log
+        loss.backward()
         losses.append(float(loss))
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert losses[0] == pytest.approx(losses[1], rel=2e-5)
+    # ... and the same gradient for every parameter: the HIP operators' backward (K1 scatter, K4, K5) against autograd through the
+    # reference's torch formulations (dag_loss.py:303-425), through the whole model
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 50
+    gscale = max(float(g.abs().max()) for g in grads[1].values())        # (a key projection's bias has a zero gradient: noise on both sides)
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        scale = float(b.abs().max()) + 1e-3 * gscale
+        # (fp32 both ways, different summation orders through the DP rows and the layers: observed <= 2.1e-4 of the largest entry)
+        assert float((a - b).abs().max()) <= 1e-3 * scale + 1e-8, (n, float((a - b).abs().max()), scale)
 
 
 def test_graph_decode_matches_dense_torch_formulation():
