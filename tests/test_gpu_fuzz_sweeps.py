@@ -1,0 +1,25 @@
+"""A short slice of every randomised sweep in tools/fuzz_*.py as part of the GPU suite (the long runs — ~4 000 cases in r02 — are
+launched by hand; each tool prints `<n> cases, <k> failures`)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tool,args", [
+    ("fuzz_dag.py", ["40", "7"]),                    # banded windows (TR <= 32): strip4g / maxstrip / exp-space K5
+    ("fuzz_dag.py", ["30", "8", "mid"]),             # TR 33 .. 64: generic row kernels, tiled K5
+    ("fuzz_dag.py", ["40", "9", "dense"]),           # dense windows: matrix-core DP, block-product K5, max-plus alignment, stand-by path
+    ("fuzz_lsg.py", ["40", "3"]),                    # K1 forward / softmax / backward
+    ("fuzz_decode.py", ["40", "5"]),                 # viterbi / jointviterbi / lookahead / greedy graph decode
+])
+def test_randomised_sweep(tool, args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    tail = [l for l in r.stdout.splitlines() if "failures" in l or l.startswith("FAIL")]
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert tail and tail[-1].endswith(", 0 failures"), "\n".join(tail[-10:])
