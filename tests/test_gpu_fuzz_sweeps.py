@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_dag.py", ["40", "9", "dense"]),           # dense windows: matrix-core DP, block-product K5, max-plus alignment, stand-by path
     ("fuzz_lsg.py", ["40", "3"]),                    # K1 forward / softmax / backward
     ("fuzz_decode.py", ["40", "5"]),                 # viterbi / jointviterbi / lookahead / greedy graph decode
+    ("fuzz_links.py", ["40", "2"]),                  # fused extract_links vs the numpy oracle
 ])
 def test_randomised_sweep(tool, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
