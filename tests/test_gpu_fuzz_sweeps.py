@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_lsg.py", ["40", "3"]),                    # K1 forward / softmax / backward
     ("fuzz_decode.py", ["40", "5"]),                 # viterbi / jointviterbi / lookahead / greedy graph decode
     ("fuzz_links.py", ["40", "2"]),                  # fused extract_links vs the numpy oracle
+    ("fuzz_layers.py", ["30", "6"]),                 # split-precision conv / GEMM tiles, layer norm, depthwise conv + BN + SiLU
     ("fuzz_tts_glue.py", ["40", "4"]),               # length regulator, durations, bucketize + embed, posterior / expected features
 ])
 def test_randomised_sweep(tool, args):
