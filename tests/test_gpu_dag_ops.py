@@ -872,3 +872,34 @@ def test_dense_grad_links_with_unrepresentable_transitions(shape):
     gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
     np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=3e-3, atol=2e-7)
     np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=3e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("shape", [(4, 40, 330, 329), (2, 90, 700, 699)])
+def test_dense_dp_on_trained_model_like_scores(shape):
+    """Emissions near 0 on a band around the alignment, a -20-nat floor elsewhere, 4-sigma transition logits over the whole window
+    (what a trained model produces; tools/peaked_dense.py): sums hundreds of binades apart within a row, many cells through the exact
+    redo — and, past its budget, the whole batch through the stand-by kernels.  Whichever path runs: alpha, beta, loss and both
+    gradients against the fp64 oracle, the alignment bit-exact."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    rng = np.random.default_rng(L)
+    ol = np.full(B, L, np.int64); tl = np.full(B, T, np.int64); ol[-1] -= 3; tl[-1] -= 2
+    j = np.arange(L)[None, None, :]; c = (np.arange(T) * (L - 1) / (T - 1))[None, :, None]
+    match = np.where(np.abs(j - c) < 6, -0.5 + 0.3 * rng.standard_normal((B, T, L)), -20.0 + 3.0 * rng.standard_normal((B, T, L))).astype(np.float32)
+    links = _weak_links(3 + L, B, L, TR, ol, 4.0)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    m.requires_grad_(); k.requires_grad_()
+    loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    assert _lib.last_launch_status() == 0 and torch.isfinite(loss).all()
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    a, b = alpha.detach().cpu().numpy(), beta.detach().cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
+    fa, fb = np.isfinite(a64), np.isfinite(b64)
+    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T + 1e-4)
+    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T + 1e-4)
+    gm, gk = torch.autograd.grad(loss.sum(), [m, k])
+    gm64, gl64 = orc.dag_grad(np.ones(B), a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=3e-3, atol=2e-7)
+    np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=3e-3, atol=2e-7)
+    path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+    np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
