@@ -32,6 +32,8 @@ struct GStripParams {
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
     int dbg;
+    const u32* gate;                          // stand-by launch: [ndir*B] words, only (direction, sample) pairs with a non-zero word are computed
+    const u32* prev;                          // ... and the counters of the launch it stands by for (status words are merged)
 };
 
 constexpr int G4_TRP = 32;
@@ -577,6 +579,10 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4g_kernel(GStripParams p)
     const int dirslot = (p.ndir == 2 && rem >= p.B) ? 1 : 0;
     const int s = is_beta ? (p.NS - 1 - so) : so;
     const int j0 = s * W;
+    if (p.gate) {
+        if (ticket == 0 && tid == 0 && p.prev) { atomicOr(&p.counters[1], p.prev[1]); p.counters[6] = p.prev[2]; p.counters[7] = p.prev[3]; for (int i = 0; i < 49; ++i) p.counters[14 + i] = p.prev[7 + i]; }
+        if (p.gate[dirslot * p.B + b] == 0u) return;         // the first launch's result for this sample stands
+    }
     const int T = p.T, L = p.L;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
@@ -621,7 +627,7 @@ static int launch_one_g(const GStripParams& p, int nwg, hipStream_t st)
 }
 
 int launch_dag_strip4g(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
+                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st, const u32* gate, const u32* prev)
 {
     const int ndir = (alpha && beta) ? 2 : 1;
     // strip width: 1024 columns when that still yields >= ~200 workgroups, else 512
@@ -630,7 +636,7 @@ int launch_dag_strip4g(const float* match, const float* links, const int64_t* ou
     const int NS = wide ? ns1024 : ns512;
     GStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
-    p.alpha = alpha; p.beta = beta; p.trace = nullptr;
+    p.alpha = alpha; p.beta = beta; p.trace = nullptr; p.gate = gate; p.prev = prev;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
     { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
     const size_t halo_bytes = (size_t)ndir * B * NS * T * G4_TRP * sizeof(u64);
