@@ -70,6 +70,10 @@ SIGNATURES = {
     "dsp_hifigan_pack_weights": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_pack_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
+    "dsp_hifigan_pack_weights_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_conv_chain_f32": (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_int, _c_p]),
+    "dsp_hifigan_pad_input_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_post_f32": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p, _c_int, _c_p]),
     "dsp_dag_alignment_trace_optional": (_c_int, [_c_int, _c_int]),
     "dsp_dag_debug_k5": (_c_int, [ctypes.POINTER(ctypes.c_uint)]),
     "dsp_dag_set_option": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -42,61 +42,87 @@ def get_anneal_value(anneal_params, update_num):
 
 
 # ------------------------------------------------------------------------------------------------ glancing (nat_dag_loss.py:202-264)
+GLANCE_STRATEGIES = (None, "number-random", "cmlm")
+
+
+def _viterbi_path(model, logits: Tensor, tgt_tokens: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor,
+                  torch_gather: bool, torch_align: bool) -> Tensor:
+    """[B, L] target index per vertex on the best alignment, -1 off it.  The two operator families are selected independently, as the
+    reference's --torch-dag-logsoftmax-gather / --torch-dag-best-alignment flags are (nat_dag_loss.py:210-222)."""
+    idx = tgt_tokens.unsqueeze(1).expand(-1, links.shape[1], -1)
+    gather = custom_ops.torch_dag_logsoftmax_gather_inplace if torch_gather else custom_ops.dag_logsoftmax_gather_inplace
+    # (no gradient here: the HIP operator then leaves the logits untouched, so a defensive clone of B*L*V is not needed)
+    match = gather(logits, idx)[1].transpose(1, 2)
+    if torch_align:
+        return custom_ops.torch_dag_best_alignment(match.detach().clone(), decode_ops.restore_valid_links(links), output_length, target_length)
+    return custom_ops.dag_best_alignment(match, links, output_length, target_length)
+
+
+def _top_scored(scores: Tensor, counts: Tensor) -> Tensor:
+    """1.0 where a position's score is among its row's `counts[b]` largest (nothing for a zero count)."""
+    rank = torch.empty_like(scores, dtype=torch.long)
+    order = scores.argsort(dim=-1, descending=True, stable=True)
+    rank.scatter_(-1, order, torch.arange(scores.shape[-1], device=scores.device).expand_as(order))
+    return (rank < counts.unsqueeze(-1)).to(scores.dtype)
+
+
 @torch.no_grad()
 def glat_function(model, word_ins_out: Tensor, tgt_tokens: Tensor, prev_output_tokens: Tensor, glat: Dict, links: Tensor = None,
-                  glance_strategy: Optional[str] = None, torch_ops: bool = False, noise: Tensor = None, unif: Tensor = None):
+                  glance_strategy: Optional[str] = None, torch_ops: bool = False, noise: Tensor = None, unif: Tensor = None,
+                  torch_gather: Optional[bool] = None, torch_align: Optional[bool] = None, unif_n: Tensor = None):
     """Glancing with the Viterbi alignment.  Same positional signature and return value as the reference's closure
     (`glat_function(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=links)` -> (glat_prev_output_tokens,
-    glat_tgt_tokens, glat_info)).  `glance_strategy`: None (independent draw per aligned vertex with probability
-    (T - same)/T * p, :229-230) or "number-random" (exactly round((T - same) * p) aligned vertices, chosen by random scores,
-    :232-242 — the released recipe, README.md:240,305).  `noise` / `unif` replay the two random draws (randn :236, rand :251);
-    drawn on the device when None.  `torch_ops` selects the torch_* DAG ops (the reference's --torch-dag-* flags)."""
-    batch_size, prelen, _ = links.shape
-    tarlen = tgt_tokens.shape[1]
-    target_length = tgt_tokens.ne(model.pad).sum(1)
-    output_length = prev_output_tokens.ne(model.pad).sum(1)
-    pred_tokens = word_ins_out.argmax(-1)
-    idx = tgt_tokens.unsqueeze(1).expand(-1, prelen, -1)
-    if torch_ops:
-        _, match = custom_ops.torch_dag_logsoftmax_gather_inplace(word_ins_out, idx)
-        match = match.transpose(1, 2)
-        dense = decode_ops.restore_valid_links(links)
-        path = custom_ops.torch_dag_best_alignment(match.detach().clone(), dense, output_length, target_length)
-    else:
-        # (no gradient here: the HIP operator then leaves the logits untouched, so a defensive clone of B*L*V is not needed)
-        _, match = custom_ops.dag_logsoftmax_gather_inplace(word_ins_out, idx)
-        match = match.transpose(1, 2)
-        path = custom_ops.dag_best_alignment(match, links, output_length, target_length)          # [B,L], -1 off the path
-    predict_align_mask = path >= 0
-    matchmask = torch.zeros(batch_size, tarlen + 1, prelen, device=path.device, dtype=torch.bool) \
-        .scatter_(1, path.unsqueeze(1) + 1, 1)[:, 1:]                                              # (:225)
-    oracle = tgt_tokens.gather(-1, path.clip(min=0))                                              # (:226)
-    same_num = ((pred_tokens == oracle) & predict_align_mask).sum(1)                              # (:227)
+    glat_tgt_tokens, glat_info)).
+
+    Which aligned vertices are revealed (`glance_strategy`):
+      None             every aligned vertex independently with probability (T - same) / T * p                     (:229-230)
+      "number-random"  exactly round((T - same) * p) of them, the ones with the largest random scores — the released recipe
+                       (README.md:240,305)                                                                        (:232-239)
+      "cmlm"           round(T * U) of them, U ~ uniform per sentence                                             (:241-248)
+    `noise` (the scores), `unif_n` (cmlm's U) and `unif` (the final per-position draw, :251) replay the random draws in the order the
+    reference takes them; each is drawn on the device when None.  `torch_gather` / `torch_align` select the torch_* DAG ops
+    independently (`torch_ops` sets both)."""
+    if glance_strategy not in GLANCE_STRATEGIES:
+        raise ValueError(f"glance strategy {glance_strategy!r} (supported: {GLANCE_STRATEGIES})")
+    torch_gather = torch_ops if torch_gather is None else torch_gather
+    torch_align = torch_ops if torch_align is None else torch_align
+    B, L, _ = links.shape
+    T = tgt_tokens.shape[1]
+    dev = tgt_tokens.device
+    n_tgt = tgt_tokens.ne(model.pad).sum(1)
+    n_out = prev_output_tokens.ne(model.pad).sum(1)
+    guess = word_ins_out.argmax(-1)
+    path = _viterbi_path(model, word_ins_out, tgt_tokens, links, n_out, n_tgt, torch_gather, torch_align)
+    on_path = path >= 0
+    oracle = tgt_tokens.gather(-1, path.clip(min=0))                       # the token each vertex is aligned to (pad-free on the path)
+    n_right = ((guess == oracle) & on_path).sum(1)
+    # vertex j emits target path[j]: the [B, T, L] emission mask, built through a scratch row for the off-path -1
+    matchmask = torch.zeros(B, T + 1, L, device=dev, dtype=torch.bool).scatter_(1, path.unsqueeze(1) + 1, 1)[:, 1:]
     if glance_strategy is None:
-        keep_prob = ((target_length - same_num) / target_length * glat["context_p"]).unsqueeze(-1) * predict_align_mask.float()
-    elif glance_strategy == "number-random":
-        prob = torch.randn(oracle.shape, device=tgt_tokens.device, dtype=torch.float) if noise is None else noise.to(tgt_tokens.device, torch.float).clone()
-        prob.masked_fill_(~predict_align_mask, -100)
-        glance_nums = ((target_length - same_num) * glat["context_p"] + 0.5).to(torch.long)
-        prob_thresh = prob.sort(descending=True)[0].gather(-1, (glance_nums - 1).clip(min=0).unsqueeze(-1)).squeeze(-1)
-        prob_thresh.masked_fill_(glance_nums == 0, 100)
-        keep_prob = (prob >= prob_thresh.unsqueeze(-1)).to(prob.dtype)
+        keep_prob = ((n_tgt - n_right) / n_tgt * glat["context_p"]).unsqueeze(-1) * on_path.float()
     else:
-        raise ValueError(f"glance strategy {glance_strategy!r} (supported: None, 'number-random')")
+        scores = torch.randn(oracle.shape, device=dev, dtype=torch.float) if noise is None else noise.to(dev, torch.float).clone()
+        scores.masked_fill_(~on_path, -100)
+        if glance_strategy == "number-random":
+            counts = ((n_tgt - n_right) * glat["context_p"] + 0.5).to(torch.long)
+        else:
+            draw = torch.rand_like(n_tgt, dtype=torch.float) if unif_n is None else unif_n.to(dev, torch.float)
+            counts = (n_tgt * draw + 0.5).to(torch.long)
+        keep_prob = _top_scored(scores, counts)
     u = torch.rand(prev_output_tokens.shape, device=prev_output_tokens.device) if unif is None else unif.to(prev_output_tokens.device)
-    keep_word_mask = (u < keep_prob).bool()
-    glat_prev_output_tokens = prev_output_tokens.masked_fill(keep_word_mask, 0) + oracle.masked_fill(~keep_word_mask, 0)
+    revealed = u < keep_prob
+    glanced = torch.where(revealed, oracle, prev_output_tokens)
     glat_info = {
-        "glat_accu": (same_num.sum() / target_length.sum()).detach(),
+        "glat_accu": (n_right.sum() / n_tgt.sum()).detach(),
         "glat_context_p": glat["context_p"],
         "glat_keep": keep_prob.mean().detach(),
         "matchmask": matchmask,
-        "keep_word_mask": keep_word_mask,
-        "glat_prev_output_tokens": glat_prev_output_tokens,
+        "keep_word_mask": revealed,
+        "glat_prev_output_tokens": glanced,
         # extras (not in the reference's dict): the RNG-free intermediates the parity tests compare
-        "path": path, "oracle": oracle, "same_num": same_num,
+        "path": path, "oracle": oracle, "same_num": n_right,
     }
-    return glat_prev_output_tokens, tgt_tokens, glat_info
+    return glanced, tgt_tokens, glat_info
 
 
 DEFAULT_CFG = dict(label_smoothing=0, glat_p="0", glance_strategy=None, no_force_emit=False, torch_dag_logsoftmax_gather=False,
@@ -184,11 +210,10 @@ class NATDAGLoss:
         return {"context_p": max(self.glat_p, 0), "require_glance_grad": False}
 
     def _glat_function(self):
-        torch_ops = bool(self.cfg.torch_dag_best_alignment and self.cfg.torch_dag_logsoftmax_gather)
-
         def fn(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=None):
             return glat_function(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=links,
-                                 glance_strategy=self.glance_strategy, torch_ops=torch_ops)
+                                 glance_strategy=self.glance_strategy, torch_gather=bool(self.cfg.torch_dag_logsoftmax_gather),
+                                 torch_align=bool(self.cfg.torch_dag_best_alignment))
         return fn
 
     # ---- nat_dag_loss.py:164-300
@@ -239,7 +264,8 @@ class S2SDAGFastSpeech2Loss(NATDAGLoss):
         if sample.get("update_num", None) is not None:
             self.set_update_num(sample["update_num"])
         prev_output_tokens = model.initialize_output_tokens_by_tokens(src_tokens, src_lengths)
-        train_dag = self.training and sample.get("update_num", 0) > self.cfg.dag_freezing_steps             # (:191)
+        upd = sample.get("update_num")
+        train_dag = self.training and (upd if upd is not None else 0) > self.cfg.dag_freezing_steps          # (:191)
         with torch.set_grad_enabled(train_dag and torch.is_grad_enabled()):
             outputs = model(src_tokens, src_lengths, prev_output_tokens, tgt_tokens, self._glat_args(), self._glat_function())
         dag_loss, alpha, beta = self._compute_dag_loss_with_alpha_beta(

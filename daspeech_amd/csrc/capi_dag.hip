@@ -28,14 +28,7 @@ int launch_max_alpha_generic(const float* match, const float* links, const int64
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
 
 bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
-int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t,
-                       const unsigned int* gate = nullptr, const unsigned int* prev = nullptr);
-
-bool colsweep_supported(const void* match, const void* alpha, const void* beta, int B, int T, int L, int TR);
-long colsweep_waves(const void* alpha, const void* beta, int B, int T);
-size_t colsweep_gran_bytes(int B, int T, int L, int ndir);
-int launch_dag_colsweep(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int,
-                        unsigned int** abort_words, unsigned int** counters, hipStream_t);
+int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
 
 bool dense_mfma_supported(int L, int TR);
@@ -58,13 +51,10 @@ int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, cons
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
-// 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 64),
-// 10 = column sweep, one DP row per lane pair (dag_dp_colsweep.hip; the auto choice for TR <= 32 when B * T fills the chip) followed by
-//      its gated stand-by launch (strip4g on the samples the sweep could not certify), 11 = the sweep alone (timing experiments).
+// 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 64).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
 static thread_local int g_path = 0;
-static int g_colsweep_auto = 0;                      // (enabled once the sweep is the faster kernel on the target shapes)
 static unsigned int g_last_fallbacks = 0;
 static unsigned int g_dbg[64] = {0};
 
@@ -87,8 +77,6 @@ extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
         const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
         const long NS = (2L * B * ns1024 >= 200) ? ns1024 : ns512;
         halo = (size_t)2 * B * NS * T * 32 * 8;
-        if (!(L & 3) && L >= 32)                      // column sweep first (counters + abort words + granules), strip4g as its stand-by
-            halo += 512 + align256((size_t)2 * B * 4) + colsweep_gran_bytes(B, T, L, 2);
     } else if (TR <= 64) {                            // banded 2-column strips of 512
         halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
     } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
@@ -132,15 +120,8 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    // auto: column sweep when its waves fill the chip, else strip4g for the log-sum DP; strip2 for the max-DP with a trace
-    const bool cs_ok = colsweep_supported(match, alpha, beta, B, T, L, TR) && strip4g_supported(match, alpha, beta, L, TR);
-    if (cs_ok && (g_path == 10 || g_path == 11 || (g_path == 0 && g_colsweep_auto && colsweep_waves(alpha, beta, B, T) >= 640))) {
-        unsigned int *abort_words = nullptr, *cs_counters = nullptr;
-        rc = launch_dag_colsweep(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, &abort_words, &cs_counters, st);
-        if (!rc && g_path != 11)
-            rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st, abort_words, cs_counters);
-    }
-    else if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
+    // auto: strip4g for the log-sum DP, strip2 for the max-DP with a trace
+    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
@@ -249,7 +230,6 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
 {
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
-    if (name && !strcmp(name, "colsweep_auto")) { g_colsweep_auto = value; return DSP_OK; }
     if (name && !strcmp(name, "dm_depth")) { set_dm_depth(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_budget")) { set_dm_budget(value); return DSP_OK; }

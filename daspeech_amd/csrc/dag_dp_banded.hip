@@ -403,35 +403,6 @@ int launch_dag_banded(int mode, const float* match, const float* links, const in
     return check_launch(mode == 0 ? "dag_loss_fwd(banded)" : "dag_best_alignment(banded)");
 }
 
-// Column-sweep DP (dag_dp_colsweep.hip): 256 bytes of counters + one abort word per (direction, sample) + the row hand-off granules, all
-// zeroed on the launch stream (a granule is valid when its upper word is non-zero: no tag epochs).  Library scratch for it is a buffer of
-// its own: the stand-by launch that follows acquires the shared one while the abort words must stay readable.
-static std::unordered_map<u64, BandedWS> g_ws_cs;
-int colsweep_acquire_ws(hipStream_t st, size_t abort_bytes, size_t gran_bytes, u32** counters, u32** abort_words, u64** gran)
-{
-    const size_t ab = (abort_bytes + 255) & ~(size_t)255;
-    const size_t need = 256 + ab + gran_bytes;
-    char* c = reinterpret_cast<char*>(caller_ws_take(need));
-    if (!c) {
-        std::lock_guard<std::mutex> lock(g_ws_mutex);
-        BandedWS& w = g_ws_cs[ws_key(st)];
-        if (w.bytes < need) {
-            if (w.base) (void)hipFree(w.base);
-            w.base = nullptr; w.bytes = 0;
-            hipError_t e = hipMalloc(&w.base, need);
-            if (e != hipSuccess) { set_error("dag colsweep workspace: hipMalloc(%zu): %s", need, hipGetErrorString(e)); return (int)e; }
-            w.bytes = need;
-        }
-        c = reinterpret_cast<char*>(w.base);
-    }
-    hipError_t e = hipMemsetAsync(c, 0, need, st);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    *counters = reinterpret_cast<u32*>(c);
-    *abort_words = reinterpret_cast<u32*>(c + 256);
-    *gran = reinterpret_cast<u64*>(c + 256 + ab);
-    return DSP_OK;
-}
-
 // error word of the most recent DP launch on this stream (host-synchronising; used by tests / debugging only).  With a caller
 // workspace the words live in the caller's memory: valid as long as the caller has not recycled it.
 int banded_last_error_word(hipStream_t st, u32* word)

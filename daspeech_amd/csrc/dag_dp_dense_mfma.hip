@@ -879,7 +879,9 @@ bool dense_rows_gated_supported(int L);
 int launch_dag_dense_rows_gated(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int,
                                 unsigned int*, unsigned long long*, unsigned int, const unsigned int*, hipStream_t);
 
-bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31); }
+// (L beyond what the stand-by log-space kernels take has no exact fallback for transitions exp space flushes: such shapes stay with the
+// generic log-space kernel)
+bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31) && dense_rows_gated_supported(L); }
 
 template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)

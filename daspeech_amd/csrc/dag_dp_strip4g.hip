@@ -32,8 +32,6 @@ struct GStripParams {
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
     int dbg;
-    const u32* gate;                          // stand-by launch: [ndir*B] words, only (direction, sample) pairs with a non-zero word are computed
-    const u32* prev;                          // ... and the counters of the launch it stands by for (status words are merged)
 };
 
 constexpr int G4_TRP = 32;
@@ -70,6 +68,12 @@ __device__ __forceinline__ void g4_barrier(G4Prof& pf) {
 
 // window element index of (column c, distance d):  alpha: predecessor j+c-d -> q = 32 + c - d ; beta: successor -> q = c + d
 template <bool BETA> __device__ __forceinline__ constexpr int gqidx(int c, int d) { return BETA ? (c + d) : (32 + c - d); }
+
+// does weight pair i (window elements 2i, 2i+1) hold a transition of column c at all?  (6 of the 72 pairs do not: skipped statically)
+template <bool BETA> __device__ __forceinline__ constexpr bool gpair_live(int c, int i) {
+    const int lo = BETA ? c + 1 : c, hi = BETA ? c + 32 : c + 31;
+    return 2 * i + 1 >= lo && 2 * i <= hi;
+}
 
 template <int NT, int MODE, bool BETA, bool PROF>
 __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_raw, int b, int s, int dirslot, int so, int profslot)
@@ -127,6 +131,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
 
     if (wave < NCW) {
         // =========================================================== compute waves
+        __builtin_amdgcn_s_setprio(2);           // the compute wave of a SIMD goes before the helper wave that shares it
         const int l = tid;                       // lane's group
         const int j = j0 + 4 * l;
         const bool col_ok = j < L;
@@ -283,8 +288,8 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                 { asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(pv[k])); \
                   v2f wa, wb; wa.x = ldexpf(pv[k].x, kg[k]); wa.y = ldexpf(pv[k].y, kg[k]); wb.x = ldexpf(pv[k].z, kg[k]); wb.y = ldexpf(pv[k].w, kg[k]); \
                   _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
-                      S2[c] = __builtin_elementwise_fma(wa, E2[c][2 * k], S2[c]); \
-                      S2[c] = __builtin_elementwise_fma(wb, E2[c][2 * k + 1], S2[c]); } }
+                      if (gpair_live<BETA>(c, 2 * k)) S2[c] = __builtin_elementwise_fma(wa, E2[c][2 * k], S2[c]); \
+                      if (gpair_live<BETA>(c, 2 * k + 1)) S2[c] = __builtin_elementwise_fma(wb, E2[c][2 * k + 1], S2[c]); } }
                 G4_GROUP(0, 8) G4_GROUP(1, 7) G4_GROUP(2, 6) G4_GROUP(3, 5) G4_GROUP(4, 4)
                 G4_GROUP(5, 3) G4_GROUP(6, 2) G4_GROUP(7, 1) G4_GROUP(8, 0)
 #undef G4_GROUP
@@ -579,10 +584,6 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4g_kernel(GStripParams p)
     const int dirslot = (p.ndir == 2 && rem >= p.B) ? 1 : 0;
     const int s = is_beta ? (p.NS - 1 - so) : so;
     const int j0 = s * W;
-    if (p.gate) {
-        if (ticket == 0 && tid == 0 && p.prev) { atomicOr(&p.counters[1], p.prev[1]); p.counters[6] = p.prev[2]; p.counters[7] = p.prev[3]; for (int i = 0; i < 49; ++i) p.counters[14 + i] = p.prev[7 + i]; }
-        if (p.gate[dirslot * p.B + b] == 0u) return;         // the first launch's result for this sample stands
-    }
     const int T = p.T, L = p.L;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
@@ -627,7 +628,7 @@ static int launch_one_g(const GStripParams& p, int nwg, hipStream_t st)
 }
 
 int launch_dag_strip4g(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st, const u32* gate, const u32* prev)
+                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
 {
     const int ndir = (alpha && beta) ? 2 : 1;
     // strip width: 1024 columns when that still yields >= ~200 workgroups, else 512
@@ -636,7 +637,7 @@ int launch_dag_strip4g(const float* match, const float* links, const int64_t* ou
     const int NS = wide ? ns1024 : ns512;
     GStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
-    p.alpha = alpha; p.beta = beta; p.trace = nullptr; p.gate = gate; p.prev = prev;
+    p.alpha = alpha; p.beta = beta; p.trace = nullptr;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
     { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
     const size_t halo_bytes = (size_t)ndir * B * NS * T * G4_TRP * sizeof(u64);

@@ -1,6 +1,7 @@
 // dag_grad.hip — K4 (grad wrt match_all) and K5 (grad wrt links) for gfx950, generic log-space form.
 // Replaces calculate_grad_match_all_kernel (dag_loss.cu:378-401) and calculate_grad_links_kernel (:432-485).
 #include "common.h"
+#include <atomic>
 
 namespace dsp {
 
@@ -342,16 +343,21 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     }
 }
 
+// PROCESS-wide: dsp_dag_loss_bwd is called from PyTorch's autograd worker thread, not from the thread that pins the kernel (a
+// thread_local pin was silently ignored by every backward driven through torch.autograd, r02 ADVICE).  g_k5_last records which
+// family the last backward launched (1 tiled log space, 2 exp space, 3 dense block products) so a test can assert its pin took.
+static std::atomic<int> g_k5_path{0};                      // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
+static std::atomic<unsigned int> g_k5_last{0};
 int k5_diag(unsigned int* out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gx_diag), 16);
     unsigned int z[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gx_diag), z, 16);
+    out[3] = g_k5_last.exchange(0u);
     return (int)e;
 }
 bool grad_dense_supported(int L, int TR);
 int launch_dag_grad_links_dense(const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, int, hipStream_t);
 
-static thread_local int g_k5_path = 0;                     // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
 void set_k5_path(int v) { g_k5_path = v; }
 
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,
@@ -373,6 +379,7 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
                            g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
         int rc = check_launch("dag_loss_bwd(grad_links, exp space)");
         if (rc) return rc;
+        g_k5_last = 2u;
     } else if (g_links && g_k5_path != 1 && grad_dense_supported(L, TR)) {
         // dense window: block products over the target axis on the f32 matrix cores (dag_grad_dense.hip).  Half of the compact
         // [L][TR] layout addresses vertices past the graph (i + d + 1 >= L): zeros, as the reference's at::zeros leaves them.
@@ -380,11 +387,13 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         if (e != hipSuccess) { set_error("hipMemsetAsync(grad_links): %s", hipGetErrorString(e)); return (int)e; }
         int rc = launch_dag_grad_links_dense(g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR, st);
         if (rc) return rc;
+        g_k5_last = 3u;
     } else if (g_links) {
         hipLaunchKernelGGL(dag_grad_links_tiled_kernel, dim3((L + 63) / 64, (TR + 31) / 32, B), dim3(256), 0, st,
                            g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
         int rc = check_launch("dag_loss_bwd(grad_links)");
         if (rc) return rc;
+        g_k5_last = 1u;
     }
     return DSP_OK;
 }

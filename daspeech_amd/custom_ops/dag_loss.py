@@ -67,18 +67,13 @@ def _f32c(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
-# Scratch of the DP launches comes from torch's allocator (one grow-only tensor per device and stream, like the reference's per-call
-# ATen scratch, dag_loss.cu:154): the C ABI zeroes what it uses on the launch stream, so nothing is allocated, freed or kept by the
-# library and the launches are graph-capturable.
-_WS = {}
-
-
+# Scratch of the DP launches comes from torch's caching allocator PER CALL (like the reference's per-call ATen scratch,
+# dag_loss.cu:154): stream-ordered, returned to the cache when the call returns (the C ABI moves its status words out of it on the
+# launch stream), subject to the allocator's OOM retry, and graph-capturable.  The C ABI zeroes what it uses on the launch stream,
+# so nothing is allocated, freed or kept by the library.  (r02 kept a grow-only tensor per (device, stream) alive for the life of
+# the process — 2.1 GB at C2 with the README's dense window, pinned outside the allocator.)
 def _workspace(dev: torch.device, nbytes: int) -> Tensor:
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _WS[key] = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-    return ws
+    return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
 
 
 def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):

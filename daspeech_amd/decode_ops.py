@@ -243,10 +243,10 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
     # the final vertex is out of reach within max_length steps (a window far narrower than the model's: L / 4 steps of at most TR
     # vertices): every candidate score is -inf, the reference's arg-maxes all return index 0 (:267-278) and it emits the one token of
     # vertex 0 — reproduced, not "fixed"
-    unreach = torch.isneginf(best).all(dim=1)
-    if bool(unreach.any()):
-        on = on & ~unreach.unsqueeze(1)
-        on[unreach, 0] = True
+    # (applied on the device unconditionally: a host-side `if unreach.any()` would synchronise every decode batch for a corner case)
+    unreach = torch.isneginf(best).all(dim=1, keepdim=True)
+    first = torch.arange(L, device=dev).unsqueeze(0) == 0
+    on = torch.where(unreach, first, on)
     prev_tok = torch.full((B,), -12345, dtype=tok.dtype, device=dev)
     # token kept if it is the LAST visited vertex, or (not pad and differs from the next visited token)   (:291-299, backward order)
     vis_idx = torch.argsort((~on).to(torch.int8), dim=1, stable=True)   # visited vertices first, ascending

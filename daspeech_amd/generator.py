@@ -11,6 +11,19 @@ import torch
 from torch import Tensor
 
 
+def _accepts_lengths(vocoder) -> bool:
+    """Does the vocoder callable take the per-utterance `lengths` keyword (models/hifigan.HiFiGANGenerator does)?"""
+    if vocoder is None:
+        return False
+    import inspect
+    try:
+        fn = vocoder.forward if hasattr(vocoder, "forward") else vocoder
+        params = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return "lengths" in params or any(p.kind == inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 class S2SNATGenerator:
     """`generate(model, sample)` is the reference's call (one batch, in order).  `submit` / `flush` / `generate_batches` run the same
     two stages as a two-deep pipeline over consecutive batches: the acoustic model of batch k is ISSUED (≈14 ms of host time for ≈1000
@@ -20,6 +33,7 @@ class S2SNATGenerator:
     def __init__(self, vocoder=None, gcmvn_mean: Optional[Tensor] = None, gcmvn_std: Optional[Tensor] = None,
                  vocoder_group: int = 8):
         self.vocoder, self.mean, self.std, self.vocoder_group = vocoder, gcmvn_mean, gcmvn_std, vocoder_group
+        self._vocoder_takes_lengths = _accepts_lengths(vocoder)
         self._side = None            # vocoder stream of the pipelined mode
         self._pending = None         # acoustic stage issued, vocoder not yet: (stage-1 outputs, completion event)
         self._inflight = None        # vocoder issued on the side stream: (results, completion event)
@@ -59,8 +73,10 @@ class S2SNATGenerator:
             gmax = max(1, max(lens[i] for i in idx))
             sub = mel_sorted[g0:g0 + gsz, :gmax]
             fmask = torch.arange(gmax, device=mel.device).unsqueeze(0) >= len_sorted[g0:g0 + gsz].unsqueeze(1)
-            # per-utterance lengths go down to the vocoder: each utterance's samples are those of vocoding it alone
-            w = self.vocoder(sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2), lengths=len_sorted[g0:g0 + gsz].clamp(min=1)).squeeze(1)
+            # per-utterance lengths go down to the vocoder: each utterance's samples are those of vocoding it alone.  (A vocoder
+            # callable that does not take `lengths` — any module with the reference generator's forward(mel) — gets the padded group.)
+            x = sub.masked_fill(fmask.unsqueeze(-1), 0).transpose(1, 2)
+            w = (self.vocoder(x, lengths=len_sorted[g0:g0 + gsz].clamp(min=1)) if self._vocoder_takes_lengths else self.vocoder(x)).squeeze(1)
             for k, i in enumerate(idx):
                 wavs[i] = w[k, : max(lens[i], 1) * hop]
         return wavs

@@ -5,7 +5,11 @@
   ConvTranspose1d  weight [Cin,Cout,2u]       -> 2 taps [2][u*Cout][Cin] fp16 (phase-major rows), shifts {0,-1}, pad u/2
 and runs Generator.forward (hifi-gan/models.py:100-119) as a chain of `dsp_hifigan_conv` launches on channels-last fp16
 activations; the residual add of each ResBlock1 unit (models.py:41-42) and the mean over the three kernel sizes (:105-111) are
-fused into the conv epilogues.  fp16 storage / fp32 accumulate: the waveform differs from the fp32 torch path by ~1e-3 (tested).
+fused into the conv epilogues.  Two arithmetic modes (`precision`):
+  "fp16"  fp16 activations + weights, fp32 accumulate (csrc/hifigan_conv.hip): the waveform differs from the reference's fp32 generator by
+          ~1.5e-3 — NARROWER than the reference, the fast mode;
+  "fp32"  fp32 activations + weights (the reference's arithmetic, hifi-gan/inference_e2e.py:47-56) with split operands on the fp16 matrix
+          cores (csrc/hifigan_conv_f32.hip): waveform within 1e-4 of the reference (tests/test_tts_golden.py).
 """
 import ctypes
 from typing import List
@@ -30,7 +34,7 @@ class HgLayerDesc(ctypes.Structure):          # include/daspeech_hifigan.h: dsp_
 
 
 class _Layer:
-    __slots__ = ("w", "bias", "shifts", "ntaps", "CI", "M", "Cout", "mode", "u", "pad", "dil")
+    __slots__ = ("w", "w_lo", "bias", "shifts", "ntaps", "CI", "M", "Cout", "mode", "u", "pad", "dil")
 
 
 def _shifts_array(sh: List[int]):
@@ -49,11 +53,29 @@ def pack_weights(w_tap_major: Tensor) -> Tensor:
     return out
 
 
+def pack_weights_f32(w_tap_major: Tensor):
+    """[ntaps][M][CI] fp32 -> (hi, lo) fp16 fragment-order buffers of the split-precision kernels (dsp_hifigan_pack_weights_f32)."""
+    lib = _lib.load()
+    w = w_tap_major.contiguous().float()
+    K, M, CI = w.shape
+    n = lib.dsp_hifigan_packed_weight_elems(K, M, CI)
+    hi = torch.empty((n,), dtype=torch.float16, device=w.device)
+    lo = torch.empty((n,), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.dsp_hifigan_pack_weights_f32(_lib.ptr(w), _lib.ptr(hi), _lib.ptr(lo), K, M, CI, _lib.current_stream_handle()),
+                   "dsp_hifigan_pack_weights_f32")
+    return hi, lo
+
+
 class HiFiGANHipRunner:
-    def __init__(self, gen, fuse_units: bool = True):
+    def __init__(self, gen, fuse_units: bool = True, precision: str = "fp16"):
         """fuse_units: run a ResBlock unit (conv, conv, residual) as ONE launch where dsp_hifigan_resunit supports its shape
-        (C <= 128); False keeps the layer-at-a-time chain (same bits, 2.5x the activation traffic) for comparison."""
-        self.fuse_units = fuse_units
+        (C <= 128); False keeps the layer-at-a-time chain (same bits, 2.5x the activation traffic) for comparison.
+        precision: "fp16" (fp16 storage, fp32 accumulate) or "fp32" (the reference's arithmetic by operand splitting; layer-at-a-time)."""
+        assert precision in ("fp16", "fp32")
+        self.precision = precision
+        self.f32 = precision == "fp32"
+        self.fuse_units = fuse_units and not self.f32
         dev = next(gen.parameters()).device
         assert dev.type == "cuda", "HiFiGANHipRunner needs the generator on a GPU"
         self.dev = dev
@@ -72,6 +94,12 @@ class HiFiGANHipRunner:
         self.post_k = cp.weight.shape[2]
         self._plans = {}
 
+    def _pack(self, L, w_tap_major: Tensor):
+        if self.f32:
+            L.w, L.w_lo = pack_weights_f32(w_tap_major)
+        else:
+            L.w, L.w_lo = pack_weights(w_tap_major.to(torch.float16)), None
+
     def _conv_layer(self, m, ci_pad=None):
         L = _Layer()
         w = m.weight.detach()                                   # [Cout, Cin, K]
@@ -79,7 +107,7 @@ class HiFiGANHipRunner:
         if ci_pad and ci_pad != Cin:
             w = torch.nn.functional.pad(w, (0, 0, 0, ci_pad - Cin))
             Cin = ci_pad
-        L.w = pack_weights(w.permute(2, 0, 1).contiguous().to(torch.float16))
+        self._pack(L, w.permute(2, 0, 1).contiguous())
         L.bias = m.bias.detach().float().contiguous() if m.bias is not None else None
         d = m.dilation[0]
         L.shifts = [(k - (K - 1) // 2) * d for k in range(K)]
@@ -92,7 +120,7 @@ class HiFiGANHipRunner:
         Cin, Cout, K = w.shape
         u = m.stride[0]
         assert K == 2 * u and m.padding[0] == (K - u) // 2, "expects the HiFi-GAN upsampler geometry (kernel 2u, pad u/2)"
-        L.w = pack_weights(w.permute(2, 1, 0).reshape(2, u * Cout, Cin).contiguous().to(torch.float16))      # tap j, row (r, co): k = j*u + r
+        self._pack(L, w.permute(2, 1, 0).reshape(2, u * Cout, Cin).contiguous())      # tap j, row (r, co): k = j*u + r
         L.bias = m.bias.detach().float().contiguous() if m.bias is not None else None
         L.shifts = [0, -1]
         L.ntaps, L.CI, L.M, L.Cout, L.mode, L.u, L.pad = 2, Cin, u * Cout, Cout, OUT_UPSAMPLE, u, (K - u) // 2
@@ -100,6 +128,7 @@ class HiFiGANHipRunner:
 
     def _run(self, L, x: Tensor, slope: float, res: Tensor = None, out: Tensor = None, mode=None, scale: float = 1.0) -> Tensor:
         B, T, CI = x.shape
+        assert not self.f32, "single-layer calls are offered by the fp16-storage kernels only"
         assert CI == L.CI and x.dtype == torch.float16 and x.is_contiguous()
         mode = L.mode if mode is None else mode
         Tout = T * L.u if L.mode == OUT_UPSAMPLE else T
@@ -176,22 +205,23 @@ class HiFiGANHipRunner:
                 first = False
             release(x); x = acc
         offs, tot = [], 0
+        esz = 4 if self.f32 else 2                                 # bytes per activation element
         for sz in sizes:
-            offs.append(tot); tot += (sz + 63) // 64 * 64          # 128-byte aligned buffers
+            offs.append(tot); tot += (sz + 63) // 64 * 64          # 128-byte (fp32: 256-byte) aligned buffers
         # ONE grow-only workspace shared by all cached plans (a plan is offsets + a launch table); growing it invalidates the tables.
         # Calls of one runner are therefore ordered on ONE stream at a time (use one runner per stream for concurrent vocoding).
         ws = getattr(self, "_ws", None)
         if ws is None or ws.numel() < tot or ws.device != dev:
             self._plans.clear()
-            ws = self._ws = torch.empty((tot,), dtype=torch.float16, device=dev)
+            ws = self._ws = torch.empty((tot,), dtype=torch.float32 if self.f32 else torch.float16, device=dev)
         base = ws.data_ptr()
         table = (HgLayerDesc * len(recs))()
         for d, rec in zip(table, recs):
             L, xb, rb, ob, tt, slope, mode, scale = rec[:8]
             L2 = rec[8] if len(rec) > 8 else None
-            d.w2 = L2.w.data_ptr() if L2 is not None else None
+            d.w2 = L2.w.data_ptr() if L2 is not None else (L.w_lo.data_ptr() if self.f32 else None)      # fp32 chain: w2 = lo part of w
             d.bias2 = L2.bias.data_ptr() if (L2 is not None and L2.bias is not None) else None
-            d.x = base + 2 * offs[xb]; d.res = (base + 2 * offs[rb]) if rb is not None else None; d.out = base + 2 * offs[ob]
+            d.x = base + esz * offs[xb]; d.res = (base + esz * offs[rb]) if rb is not None else None; d.out = base + esz * offs[ob]
             d.w = L.w.data_ptr(); d.bias = L.bias.data_ptr() if L.bias is not None else None
             d.T, d.CI, d.M, d.ntaps = tt, L.CI, L.M, L.ntaps
             for k, sh in enumerate(L.shifts):
@@ -199,7 +229,7 @@ class HiFiGANHipRunner:
             d.pre_slope, d.scale = slope, scale
             d.out_mode = L.mode if mode is None else mode
             d.up_u, d.up_pad, d.Tout, d.Cout = L.u, L.pad, (tt * L.u if L.mode == OUT_UPSAMPLE else tt), L.Cout
-        plan = (ws, table, base + 2 * offs[x_first], base + 2 * offs[x], t, self.ups[-1].Cout if self.ups else self.pre.Cout)
+        plan = (ws, table, base + esz * offs[x_first], base + esz * offs[x], t, self.ups[-1].Cout if self.ups else self.pre.Cout)
         if len(self._plans) >= 32:
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = plan
@@ -216,8 +246,16 @@ class HiFiGANHipRunner:
             ws, table, x_in, x_last, Tw, Cl = self._plan(B, T, mel.device)
             st = _lib.current_stream_handle()
             mt = mel.detach().float().transpose(1, 2).contiguous()
-            _lib.check(lib.dsp_hifigan_pack_input(_lib.ptr(mt), ctypes.c_void_p(x_in), B, T, C, self.in_pad, st), "dsp_hifigan_pack_input")
             wav = torch.empty((B, Tw), dtype=torch.float32, device=mel.device)
+            if self.f32:
+                lens = None if lengths is None else lengths.to(device=mel.device, dtype=torch.int32).contiguous()
+                assert lens is None or lens.shape == (B,)
+                _lib.check(lib.dsp_hifigan_pad_input_f32(_lib.ptr(mt), ctypes.c_void_p(x_in), B, T, C, self.in_pad, st), "dsp_hifigan_pad_input_f32")
+                _lib.check(lib.dsp_hifigan_conv_chain_f32(table, len(table), B, _lib.ptr(lens), T, st), "dsp_hifigan_conv_chain_f32")
+                _lib.check(lib.dsp_hifigan_post_f32(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl,
+                                                    self.post_k, 0.01, _lib.ptr(lens), Tw // T, st), "dsp_hifigan_post_f32")
+                return wav.unsqueeze(1)
+            _lib.check(lib.dsp_hifigan_pack_input(_lib.ptr(mt), ctypes.c_void_p(x_in), B, T, C, self.in_pad, st), "dsp_hifigan_pack_input")
             if lengths is None:
                 _lib.check(lib.dsp_hifigan_conv_chain(table, len(table), B, st), "dsp_hifigan_conv_chain")
                 _lib.check(lib.dsp_hifigan_post(ctypes.c_void_p(x_last), _lib.ptr(self.post_w), self.post_b, _lib.ptr(wav), B, Tw, Cl, self.post_k,

@@ -7,7 +7,9 @@ reference state dict — with or without weight-norm (`weight_g`/`weight_v`) —
 
 Compute: activations stay channels-first [B, C, T]; every conv goes through `conv_backend`:
   * "torch"  — torch.nn.functional conv1d / conv_transpose1d (MIOpen on ROCm); the functional reference of this repo;
-  * "hip"    — hand-written gfx950 kernels (daspeech_amd/csrc/hifigan_conv.hip) where available.
+  * "hip"    — hand-written gfx950 kernels: fp32 activations / weights as the reference (operand splitting on the fp16 matrix cores,
+                daspeech_amd/csrc/hifigan_conv_f32.hip; waveform within 1e-4 of the reference generator);
+  * "hip_fp16" — the same stack with fp16 activation / weight storage (csrc/hifigan_conv.hip): ~3x faster, 1.5e-3 off the reference.
 """
 import json
 from typing import Dict
@@ -107,11 +109,12 @@ class HiFiGANGenerator(nn.Module):
         """mel [B, 80, T] (de-normalised log-mel) -> waveform [B, 1, T*256] in (-1, 1).  `lengths` [B]: mel frames per utterance of a
         zero-padded batch; waveform[b, :, :lengths[b]*hop] then equals the utterance vocoded on its own, which is what the reference
         does (hifi-gan/inference_e2e.py:47-56) — the HIP backend masks per layer inside its kernels, the torch backend loops."""
-        if self.conv_backend == "hip" and mel.is_cuda:
-            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self.conv_backend in ("hip", "hip_fp16") and mel.is_cuda:
+            key = (self.conv_backend,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
             if getattr(self, "_hip_runner", None) is None or getattr(self, "_hip_runner_key", None) != key:
                 from ..hifigan_ops import HiFiGANHipRunner
-                self._hip_runner, self._hip_runner_key = HiFiGANHipRunner(self), key       # re-packed whenever a weight changed
+                prec = "fp32" if self.conv_backend == "hip" else "fp16"
+                self._hip_runner, self._hip_runner_key = HiFiGANHipRunner(self, precision=prec), key   # re-packed whenever a weight changed
             return self._hip_runner(mel, lengths)
         if lengths is not None:
             out = mel.new_zeros(mel.shape[0], 1, mel.shape[2] * self.hop)

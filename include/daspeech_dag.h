@@ -146,7 +146,8 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);
-/* diagnostics of the exp-space grad_links kernel since the last call: out4 = {lanes redone exactly, unsafe factor, weak link, 0} */
+/* diagnostics of the grad_links kernels since the last call: out4 = {lanes redone exactly, unsafe factor, weak link (exp-space kernel),
+ * family of the last grad_links launch: 1 tiled log space, 2 exp space, 3 dense block products, 0 none} */
 int dsp_dag_debug_k5(unsigned int* out4);
 int dsp_dag_set_option(const char* name, int value);
 int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);

@@ -147,9 +147,10 @@ def forward_decoder(logits, links, features, prev_output_tokens, strategy, pad=1
 # a10 — GLAT.  DASpeech/criterions/nat_dag_loss.py:202-264, DASpeech/criterions/utilities.py:17-37
 # ----------------------------------------------------------------------------------------------------------------
 
-def glat(logits, links, prev_output_tokens, tgt_tokens, context_p, strategy=None, noise=None, unif=None, pad=1):
+def glat(logits, links, prev_output_tokens, tgt_tokens, context_p, strategy=None, noise=None, unif=None, pad=1, unif_n=None):
     """RNG-free outputs (path, matchmask, oracle tokens, same_num, glance_nums / keep_prob) and — given the draws `noise`
-    (the randn of :236) and `unif` (the rand of :251) — keep_word_mask and glat_prev_output_tokens."""
+    (the randn of :236 / :242), `unif_n` (cmlm's per-sentence rand_like, :244) and `unif` (the rand of :251) — keep_word_mask and
+    glat_prev_output_tokens."""
     f32 = np.float32
     logits = np.asarray(logits, f32)
     tgt = np.asarray(tgt_tokens); prev = np.asarray(prev_output_tokens)
@@ -171,8 +172,13 @@ def glat(logits, links, prev_output_tokens, tgt_tokens, context_p, strategy=None
            "glat_accu": f32(same.sum()) / f32(tgt_len.sum())}
     if strategy is None:
         keep_prob = ((tgt_len - same).astype(f32) / tgt_len.astype(f32) * f32(context_p))[:, None] * on.astype(f32)   # :230
-    elif strategy == "number-random":
-        glance_nums = ((tgt_len - same).astype(f32) * f32(context_p) + f32(0.5)).astype(np.int64)                     # :238
+    elif strategy in ("number-random", "cmlm"):
+        if strategy == "number-random":
+            glance_nums = ((tgt_len - same).astype(f32) * f32(context_p) + f32(0.5)).astype(np.int64)                 # :238
+        else:
+            if unif_n is None:
+                return out
+            glance_nums = (tgt_len.astype(f32) * np.asarray(unif_n, f32) + f32(0.5)).astype(np.int64)                 # :244
         out["glance_nums"] = glance_nums
         if noise is None:
             return out

@@ -204,7 +204,8 @@ def glat_golden():
     store = {}
     rng = np.random.default_rng(44)
     for tag, (B, L, T, TR, V, strategy, p) in {"none": (3, 18, 6, 5, 11, None, 0.5), "nr": (4, 22, 7, 21, 9, "number-random", 0.5),
-                                               "nr0": (2, 12, 5, 11, 7, "number-random", 0.01)}.items():
+                                               "nr0": (2, 12, 5, 11, 7, "number-random", 0.01),
+                                               "cmlm": (4, 20, 8, 19, 9, "cmlm", 0.5)}.items():
         lens = np.array([L, L - 2, L - 4, L - 1][:B]); tlens = np.array([T, T - 1, T - 2, T][:B])
         logits = (rng.standard_normal((B, L, V)) * 1.5).astype(np.float32)
         links = make_links(rng, B, L, min(TR, L - 1), lens)
@@ -226,12 +227,14 @@ def glat_golden():
         with torch.enable_grad():
             gp, gt, info = glat_fn(model, torch.from_numpy(logits.copy()), torch.from_numpy(tgt), torch.from_numpy(prev), {"context_p": p},
                                    links=torch.from_numpy(links.copy()))
-        # replay of the draws, in the reference's order: randn(oracle.shape) [number-random only], then rand(prev.shape)
+        # replay of the draws, in the reference's order: randn(oracle.shape) [number-random / cmlm], rand_like(target_length) [cmlm
+        # only: the glance count], then rand(prev.shape)
         torch.manual_seed(seed)
         noise = torch.randn(B, L) if strategy is not None else torch.zeros(B, L)
+        unif_n = torch.rand(B) if strategy == "cmlm" else torch.zeros(B)
         unif = torch.rand(B, L)
         store.update({f"{tag}_logits": logits, f"{tag}_links": links, f"{tag}_prev": prev, f"{tag}_tgt": tgt, f"{tag}_p": np.float32(p),
-                      f"{tag}_strategy": np.array(str(strategy)), f"{tag}_noise": noise.numpy(), f"{tag}_unif": unif.numpy(),
+                      f"{tag}_strategy": np.array(str(strategy)), f"{tag}_noise": noise.numpy(), f"{tag}_unif": unif.numpy(), f"{tag}_unif_n": unif_n.numpy(),
                       f"{tag}_glat_prev": gp.numpy(), f"{tag}_matchmask": info["matchmask"].numpy(), f"{tag}_keep_word_mask": info["keep_word_mask"].numpy(),
                       f"{tag}_glat_accu": np.float32(info["glat_accu"]), f"{tag}_glat_keep": np.float32(info["glat_keep"])})
         print("glat", tag, "kept", info["keep_word_mask"].sum(1).tolist(), "accu", float(info["glat_accu"]))

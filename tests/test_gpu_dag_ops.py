@@ -422,6 +422,7 @@ def test_grad_links_exp_space_weak_and_peaked_links(shape, k5):
         _lib.load().dsp_dag_debug_k5(diag)
     finally:
         _lib.set_option("k5_path", 0)
+    assert diag[3] == (2 if (k5 == 2 and L % 4 == 0) else 1)       # the pinned kernel family is the one that ran (autograd's worker thread sees the pin)
     if k5 == 2 and L % 4 == 0:
         assert diag[2] > 0                               # the weak-transition redo really ran
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
@@ -529,6 +530,7 @@ def test_dense_grad_links_block_products_match_oracle(shape, weak):
     64 and L-1, -inf emissions, transitions ~2^-130 (weak), and the compact layout's entries past the graph (i + d + 1 >= L_b) are
     exactly zero as the reference's at::zeros output leaves them (dag_loss.cu:493)."""
     from daspeech_amd import _lib
+    import ctypes
     B, T, L, TR = shape
     match, links, ol, tl = make_dag_inputs(17 + L, B, T, L, TR)
     rng = np.random.default_rng(L + 5)
@@ -545,6 +547,8 @@ def test_dense_grad_links_block_products_match_oracle(shape, weak):
             fin = torch.isfinite(loss)
             gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
             assert _lib.last_launch_status() == 0
+            diag = (ctypes.c_uint * 4)(); _lib.load().dsp_dag_debug_k5(diag)
+            assert diag[3] == (1 if k5 == 1 else 3), (k5, diag[3])          # 1 = the tiled log-space kernel really ran when pinned
             res[k5] = (gm.cpu().numpy(), gl.cpu().numpy())
     finally:
         _lib.set_option("k5_path", 0)

@@ -304,30 +304,30 @@ def test_oracle_glat_hand_case():
 def _glat_case(g, tag):
     strategy = str(g[f"{tag}_strategy"])
     return (g[f"{tag}_logits"], g[f"{tag}_links"], g[f"{tag}_prev"], g[f"{tag}_tgt"], float(g[f"{tag}_p"]),
-            None if strategy == "None" else strategy, g[f"{tag}_noise"], g[f"{tag}_unif"])
+            None if strategy == "None" else strategy, g[f"{tag}_noise"], g[f"{tag}_unif"], g[f"{tag}_unif_n"])
 
 
-@pytest.mark.parametrize("tag", ["none", "nr", "nr0"])
+@pytest.mark.parametrize("tag", ["none", "nr", "nr0", "cmlm"])
 def test_oracle_glat_vs_reference(golden_dir, tag):
     g = load(golden_dir, "glat")
-    logits, links, prev, tgt, p, strategy, noise, unif = _glat_case(g, tag)
-    o = gorc.glat(logits, links, prev, tgt, p, strategy, noise, unif, PAD)
+    logits, links, prev, tgt, p, strategy, noise, unif, unif_n = _glat_case(g, tag)
+    o = gorc.glat(logits, links, prev, tgt, p, strategy, noise, unif, PAD, unif_n=unif_n)
     np.testing.assert_array_equal(o["matchmask"], g[f"{tag}_matchmask"])
     np.testing.assert_array_equal(o["keep_word_mask"], g[f"{tag}_keep_word_mask"])
     np.testing.assert_array_equal(o["glat_prev_output_tokens"], g[f"{tag}_glat_prev"])
     np.testing.assert_allclose(o["glat_accu"], g[f"{tag}_glat_accu"], rtol=1e-6)
     np.testing.assert_allclose(o["glat_keep"], g[f"{tag}_glat_keep"], rtol=1e-5)
-    if strategy == "number-random":                                   # count invariant: exactly glance_nums glanced vertices per sample
+    if strategy in ("number-random", "cmlm"):                         # count invariant: exactly glance_nums glanced vertices per sample
         np.testing.assert_array_equal(o["keep_word_mask"].sum(1), o["glance_nums"])
 
 
 def _product_glat(g, tag, device, torch_ops):
     from daspeech_amd.criterions import glat_function
-    logits, links, prev, tgt, p, strategy, noise, unif = _glat_case(g, tag)
+    logits, links, prev, tgt, p, strategy, noise, unif, unif_n = _glat_case(g, tag)
     t = lambda a: torch.from_numpy(a).to(device)
     model = SimpleNamespace(pad=PAD)
     return glat_function(model, t(logits.copy()), t(tgt), t(prev), {"context_p": p}, links=t(links), glance_strategy=strategy,
-                         torch_ops=torch_ops, noise=t(noise), unif=t(unif))
+                         torch_ops=torch_ops, noise=t(noise), unif=t(unif), unif_n=t(unif_n))
 
 
 def _check_glat(out, g, tag):
@@ -340,21 +340,21 @@ def _check_glat(out, g, tag):
     np.testing.assert_allclose(float(info["glat_keep"]), g[f"{tag}_glat_keep"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["none", "nr", "nr0"])
+@pytest.mark.parametrize("tag", ["none", "nr", "nr0", "cmlm"])
 def test_product_glat_torch_ops_vs_reference(golden_dir, tag):
     g = load(golden_dir, "glat")
     _check_glat(_product_glat(g, tag, "cpu", True), g, tag)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["none", "nr", "nr0"])
+@pytest.mark.parametrize("tag", ["none", "nr", "nr0", "cmlm"])
 def test_product_glat_hip_vs_reference_and_oracle(golden_dir, tag):
     """criterions.glat_function on the HIP ops (dag_logsoftmax_gather_inplace + dag_best_alignment) with the stored draws."""
     g = load(golden_dir, "glat")
     out = _product_glat(g, tag, "cuda", False)
     _check_glat(out, g, tag)
-    logits, links, prev, tgt, p, strategy, noise, unif = _glat_case(g, tag)
-    o = gorc.glat(logits, links, prev, tgt, p, strategy, noise, unif, PAD)
+    logits, links, prev, tgt, p, strategy, noise, unif, unif_n = _glat_case(g, tag)
+    o = gorc.glat(logits, links, prev, tgt, p, strategy, noise, unif, PAD, unif_n=unif_n)
     for key in ("path", "oracle", "same_num"):
         np.testing.assert_array_equal(out[2][key].cpu().numpy(), o[key])
 

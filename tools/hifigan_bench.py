@@ -7,9 +7,10 @@ g = HiFiGANGenerator().cuda().eval()
 mel = torch.randn(B, 80, T, device="cuda")
 flops = 0.614e9 * B * T
 from daspeech_amd.hifigan_ops import HiFiGANHipRunner
-for backend in (("torch",) if os.environ.get("HG_TORCH") else ()) + ("hip-chain", "hip"):
-    g.conv_backend = backend.split("-")[0]
-    g._hip_runner = HiFiGANHipRunner(g, fuse_units=(backend == "hip")) if backend != "torch" else None
+for backend in (("torch",) if os.environ.get("HG_TORCH") else ()) + ("hip-chain", "hip", "hip-f32"):
+    g.conv_backend = "torch" if backend == "torch" else "hip"
+    g._hip_runner = HiFiGANHipRunner(g, fuse_units=(backend == "hip"), precision="fp32" if backend == "hip-f32" else "fp16") if backend != "torch" else None
+    g._hip_runner_key = ("hip",) + tuple((p.data_ptr(), p._version) for p in g.parameters())
     with torch.no_grad():
         for _ in range(2): g(mel)
         torch.cuda.synchronize(); t0 = time.perf_counter()
