@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
     ap.add_argument("--no-peaked", action="store_true")
     ap.add_argument("--no-c1", action="store_true")
+    ap.add_argument("--torch-links", action="store_true", help="train: the torch [B,L,L,h] formulation of extract_links instead of the fused band kernels")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.workload == "s2tt" else 32
@@ -387,6 +388,8 @@ def build_model_step(ctx, args, workload):
     B = args.batch
     model = calibrate_synthetic_weights(S2TConformerDAGModel() if workload == "s2tt" else S2SConformerDAGFastSpeech2Model()).to(dev)
     model.args.decode_strategy = args.decode_strategy
+    if getattr(args, "torch_links", False):
+        model.decoder.fused_links = False
     batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
     amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
     state = {"frames": 0, "model": model, "batches": batches, "B": B}
@@ -497,6 +500,10 @@ def run_model(ctx, args, workload, steps, warmup, sustain=0):
         rep["mel_frames_per_utt"] = state["mel_frames_per_utt"]
         if ctx.rank == 0:
             rep["roofline"] = vocoder_roofline(ctx, args, state)
+    if workload == "train":
+        rep["peak_memory_GB"] = ctx.torch.cuda.max_memory_allocated() / 2 ** 30
+        rep["workload"] += ("; extract_links: torch [B,L,L,h] formulation" if getattr(args, "torch_links", False)
+                            else "; extract_links: fused compact-band HIP forward + backward")
     state.clear()
     ctx.torch.cuda.empty_cache()
     return rep
@@ -518,7 +525,8 @@ def main():
         dtype = ("f32" if args.amp == "none" else args.amp) if args.workload != "train" else ("bf16" if args.amp == "bf16" else "fp16")
         result = {**base, "value": rep["value"], "steps": rep["steps"], "warmup": rep["warmup"], "ms_per_step": rep["ms_per_step"], "dtype": dtype,
                   "config": {"workload": rep["workload"], "batch_per_gpu": rep["batch_per_gpu"], "parallelism": par,
-                             **({"mel_frames_per_utt": rep["mel_frames_per_utt"]} if "mel_frames_per_utt" in rep else {})},
+                             **({"mel_frames_per_utt": rep["mel_frames_per_utt"]} if "mel_frames_per_utt" in rep else {}),
+                             **({"peak_memory_GB": rep["peak_memory_GB"]} if "peak_memory_GB" in rep else {})},
                   "roofline": rep.get("roofline"), "cpu_baseline": None}
     elif args.workload == "dag":
         rep, roofline = dag_report(ctx, args, args.steps, args.warmup)

@@ -44,6 +44,9 @@ SIGNATURES = {
     "dsp_follow_path": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_gather_rows": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_extract_links": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
+    "dsp_extract_links_train": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
+    "dsp_extract_links_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                       ctypes.c_float, _c_p]),
     "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_durations": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "dsp_bucketize_embed_add": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p]),

@@ -25,6 +25,7 @@ template <int CK4>                            // head width / 4
 __global__ __launch_bounds__(256) void extract_links_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ log_gates,
     const int64_t* __restrict__ out_len, const float* __restrict__ dist_bias, float* __restrict__ links,
+    float* __restrict__ stats,                // [B,L,H,2] (window max, log of the window's sum) per head: the backward's state, or NULL
     int B, int L, int TR, float scale)
 {
     extern __shared__ __attribute__((aligned(16))) float xl_smem[];
@@ -85,7 +86,11 @@ __global__ __launch_bounds__(256) void extract_links_kernel(
             for (int dc = 0; dc < TR; dc += 32) { const int d = dc + d0; if (d < TR) sum += __expf(sc[((size_t)ii * TRp + d) * XL_H + h] - mx[ii]); }
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 32);
-        if (d0 == 0) { red[(ii * XL_H + h) * 2] = mx[ii]; red[(ii * XL_H + h) * 2 + 1] = (mx[ii] == NEG_INF) ? 0.f : __logf(sum); }
+        if (d0 == 0) {
+            const float ls = (mx[ii] == NEG_INF) ? 0.f : __logf(sum);
+            red[(ii * XL_H + h) * 2] = mx[ii]; red[(ii * XL_H + h) * 2 + 1] = ls;
+            if (stats && ii < nit) { float* st = stats + (((size_t)b * L + i0 + ii) * XL_H + h) * 2; st[0] = mx[ii]; st[1] = ls; }
+        }
     }
     __syncthreads();
     // ---- links[b,i,d] = logsumexp_h(score - max_h - logsum_h + log_gate_h); every thread takes slots tid, tid+256, ...
@@ -116,7 +121,217 @@ __global__ __launch_bounds__(256) void extract_links_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the fused link producer on the COMPACT band (training side): no [B,L,L,H] tensor exists
+// in either direction.  With  ls[i,d,h] = log_softmax_d(s[i,d,h]),  links[i,d] = logsumexp_h(ls[i,d,h] + g[i,h])  and the incoming
+// gradient G[i,d]:
+//     A[i,d,h]  = G[i,d] * exp(ls[i,d,h] + g[i,h] - links[i,d])            (the head's share of the link)
+//     dg[i,h]   = SA[i,h] = sum_d A[i,d,h]
+//     ds[i,d,h] = A[i,d,h] - exp(ls[i,d,h]) * SA[i,h]                      (log-soft-max backward)
+//     dq[i,h,:] = scale * sum_d ds[i,d,h] * k[i+d+1,h,:]        dk[j,h,:] = scale * sum_{i+d+1=j} ds[i,d,h] * q[i,h,:]
+// Two launches of one kernel.  OWNER rows (4 per workgroup) are source vertices i for dq / dg (partners = successors j) and
+// successors j for dk (TRANSPOSED: partners = sources i); the scores of the owner rows against their partners are recomputed
+// as in the forward (thread = (head, partner slot), partner row in registers), ds is built in the LDS score image from the
+// forward's per-row soft-max state (`stats`) and — for dk — the dg / SA the first launch wrote, and then contracted with the
+// partner rows by threads (owner pair, head, 4 channels).  Nothing but q, k, the compact links / G and [B,L,H] state moves.
+template <int CK4, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void extract_links_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ log_gates,
+    const int64_t* __restrict__ out_len, const float* __restrict__ dist_bias, const float* __restrict__ links,
+    const float* __restrict__ G, const float* __restrict__ stats, float* __restrict__ dgate /* = SA: written by the first launch */,
+    float* __restrict__ dout /* dq or dk */, int B, int L, int TR, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float xl_smem[];
+    constexpr int CK = CK4 * 4;
+    const int TRp = ((TR + 31) / 32) * 32;
+    float* own = xl_smem;                          // [IT][H][CK]   the owner rows (q for dq, k for dk)
+    float* sc = own + XL_IT * XL_H * CK;           // [IT][TRp][H]  scores, then ds
+    float* red = sc + (size_t)XL_IT * TRp * XL_H;  // [IT][H]       SA of the owner rows (first launch)
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, d0 = tid & 31, h = tid >> 5;
+    const int Lb = min((int)out_len[b], L);
+    const size_t rowstride = (size_t)XL_H * CK;
+    const int o0 = blockIdx.x * XL_IT;
+    const int nit = min(XL_IT, L - o0);
+    const float* OWN = TRANSPOSED ? k : q;
+    const float* PAR = TRANSPOSED ? q : k;
+    for (int e = tid; e < nit * XL_H * CK; e += 256) own[e] = OWN[((size_t)b * L + o0) * rowstride + e];
+    for (int e = tid; e < XL_IT * TRp * XL_H; e += 256) sc[e] = TRANSPOSED ? 0.f : NEG_INF;
+    __syncthreads();
+    // partner range: successors o0+1 .. o0+nit-1+TR (inside the graph), or sources o0-TR .. o0+nit-2
+    const int pbeg = TRANSPOSED ? max(0, o0 - TR) : (o0 + 1);
+    const int pend = TRANSPOSED ? min(o0 + nit - 1, Lb) : min(Lb, o0 + nit + TR);
+    for (int pc = pbeg; pc < pend; pc += 32) {
+        const int pp = pc + d0;
+        const bool live = pp < pend;
+        float4 pv[CK4];
+        const float4* pr = reinterpret_cast<const float4*>(PAR + ((size_t)b * L + (live ? pp : pc)) * rowstride + (size_t)h * CK);
+#pragma unroll
+        for (int c = 0; c < CK4; ++c) pv[c] = pr[c];
+        float st_mx = 0.f, st_ls = 0.f, st_g = 0.f, st_sa = 0.f;
+        if (TRANSPOSED && live) {                   // the soft-max row is the PARTNER (source vertex pp)
+            const size_t so = ((size_t)b * L + pp) * XL_H + h;
+            st_mx = stats[2 * so]; st_ls = stats[2 * so + 1]; st_g = log_gates[so]; st_sa = dgate[so];
+        }
+#pragma unroll
+        for (int oo = 0; oo < XL_IT; ++oo) {
+            const int o = o0 + oo;
+            const int d = TRANSPOSED ? (o - pp - 1) : (pp - o - 1);
+            const float4* orow = reinterpret_cast<const float4*>(own + (oo * XL_H + h) * CK);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CK4; ++c) {
+                const float4 ov = orow[c];
+                a0 = fmaf(ov.x, pv[c].x, a0); a1 = fmaf(ov.y, pv[c].y, a1); a2 = fmaf(ov.z, pv[c].z, a2); a3 = fmaf(ov.w, pv[c].w, a3);
+            }
+            if (live && oo < nit && d >= 0 && d < TR && (!TRANSPOSED || o < Lb)) {
+                float sv = ((a0 + a1) + (a2 + a3)) * scale;
+                if (dist_bias) sv += dist_bias[d];
+                if (!TRANSPOSED) sc[((size_t)oo * TRp + d) * XL_H + h] = sv;
+                else {
+                    const size_t lo = ((size_t)b * L + pp) * TR + d;
+                    const float lk = links[lo], ls = (sv - st_mx) - st_ls;
+                    const float A = (lk == NEG_INF || st_mx == NEG_INF) ? 0.f : G[lo] * __expf(ls + st_g - lk);
+                    sc[((size_t)oo * TRp + d) * XL_H + h] = (st_mx == NEG_INF) ? 0.f : (A - __expf(ls) * st_sa);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!TRANSPOSED) {
+        // ---- SA of the owner rows, then ds in place
+        for (int oo = 0; oo < nit; ++oo) {
+            const int i = o0 + oo;
+            const size_t so = ((size_t)b * L + i) * XL_H + h;
+            const float mxv = stats[2 * so], lsv = stats[2 * so + 1], gv = log_gates[so];
+            float sa = 0.f;
+            if (mxv != NEG_INF)
+                for (int dc = 0; dc < TR; dc += 32) {
+                    const int d = dc + d0;
+                    if (d < TR) {
+                        const float sv = sc[((size_t)oo * TRp + d) * XL_H + h];
+                        const size_t lo = ((size_t)b * L + i) * TR + d;
+                        const float lk = links[lo];
+                        if (sv != NEG_INF && lk != NEG_INF) sa += G[lo] * __expf(((sv - mxv) - lsv) + gv - lk);
+                    }
+                }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) sa += __shfl_xor(sa, o, 32);
+            if (d0 == 0) { red[oo * XL_H + h] = sa; dgate[so] = sa; }
+            for (int dc = 0; dc < TRp; dc += 32) {
+                const int d = dc + d0;
+                const float sv = sc[((size_t)oo * TRp + d) * XL_H + h];
+                float dsv = 0.f;
+                if (d < TR && sv != NEG_INF && mxv != NEG_INF) {
+                    const size_t lo = ((size_t)b * L + i) * TR + d;
+                    const float lk = links[lo], ls = (sv - mxv) - lsv;
+                    const float A = (lk == NEG_INF) ? 0.f : G[lo] * __expf(ls + gv - lk);
+                    dsv = A - __expf(ls) * sa;
+                }
+                sc[((size_t)oo * TRp + d) * XL_H + h] = dsv;
+            }
+        }
+        for (int oo = nit; oo < XL_IT; ++oo)
+            for (int dc = 0; dc < TRp; dc += 32) sc[((size_t)oo * TRp + dc + d0) * XL_H + h] = 0.f;
+        __syncthreads();
+    }
+    // ---- contraction with the partner rows: thread = (owner pair, head, 4 channels)
+    {
+        const int c4 = tid & (CK4 - 1), hh = (tid / CK4) % XL_H, op = tid / (CK4 * XL_H);       // CK4 * 8 * 2 = 256 for CK = 64
+        constexpr int NOP = 256 / (CK4 * XL_H);                                                 // owner groups per pass (2 for CK 64, 4 for CK 32, 1 for CK 128)
+        constexpr int OPG = XL_IT / NOP;                                                        // owner rows per thread
+        float4 acc[OPG];
+#pragma unroll
+        for (int x = 0; x < OPG; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pp = pbeg; pp < pend; ++pp) {
+            const float4 pv = *reinterpret_cast<const float4*>(PAR + ((size_t)b * L + pp) * rowstride + (size_t)hh * CK + c4 * 4);
+#pragma unroll
+            for (int x = 0; x < OPG; ++x) {
+                const int oo = op * OPG + x;
+                const int d = TRANSPOSED ? (o0 + oo - pp - 1) : (pp - o0 - oo - 1);
+                const float dsv = (d >= 0 && d < TR) ? sc[((size_t)oo * TRp + d) * XL_H + hh] : 0.f;
+                acc[x].x = fmaf(dsv, pv.x, acc[x].x); acc[x].y = fmaf(dsv, pv.y, acc[x].y);
+                acc[x].z = fmaf(dsv, pv.z, acc[x].z); acc[x].w = fmaf(dsv, pv.w, acc[x].w);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < OPG; ++x) {
+            const int oo = op * OPG + x;
+            if (oo < nit)
+                *reinterpret_cast<float4*>(dout + ((size_t)b * L + o0 + oo) * rowstride + (size_t)hh * CK + c4 * 4) =
+                    make_float4(acc[x].x * scale, acc[x].y * scale, acc[x].z * scale, acc[x].w * scale);
+        }
+    }
+}
+
 }  // namespace dsp
+
+static int xl_check(const char* fn, const void* q, const void* k, const void* g, const void* ol, const void* links, int B, int L, int H, int CK, int TR, size_t* lds)
+{
+    using namespace dsp;
+    if (B < 0 || L < 1 || TR < 1 || CK < 4) { set_error("%s: bad sizes B=%d L=%d TR=%d CK=%d", fn, B, L, TR, CK); return DSP_EINVAL; }
+    if (H != XL_H) { set_error("%s: needs %d heads (got H=%d)", fn, XL_H, H); return DSP_EINVAL; }
+    if (B > 0 && (!q || !k || !g || !ol || !links)) { set_error("%s: null pointer", fn); return DSP_EINVAL; }
+    if ((((uintptr_t)q) | ((uintptr_t)k)) & 15) { set_error("%s: q / k must be 16-byte aligned", fn); return DSP_EINVAL; }
+    *lds = ((size_t)XL_IT * XL_H * CK + (size_t)XL_IT * ((TR + 31) / 32) * 32 * XL_H + 2 * XL_IT * XL_H) * sizeof(float);
+    if (*lds > 150 * 1024) { set_error("%s: TR=%d too large for the score image", fn, TR); return DSP_EINVAL; }
+    if (!(CK == 32 || CK == 64 || CK == 128)) { set_error("%s: head width %d (32, 64 or 128)", fn, CK); return DSP_EINVAL; }
+    return DSP_OK;
+}
+
+extern "C" int dsp_extract_links_train(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
+                                       const float* dist_bias, float* links, float* stats, int B, int L, int H, int CK, int TR, float scale,
+                                       dsp_stream_t stream)
+{
+    using namespace dsp;
+    size_t lds;
+    int rc = xl_check("extract_links_train", q, k, log_gates, out_len, links, B, L, H, CK, TR, &lds);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!stats) { set_error("extract_links_train: null stats"); return DSP_EINVAL; }
+    auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
+                       q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale);
+    return check_launch("extract_links_train");
+}
+
+template <int CK4>
+static int xl_bwd_launch(const float* q, const float* k, const float* g, const int64_t* ol, const float* bias, const float* links, const float* G,
+                         const float* stats, float* dq, float* dk, float* dg, int B, int L, int TR, float scale, size_t lds, hipStream_t st)
+{
+    using namespace dsp;
+    auto ka = extract_links_bwd_kernel<CK4, false>;
+    auto kb = extract_links_bwd_kernel<CK4, true>;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const dim3 grid((L + XL_IT - 1) / XL_IT, B);
+    hipLaunchKernelGGL(ka, grid, dim3(256), lds, st, q, k, g, ol, bias, links, G, stats, dg, dq, B, L, TR, scale);
+    int rc = check_launch("extract_links_bwd(dq, dgate)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(kb, grid, dim3(256), lds, st, q, k, g, ol, bias, links, G, stats, dg, dk, B, L, TR, scale);
+    return check_launch("extract_links_bwd(dk)");
+}
+
+extern "C" int dsp_extract_links_bwd(const float* q, const float* k, const float* log_gates, const int64_t* out_len, const float* dist_bias,
+                                     const float* links, const float* grad_links, const float* stats,
+                                     float* grad_q, float* grad_k, float* grad_log_gates, int B, int L, int H, int CK, int TR, float scale,
+                                     dsp_stream_t stream)
+{
+    using namespace dsp;
+    size_t lds;
+    int rc = xl_check("extract_links_bwd", q, k, log_gates, out_len, links, B, L, H, CK, TR, &lds);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!grad_links || !stats || !grad_q || !grad_k || !grad_log_gates) { set_error("extract_links_bwd: null pointer"); return DSP_EINVAL; }
+    if ((((uintptr_t)grad_q) | ((uintptr_t)grad_k)) & 15) { set_error("extract_links_bwd: grad_q / grad_k must be 16-byte aligned"); return DSP_EINVAL; }
+    hipStream_t st = as_stream(stream);
+    if (CK == 64) return xl_bwd_launch<16>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
+    if (CK == 32) return xl_bwd_launch<8>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
+    return xl_bwd_launch<32>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
+}
 
 extern "C" int dsp_extract_links(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
                                  const float* dist_bias, float* links, int B, int L, int H, int CK, int TR, float scale,
@@ -134,6 +349,6 @@ extern "C" int dsp_extract_links(const float* q, const float* k, const float* lo
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
-                       q, k, log_gates, out_len, dist_bias, links, B, L, TR, scale);
+                       q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale);
     return check_launch("extract_links");
 }

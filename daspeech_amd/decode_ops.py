@@ -108,6 +108,53 @@ def extract_links(q: Tensor, k: Tensor, log_gates: Tensor, output_length: Tensor
     return links
 
 
+class _ExtractLinksFn(torch.autograd.Function):
+    """Fused link producer under autograd: forward = dsp_extract_links_train (compact band + per-row soft-max state), backward =
+    dsp_extract_links_bwd (scores recomputed per tile; no [B,L,L,H] tensor in either direction)."""
+
+    @staticmethod
+    def forward(ctx, q, k, log_gates, output_length, TR, dist_bias):
+        qf = q.detach().to(torch.float32).contiguous()
+        kf = k.detach().to(torch.float32).contiguous()
+        gf = log_gates.detach().to(torch.float32).contiguous()
+        ol = output_length.to(torch.long).contiguous()
+        B, L, H, CK = qf.shape
+        bias = None if dist_bias is None else dist_bias.detach().to(device=qf.device, dtype=torch.float32).contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(qf.device):
+            links = torch.empty((B, L, TR), dtype=torch.float32, device=qf.device)
+            stats = torch.empty((B, L, H, 2), dtype=torch.float32, device=qf.device)
+            _lib.check(lib.dsp_extract_links_train(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
+                                                   _lib.ptr(stats), B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()),
+                       "dsp_extract_links_train")
+        ctx.save_for_backward(qf, kf, gf, ol, links, stats, bias if bias is not None else qf.new_empty(0))
+        ctx.TR, ctx.has_bias, ctx.in_dtypes = TR, bias is not None, (q.dtype, k.dtype, log_gates.dtype)
+        ctx.mark_non_differentiable(output_length)
+        return links
+
+    @staticmethod
+    def backward(ctx, grad_links):
+        qf, kf, gf, ol, links, stats, bias = ctx.saved_tensors
+        B, L, H, CK = qf.shape
+        g = grad_links.detach().to(torch.float32).contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(qf.device):
+            dq, dk = torch.empty_like(qf), torch.empty_like(kf)
+            dg = torch.empty_like(gf)
+            _lib.check(lib.dsp_extract_links_bwd(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias if ctx.has_bias else None),
+                                                 _lib.ptr(links), _lib.ptr(g), _lib.ptr(stats), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dg),
+                                                 B, L, H, CK, ctx.TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links_bwd")
+        dt = ctx.in_dtypes
+        return dq.to(dt[0]), dk.to(dt[1]), dg.to(dt[2]), None, None, None
+
+
+def extract_links_autograd(q: Tensor, k: Tensor, log_gates: Tensor, output_length: Tensor, TR: int,
+                           dist_bias: Optional[Tensor] = None) -> Tensor:
+    """`extract_links` with gradients w.r.t. q, k and log_gates (training: the step in front of dag_loss).  `dist_bias` is a constant."""
+    _gpu("extract_links", q, k, log_gates, output_length)
+    return _ExtractLinksFn.apply(q, k, log_gates, output_length, int(TR), dist_bias)
+
+
 def posterior(alpha: Tensor, beta: Tensor) -> Tensor:
     """score = exp(alpha + beta - logsumexp_j(alpha + beta)), NaN -> 0   (s2s_dag_fastspeech2_loss.py:259-260)."""
     _gpu("posterior", alpha, beta)

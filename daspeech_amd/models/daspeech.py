@@ -270,7 +270,7 @@ class DAGDecoder(nn.Module):
         self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
         self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
-        self.fused_links = True                 # inference: fused compact-band HIP kernel (False: the torch formulation)
+        self.fused_links = True                 # fused compact-band HIP kernels, forward and backward (False: the torch formulation)
 
     @staticmethod
     def positions(tokens: Tensor) -> Tensor:
@@ -298,10 +298,15 @@ class DAGDecoder(nn.Module):
         k = decode_ops.linear(fp, self.key_linear).view(B, L, h, ck).float()
         log_gates = F.log_softmax(decode_ops.linear(fp, self.gate_linear), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
-        if feats.is_cuda and not torch.is_grad_enabled() and h == 8 and ck % 4 == 0 and ck <= 128 and TR >= 1 and self.fused_links:
-            # inference: the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather
+        if feats.is_cuda and h == 8 and ck in (32, 64, 128) and TR >= 1 and self.fused_links \
+                and not (dist_bias is not None and dist_bias.requires_grad and torch.is_grad_enabled()):
+            # the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather; under autograd the backward
+            # recomputes the scores tile by tile from q, k and [B,L,h] soft-max state (dsp_extract_links_bwd)
             bias = None if dist_bias is None else dist_bias[:TR]
-            return decode_ops.extract_links(q, k, log_gates, prev_output_tokens.ne(PAD).sum(-1), TR, bias)
+            olen = prev_output_tokens.ne(PAD).sum(-1)
+            if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or log_gates.requires_grad):
+                return decode_ops.extract_links_autograd(q, k, log_gates, olen, TR, bias)
+            return decode_ops.extract_links(q, k, log_gates, olen, TR, bias)
         content = torch.einsum("bicf,bjcf->bijc", q, k) / (ck ** 0.5)                               # [B,L,L,h]
         idx = torch.arange(L, device=feats.device).unsqueeze(1) + torch.arange(TR, device=feats.device).unsqueeze(0) + 1
         out_len = prev_output_tokens.ne(PAD).sum(-1)

@@ -47,6 +47,18 @@ int dsp_gather_rows(const void* features, int dtype, const int32_t* keep_idx, co
 int dsp_extract_links(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
                       const float* dist_bias, float* links, int B, int L, int H, int CK, int TR, float scale,
                       dsp_stream_t stream);
+/* The TRAINING side of F0 (the step in front of dag_loss: s2t_conformer_dag.py:171-212 under autograd), still on the compact band only:
+ *   dsp_extract_links_train   the same forward, additionally writing `stats` [B,L,H,2] = (window maximum, log of the window's sum of
+ *                             exp(score - maximum)) per source vertex and head — all the state the backward needs besides q, k, links;
+ *   dsp_extract_links_bwd     grad_links [B,L,TR] (entries of -inf links are ignored) -> grad_q, grad_k [B,L,H,CK], grad_log_gates [B,L,H].
+ *                             Scores are recomputed per 4-vertex tile, d(score) lives in LDS only: no [B,L,L,H] tensor in either direction. */
+int dsp_extract_links_train(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
+                            const float* dist_bias, float* links, float* stats, int B, int L, int H, int CK, int TR, float scale,
+                            dsp_stream_t stream);
+int dsp_extract_links_bwd(const float* q, const float* k, const float* log_gates, const int64_t* out_len, const float* dist_bias,
+                          const float* links, const float* grad_links, const float* stats,
+                          float* grad_q, float* grad_k, float* grad_log_gates, int B, int L, int H, int CK, int TR, float scale,
+                          dsp_stream_t stream);
 
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */

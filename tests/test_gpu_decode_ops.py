@@ -184,6 +184,86 @@ def test_fused_extract_links_matches_torch_formulation(TRmax):
     torch.testing.assert_close(torch.logsumexp(got[rows], -1), torch.zeros_like(got[rows][:, 0]), rtol=0, atol=2e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("TRmax,heads_dim", [(32, 512), (99999, 512), (7, 512), (99999, 256), (20, 1024)])
+def test_fused_extract_links_backward_matches_torch_formulation(TRmax, heads_dim):
+    """dsp_extract_links_train / dsp_extract_links_bwd (compact band, scores recomputed per tile, no [B,L,L,H] tensor) under autograd vs
+    the torch restatement of s2t_conformer_dag.py:171-212: gradients w.r.t. q, k and the gate logits — and through them every parameter
+    of the links head — on ragged graphs, banded and dense (TR = L-1) windows, head widths 32 / 64 / 128, with a loss that weights the
+    links unevenly and ignores the -inf entries (as dag_loss's gradient does)."""
+    from daspeech_amd.models.daspeech import DAGDecoder, DEFAULT_ARGS, PAD, BOS, EOS, UNK
+    from types import SimpleNamespace
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    a = SimpleNamespace(**{**DEFAULT_ARGS, "max_transition_length": TRmax, "decoder_embed_dim": heads_dim, "decoder_layers": 0})
+    dec = DAGDecoder(a).to(dev).train()
+    B, L = 3, 70
+    lens = [70, 51, 2]
+    prev = torch.full((B, L), PAD, dtype=torch.long, device=dev)
+    for b, n in enumerate(lens):
+        prev[b, :n] = UNK; prev[b, 0] = BOS; prev[b, n - 1] = EOS
+    feats0 = torch.randn(B, L, a.decoder_embed_dim, device=dev)
+    wgt = None
+    res = {}
+    for fused in (True, False):
+        dec.fused_links = fused
+        dec.zero_grad(set_to_none=True)
+        feats = feats0.clone().requires_grad_()
+        links = dec.extract_links(feats, prev)
+        if wgt is None:
+            wgt = torch.randn_like(links)
+        fin = torch.isfinite(links)
+        loss = (links.masked_fill(~fin, 0.0) * wgt).sum() + 0.3 * torch.logsumexp(links.masked_fill(~fin, -1e4), -1).sum()
+        loss.backward()
+        res[fused] = (links.detach(), feats.grad.detach(), {n: p.grad.detach().clone() for n, p in dec.named_parameters() if p.grad is not None})
+    (l1, g1, p1), (l0, g0, p0) = res[True], res[False]
+    assert torch.equal(torch.isneginf(l1), torch.isneginf(l0))
+    f = torch.isfinite(l0)
+    torch.testing.assert_close(l1[f], l0[f], rtol=1e-5, atol=2e-5)
+    scale = max(1.0, float(g0.abs().max()))
+    assert float((g1 - g0).abs().max()) <= 1e-5 * scale + 2e-5, float((g1 - g0).abs().max())
+    assert set(p1) == set(p0) and {"query_linear.weight", "key_linear.weight", "gate_linear.weight"} <= set(p1)
+    for n in p0:
+        sc = max(1.0, float(p0[n].abs().max()))
+        assert float((p1[n] - p0[n]).abs().max()) <= 2e-5 * sc + 2e-5, (n, float((p1[n] - p0[n]).abs().max()), sc)
+
+
+@pytest.mark.gpu
+def test_fused_extract_links_backward_direct_q_k_gates():
+    """The autograd function itself: gradients w.r.t. q, k, log_gates against autograd through the torch band formulation (<= 1e-5)."""
+    from daspeech_amd import decode_ops
+    torch.manual_seed(2)
+    B, L, H, CK, TR = 2, 45, 8, 64, 44
+    olen = torch.tensor([45, 30], device="cuda")
+    q0 = torch.randn(B, L, H, CK, device="cuda") * 0.5; k0 = torch.randn(B, L, H, CK, device="cuda") * 0.5
+    g0 = torch.log_softmax(torch.randn(B, L, H, device="cuda"), -1)
+
+    def torch_links(q, k, lg):
+        content = torch.einsum("bicf,bjcf->bijc", q, k) / (CK ** 0.5)
+        idx = torch.arange(L, device="cuda").unsqueeze(1) + torch.arange(TR, device="cuda").unsqueeze(0) + 1
+        invalid = idx.unsqueeze(0) >= olen.view(B, 1, 1)
+        band = content.gather(2, idx.unsqueeze(0).masked_fill(invalid, 0).unsqueeze(-1).expand(-1, -1, -1, H))
+        nouse = invalid.all(-1)
+        band = band.masked_fill(invalid.unsqueeze(-1), float("-inf")).masked_fill(nouse.view(B, L, 1, 1), 0.0)
+        band = torch.log_softmax(band, 2).masked_fill(invalid.unsqueeze(-1), -1e30)
+        out = torch.logsumexp(band + lg.unsqueeze(2), -1)
+        return out.masked_fill(invalid, float("-inf"))
+
+    w = torch.randn(B, L, TR, device="cuda")
+    grads = []
+    for fn in (lambda q, k, lg: decode_ops.extract_links_autograd(q, k, lg, olen, TR), torch_links):
+        q, k, lg = q0.clone().requires_grad_(), k0.clone().requires_grad_(), g0.clone().requires_grad_()
+        links = fn(q, k, lg)
+        fin = torch.isfinite(links)
+        (links.masked_fill(~fin, 0.0) * w).sum().backward()
+        grads.append((links.detach(), q.grad, k.grad, lg.grad))
+    (la, qa, ka, ga), (lb, qb, kb, gb) = grads
+    f = torch.isfinite(lb)
+    torch.testing.assert_close(la[f], lb[f], rtol=1e-5, atol=2e-5)
+    for x, y, n in ((qa, qb, "q"), (ka, kb, "k"), (ga, gb, "log_gates")):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), (n, float((x - y).abs().max()))
+
+
 @pytest.mark.parametrize("joint", [True, False])
 @pytest.mark.parametrize("shape", [(3, 40, 6), (4, 96, 95), (2, 260, 259), (5, 128, 32), (2, 1000, 999)])
 def test_viterbi_decode_hip_matches_reference_loop_restatement(shape, joint):
