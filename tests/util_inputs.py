@@ -48,3 +48,45 @@ def seeded_weights(shapes, seed, gain=1.0):
             v = 0.05 * n
         out[name] = v.astype(np.float32)
     return out
+
+
+def seeded_model_state(shapes, seed):
+    """`seeded_weights` for a WHOLE S2ST model (reference parameter names), post-processed by name so that random weights decode a
+    non-degenerate graph and speak for a few frames per token — applied identically by the golden generator (to the reference model)
+    and by the tests (to the product model):
+      * BatchNorm running_var -> 1 + 0.1 |n| (a variance), num_batches_tracked untouched;
+      * the decoder's residual branches (self_attn / encoder_attn out_proj, fc2) x 0.1 and its learned positions x 40: vertex features
+        then follow the vertex POSITION, not a common mode, so neighbouring vertices emit different tokens;
+      * the four special-token embeddings x 0.05: with tied input / output embeddings the all-<unk> graph skeleton would otherwise
+        score <unk> highest everywhere;
+      * link positions x 20; duration predictor: proj.weight x 0.05, proj.bias = ln 4.5 (3-4 mel frames per token)."""
+    fl = {k: v for k, v in shapes.items() if not k.endswith(("num_batches_tracked", "_float_tensor", ".version"))}
+    w = seeded_weights(fl, seed, gain=1.0)
+    for k in list(w):
+        if k.endswith("running_var"):
+            w[k] = (1.0 + 0.1 * np.abs(w[k] / 0.05)).astype(np.float32)
+        if k.startswith("decoder.layers.") and k.endswith(("self_attn.out_proj.weight", "encoder_attn.out_proj.weight", "fc2.weight")):
+            w[k] = w[k] * np.float32(0.1)
+    if "decoder.embed_positions.weight" in w:
+        w["decoder.embed_positions.weight"] = w["decoder.embed_positions.weight"] * np.float32(40.0)
+    if "decoder.embed_tokens.weight" in w:
+        w["decoder.embed_tokens.weight"][:4] *= np.float32(0.05)
+    if "decoder.link_positional.weight" in w:
+        w["decoder.link_positional.weight"] = w["decoder.link_positional.weight"] * np.float32(20.0)
+    dp = "tts.var_adaptor.duration_predictor.proj."
+    if dp + "weight" in w:
+        w[dp + "weight"] = w[dp + "weight"] * np.float32(0.05)
+        w[dp + "bias"] = np.full_like(w[dp + "bias"], np.log(4.5))
+    if "decoder.output_projection.weight" in fl and "decoder.embed_tokens.weight" in w:       # tied (--share-decoder-input-output-embed)
+        w["decoder.output_projection.weight"] = w["decoder.embed_tokens.weight"]
+    return w
+
+
+def seeded_fbank(seed, frames):
+    """[B, max(frames), 80] float32 synthetic filter-bank batch, zero padded, from a seed (golden generator and tests)."""
+    rng = np.random.default_rng(seed)
+    B, F = len(frames), int(max(frames))
+    x = rng.standard_normal((B, F, 80)).astype(np.float32)
+    for b, n in enumerate(frames):
+        x[b, int(n):] = 0
+    return x
