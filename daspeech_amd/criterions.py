@@ -209,11 +209,15 @@ class NATDAGLoss:
             return None
         return {"context_p": max(self.glat_p, 0), "require_glance_grad": False}
 
+    # `glat_draws` = {"noise": ..., "unif": ..., "unif_n": ...} replays the glancing's random draws (parity tests against the reference's
+    # recorded draws); None = drawn on the device
+    glat_draws = None
+
     def _glat_function(self):
         def fn(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=None):
             return glat_function(model, word_ins_out, tgt_tokens, prev_output_tokens, glat, links=links,
                                  glance_strategy=self.glance_strategy, torch_gather=bool(self.cfg.torch_dag_logsoftmax_gather),
-                                 torch_align=bool(self.cfg.torch_dag_best_alignment))
+                                 torch_align=bool(self.cfg.torch_dag_best_alignment), **(self.glat_draws or {}))
         return fn
 
     # ---- nat_dag_loss.py:164-300

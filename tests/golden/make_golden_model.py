@@ -133,6 +133,62 @@ def main():
         store[f"mel{b}"] = o["feature"].numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "s2st_reference_e2e.npz"), **store)
     print("tokens per utterance", [int((t != d.pad()).sum()) for t in dec.output_tokens], "mel frames", [o["feature"].shape[0] for o in out], "token margin", tok_margin)
+    criterion_golden(model, d, ui)
+
+
+def criterion_golden(model, d, ui):
+    """nat_dag_loss_reference.npz: the reference's NATDAGLoss.forward (DASpeech/criterions/nat_dag_loss.py:164-300) — GLAT two-pass forward
+    with number-random glancing at p = 0.5, force-emit, torch DAG ops (its own --torch-dag-* CPU path) — and loss.backward() through the
+    whole reference model (eval mode: no dropout draws), for the seeded weights above.  The two random draws of the glancing are replayed
+    from the seed in the reference's order (randn(B, L) then rand(B, L); nothing else draws in eval mode) and stored."""
+    import torch
+    from DASpeech.criterions.nat_dag_loss import NATDAGLoss
+    frames = (300, 236)
+    src = torch.from_numpy(ui.seeded_fbank(SEED + 7, frames)); lens = torch.tensor(frames)
+    rng = np.random.default_rng(SEED + 8)
+    tl = (17, 12)
+    T = max(tl) + 2
+    tgt = np.full((len(frames), T), d.pad(), np.int64)
+    for b, n in enumerate(tl):
+        tgt[b, 0] = d.bos(); tgt[b, 1:n + 1] = rng.integers(4, len(d), n); tgt[b, n + 1] = d.eos()
+    cfg = types.SimpleNamespace(label_smoothing=0, glat_p="0.5", glance_strategy="number-random", no_force_emit=False,
+                                torch_dag_logsoftmax_gather=True, torch_dag_best_alignment=True, torch_dag_loss=True)
+    crit = NATDAGLoss(cfg, types.SimpleNamespace(tgt_dict=d, target_dictionary=d))
+    model.eval()
+    model.zero_grad(set_to_none=True)
+    captured = {}
+    fwd = model.forward
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        captured.update({k2: v for k2, v in out.items() if k2 in ("keep_word_mask", "glat_accu", "glat_keep")})
+        return out
+    model.forward = spy
+    sample = {"net_input": {"src_tokens": src, "src_lengths": lens}, "target": torch.from_numpy(tgt), "update_num": 10}
+    draw_seed = 4242
+    torch.manual_seed(draw_seed)
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    model.forward = fwd
+    L = int(max(frames) * 0.5)
+    torch.manual_seed(draw_seed)
+    noise = torch.randn(len(frames), L); unif = torch.rand(len(frames), L)
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    pick = ["decoder.gate_linear.weight", "decoder.query_linear.bias", "decoder.key_linear.bias", "encoder.linear.bias", "decoder.layers.3.fc2.bias",
+            "encoder.conformer_layers.11.final_layer_norm.weight", "decoder.embed_positions.weight"]
+    store = {"frames": np.array(frames), "target": tgt, "draw_seed": np.int64(draw_seed), "noise": noise.numpy(), "unif": unif.numpy(),
+             "loss": np.float64(float(loss)), "keep_word_mask": captured["keep_word_mask"].numpy(), "glat_accu": np.float32(float(captured["glat_accu"])),
+             "glat_keep": np.float32(float(captured["glat_keep"])), "n_grads": np.int64(len(grads))}
+    for k in ("ntokens", "nvalidtokens", "nsentences", "invalid_nsentences"):
+        store["log_" + k] = np.int64(int(log[k]))
+    store["log_dag_nll_loss"] = np.float64(float(log["dag_nll-loss"]))
+    for k in pick:
+        g = grads[k]
+        store["grad:" + k] = (g if g.numel() <= 4096 else g.reshape(-1)[:4096]).numpy().astype(np.float32)
+        store["gradnorm:" + k] = np.float64(float(g.double().norm()))
+    store["grad_total_norm"] = np.float64(float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values()))))
+    np.savez_compressed(os.path.join(HERE, "nat_dag_loss_reference.npz"), **store)
+    print("criterion: loss", float(loss), "glanced", captured["keep_word_mask"].sum(1).tolist(), "grads", len(grads), "total norm", float(store["grad_total_norm"]))
 
 
 if __name__ == "__main__":

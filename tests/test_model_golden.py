@@ -102,3 +102,60 @@ def test_s2st_end_to_end_vs_reference_generator():
         assert mel.shape == mel_ref.shape, (b, mel.shape, mel_ref.shape)
         scale = np.abs(mel_ref).max()
         assert np.abs(mel - mel_ref).max() <= 1e-4 * scale + 1e-5, (b, np.abs(mel - mel_ref).max(), scale)
+
+
+def _seeded_product_model(man, seed):
+    m = _product_model(man)
+    shapes = {k: tuple(v["shape"]) for k, v in man["keys"].items() if v["dtype"].startswith("float")}
+    sd = {k: torch.from_numpy(v) for k, v in seeded_model_state(shapes, seed).items()}
+    for k, meta in man["keys"].items():
+        if k not in sd:
+            sd[k] = torch.zeros(tuple(meta["shape"]), dtype=torch.float32 if meta["dtype"].startswith("float") else torch.long)
+    m.load_reference_state_dict({"model": sd}, strict=True)
+    return m
+
+
+@pytest.mark.gpu
+def test_nat_dag_loss_criterion_vs_reference_forward_and_backward():
+    """criterions.NATDAGLoss on the HIP ops (GLAT two-pass forward, number-random glancing at p = 0.5 with the reference's recorded draws,
+    force-emit, dag_loss) against the REFERENCE's NATDAGLoss.forward + loss.backward() through its whole model (its --torch-dag-* CPU
+    path): the glanced positions, the loss, the logging counts and the gradients reaching encoder, decoder and the links head."""
+    from daspeech_amd.criterions import NATDAGLoss
+    man = _manifest()
+    g = dict(np.load(os.path.join(GOLDEN, "nat_dag_loss_reference.npz")))
+    e2e = dict(np.load(os.path.join(GOLDEN, "s2st_reference_e2e.npz")))
+    m = _seeded_product_model(man, int(e2e["seed"])).cuda().eval()
+    frames = [int(x) for x in g["frames"]]
+    src = torch.from_numpy(seeded_fbank(int(e2e["seed"]) + 7, frames)).cuda()
+    sample = {"net_input": {"src_tokens": src, "src_lengths": torch.tensor(frames, device="cuda")}, "target": torch.from_numpy(g["target"]).cuda(),
+              "update_num": 10}
+    crit = NATDAGLoss(glat_p="0.5", glance_strategy="number-random")
+    crit.glat_draws = {"noise": torch.from_numpy(g["noise"]).cuda(), "unif": torch.from_numpy(g["unif"]).cuda()}
+    captured = {}
+    fwd = m.forward
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        captured.update({k2: v for k2, v in out.items() if k2 in ("keep_word_mask", "glat_accu", "glat_keep")})
+        return out
+    m.forward = spy
+    loss, sample_size, log = crit(m, sample)
+    loss.backward()
+    assert np.array_equal(captured["keep_word_mask"].cpu().numpy(), g["keep_word_mask"])
+    assert float(captured["glat_accu"]) == pytest.approx(float(g["glat_accu"]), rel=1e-6)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-5)
+    assert float(log["dag_nll-loss"]) == pytest.approx(float(g["log_dag_nll_loss"]), rel=2e-5)
+    for k in ("ntokens", "nvalidtokens", "nsentences", "invalid_nsentences"):
+        assert int(log[k]) == int(g["log_" + k]), k
+    assert sample_size == 1
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert len(grads) == int(g["n_grads"])
+    total = float(torch.sqrt(sum(x.double().pow(2).sum() for x in grads.values())))
+    assert total == pytest.approx(float(g["grad_total_norm"]), rel=2e-4)
+    for key in [k[5:] for k in g if k.startswith("grad:")]:
+        ref = g["grad:" + key]
+        got = grads[key].detach().float().cpu().numpy().reshape(-1)[: ref.size].reshape(ref.shape)
+        norm = float(g["gradnorm:" + key])
+        # (decoder.key_linear.bias has a mathematically ZERO gradient — a key bias shifts every score of a soft-max row alike — so both
+        #  sides hold rounding noise of ~1e-9 there: the absolute floor is tied to the whole gradient's norm)
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7 * total, (key, np.abs(got - ref).max(), np.abs(ref).max(), norm)
