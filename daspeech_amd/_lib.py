@@ -48,6 +48,8 @@ SIGNATURES = {
     "dsp_extract_links_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        ctypes.c_float, _c_p]),
     "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_posterior_features": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_posterior_features_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_durations": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_i64, _c_p]),
     "dsp_bucketize_embed_add": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_i64, _c_int, _c_p]),
     "dsp_length_regulator_lens": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),

@@ -308,8 +308,8 @@ class S2SDAGFastSpeech2Loss(NATDAGLoss):
             input_to_tts = model.adaptor(features_on_path)
         else:
             # expect: z_i = sum_j P(a_i = j | x, y) v_j   (:252-265)
-            score = decode_ops.posterior(alpha, beta).to(features.dtype)
-            input_to_tts = model.adaptor(torch.matmul(score, features)[:, 1:, :])
+            # (fused: the [B,T,L] posterior never exists; gradient to the features through dsp_posterior_features_bwd)
+            input_to_tts = model.adaptor(decode_ops.posterior_features(alpha, beta, features)[:, 1:, :])
             features_padding_mask = ~_lengths_to_mask(sample["target_text_lengths"] - 1, input_to_tts.shape[1])
         _feat_out, _, log_dur_out, pitch_out, energy_out = model.tts(
             input_to_tts, features_padding_mask, durations=sample["durations"], pitches=sample["pitches"], energies=sample["energies"])

@@ -188,6 +188,90 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- F1 fused: expected hidden states without the [B,T,L] score tensor
+//   out[b,t,:] = sum_j softmax_j(alpha + beta)[b,t,j] * features[b,j,:]            (s2s_dag_fastspeech2_loss.py:259-262)
+// One workgroup per (sample, PF_TT target rows): the rows' posteriors are built in LDS (log-sum-exp per row by one wave each), then
+// every thread owns feature columns and walks the L vertices once for all PF_TT rows (the feature row is read once per workgroup,
+// the posterior is an LDS broadcast).  `lse` [B,T] is kept for the backward.  Rows without a finite entry give 0 (the NaN -> 0).
+constexpr int PF_TT = 8;
+__global__ __launch_bounds__(256) void posterior_features_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                                 const float* __restrict__ feats, float* __restrict__ out,
+                                                                 float* __restrict__ lse_out, int T, int L, int D)
+{
+    extern __shared__ float pf_smem[];                     // [PF_TT][L]
+    const int b = blockIdx.y, t0 = blockIdx.x * PF_TT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int tt = wave; tt < PF_TT; tt += 4) {
+        const int t = t0 + tt;
+        float* pr = pf_smem + (size_t)tt * L;
+        if (t >= T) { for (int j = lane; j < L; j += 64) pr[j] = 0.f; continue; }
+        const float* a = alpha + ((size_t)b * T + t) * L; const float* bb = beta + ((size_t)b * T + t) * L;
+        float m = NEG_INF;
+        for (int j = lane; j < L; j += 64) m = fmaxf(m, a[j] + bb[j]);
+        m = wave_max(m);
+        float lse = NEG_INF;
+        if (m > NEG_INF && !isinf(m)) {
+            float sum = 0.f;
+            for (int j = lane; j < L; j += 64) sum += __expf(a[j] + bb[j] - m);
+            sum = wave_sum(sum);
+            lse = m + __logf(sum);
+        }
+        for (int j = lane; j < L; j += 64) pr[j] = (lse == NEG_INF) ? 0.f : __expf(a[j] + bb[j] - lse);
+        if (lane == 0 && lse_out) lse_out[(size_t)b * T + t] = lse;
+    }
+    __syncthreads();
+    const float* F = feats + (size_t)b * L * D;
+    for (int d = 2 * tid; d < D; d += 512) {
+        float2 acc[PF_TT];
+#pragma unroll
+        for (int tt = 0; tt < PF_TT; ++tt) acc[tt] = make_float2(0.f, 0.f);
+        for (int j = 0; j < L; ++j) {
+            const float2 f = *reinterpret_cast<const float2*>(F + (size_t)j * D + d);
+#pragma unroll
+            for (int tt = 0; tt < PF_TT; ++tt) { const float pv = pf_smem[(size_t)tt * L + j]; acc[tt].x = fmaf(pv, f.x, acc[tt].x); acc[tt].y = fmaf(pv, f.y, acc[tt].y); }
+        }
+#pragma unroll
+        for (int tt = 0; tt < PF_TT; ++tt)
+            if (t0 + tt < T) *reinterpret_cast<float2*>(out + ((size_t)b * T + t0 + tt) * D + d) = acc[tt];
+    }
+}
+
+// backward wrt the features:  dF[b,j,:] = sum_t posterior[b,t,j] * dOut[b,t,:]  — a workgroup owns PF_TT vertices, rebuilds their
+// posterior columns from alpha, beta and the saved row log-sum-exps, and walks the T rows of dOut once
+__global__ __launch_bounds__(256) void posterior_features_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                                     const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                     float* __restrict__ dfeats, int T, int L, int D)
+{
+    extern __shared__ float pf_smem[];                     // [T][PF_TT]
+    const int b = blockIdx.y, j0 = blockIdx.x * PF_TT;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < T * PF_TT; e += 256) {
+        const int t = e / PF_TT, jj = e - t * PF_TT, j = j0 + jj;
+        float pv = 0.f;
+        if (j < L) {
+            const float ls = lse[(size_t)b * T + t];
+            const size_t o = ((size_t)b * T + t) * L + j;
+            if (ls != NEG_INF) pv = __expf(alpha[o] + beta[o] - ls);
+        }
+        pf_smem[e] = pv;
+    }
+    __syncthreads();
+    const float* G = dout + (size_t)b * T * D;
+    for (int d = 2 * tid; d < D; d += 512) {
+        float2 acc[PF_TT];
+#pragma unroll
+        for (int jj = 0; jj < PF_TT; ++jj) acc[jj] = make_float2(0.f, 0.f);
+        for (int t = 0; t < T; ++t) {
+            const float2 g = *reinterpret_cast<const float2*>(G + (size_t)t * D + d);
+#pragma unroll
+            for (int jj = 0; jj < PF_TT; ++jj) { const float pv = pf_smem[t * PF_TT + jj]; acc[jj].x = fmaf(pv, g.x, acc[jj].x); acc[jj].y = fmaf(pv, g.y, acc[jj].y); }
+        }
+#pragma unroll
+        for (int jj = 0; jj < PF_TT; ++jj)
+            if (j0 + jj < L) *reinterpret_cast<float2*>(dfeats + ((size_t)b * L + j0 + jj) * D + d) = acc[jj];
+    }
+}
+
 // ---------------------------------------------------------------- F6
 __global__ void durations_kernel(const float* __restrict__ log_dur, const uint8_t* __restrict__ pad, float factor,
                                  int64_t* __restrict__ dur, long n)
@@ -333,6 +417,32 @@ extern "C" int dsp_gather_rows(const void* features, int dtype, const int32_t* k
     hipLaunchKernelGGL(gather_rows_kernel, dim3(Fmax, B), dim3(64), 0, as_stream(stream), (const char*)features, keep_idx, n_feat,
                        (char*)out, L, (long)D * es, cap, Fmax);
     return check_launch("gather_rows");
+}
+
+extern "C" int dsp_posterior_features(const float* alpha, const float* beta, const float* features, float* out, float* lse,
+                                      int B, int T, int L, int D, dsp_stream_t stream)
+{
+    if (B < 0 || T < 1 || L < 1 || D < 2 || (D & 1)) { set_error("posterior_features: bad sizes (D must be even)"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!alpha || !beta || !features || !out) { set_error("posterior_features: null pointer"); return DSP_EINVAL; }
+    const size_t lds = (size_t)PF_TT * L * sizeof(float);
+    if (lds > 150 * 1024) { set_error("posterior_features: L=%d too large for the posterior rows in LDS", L); return DSP_EINVAL; }
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(posterior_features_kernel, dim3((T + PF_TT - 1) / PF_TT, B), dim3(256), lds, as_stream(stream), alpha, beta, features, out, lse, T, L, D);
+    return check_launch("posterior_features");
+}
+
+extern "C" int dsp_posterior_features_bwd(const float* alpha, const float* beta, const float* lse, const float* grad_out, float* grad_features,
+                                          int B, int T, int L, int D, dsp_stream_t stream)
+{
+    if (B < 0 || T < 1 || L < 1 || D < 2 || (D & 1)) { set_error("posterior_features_bwd: bad sizes (D must be even)"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!alpha || !beta || !lse || !grad_out || !grad_features) { set_error("posterior_features_bwd: null pointer"); return DSP_EINVAL; }
+    const size_t lds = (size_t)PF_TT * T * sizeof(float);
+    if (lds > 150 * 1024) { set_error("posterior_features_bwd: T=%d too large for the posterior columns in LDS", T); return DSP_EINVAL; }
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_features_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(posterior_features_bwd_kernel, dim3((L + PF_TT - 1) / PF_TT, B), dim3(256), lds, as_stream(stream), alpha, beta, lse, grad_out, grad_features, T, L, D);
+    return check_launch("posterior_features_bwd");
 }
 
 extern "C" int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream)

@@ -169,11 +169,54 @@ def posterior(alpha: Tensor, beta: Tensor) -> Tensor:
     return score
 
 
+class _PosteriorFeaturesFn(torch.autograd.Function):
+    """score @ features with the row soft-max of alpha + beta fused in (no [B,T,L] score tensor in either direction); gradient w.r.t.
+    the features only — alpha / beta are detached, as the reference's are (dag_loss.py:180-186)."""
+
+    @staticmethod
+    def forward(ctx, alpha, beta, features):
+        a = alpha.detach().to(torch.float32).contiguous()
+        b = beta.detach().to(torch.float32).contiguous()
+        f = features.detach().to(torch.float32).contiguous()
+        B, T, L = a.shape
+        D = f.shape[2]
+        lib = _lib.load()
+        with torch.cuda.device(a.device):
+            out = torch.empty((B, T, D), dtype=torch.float32, device=a.device)
+            lse = torch.empty((B, T), dtype=torch.float32, device=a.device)
+            _lib.check(lib.dsp_posterior_features(_lib.ptr(a), _lib.ptr(b), _lib.ptr(f), _lib.ptr(out), _lib.ptr(lse), B, T, L, D,
+                                                  _lib.current_stream_handle()), "dsp_posterior_features")
+        ctx.save_for_backward(a, b, lse)
+        ctx.fdtype, ctx.L = features.dtype, L
+        return out.to(features.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a, b, lse = ctx.saved_tensors
+        B, T, L = a.shape
+        g = grad_out.detach().to(torch.float32).contiguous()
+        D = g.shape[2]
+        lib = _lib.load()
+        with torch.cuda.device(a.device):
+            df = torch.empty((B, L, D), dtype=torch.float32, device=a.device)
+            _lib.check(lib.dsp_posterior_features_bwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(df), B, T, L, D,
+                                                      _lib.current_stream_handle()), "dsp_posterior_features_bwd")
+        return None, None, df.to(ctx.fdtype)
+
+
+def posterior_features(alpha: Tensor, beta: Tensor, features: Tensor) -> Tensor:
+    """[B,T,D] = softmax_j(alpha + beta) @ features, fused (dsp_posterior_features): the posterior never exists in HBM; differentiable
+    w.r.t. `features`.  Falls back to the two-step form when the shape does not fit the kernel (odd D, rows beyond LDS)."""
+    _gpu("posterior_features", alpha, beta, features)
+    B, T, L = alpha.shape
+    if features.shape[2] % 2 or 8 * max(L, T) * 4 > 150 * 1024:
+        return torch.matmul(posterior(alpha, beta).to(features.dtype), features)
+    return _PosteriorFeaturesFn.apply(alpha, beta, features)
+
+
 def expect_features(alpha: Tensor, beta: Tensor, features: Tensor) -> Tensor:
-    """Expected hidden states of the "expect" strategy: (score @ features)[:, 1:]   (:259-263).  The posterior is a HIP
-    kernel; the [T x L] x [L x D] product is a library MFMA GEMM (hipBLASLt through torch.matmul)."""
-    score = posterior(alpha, beta).to(features.dtype)
-    return torch.matmul(score, features)[:, 1:, :]
+    """Expected hidden states of the "expect" strategy: (score @ features)[:, 1:]   (:259-263), fused: see posterior_features."""
+    return posterior_features(alpha, beta, features)[:, 1:, :]
 
 
 def predicted_durations(log_dur: Tensor, padding_mask: Tensor, d_factor: float = 1.0) -> Tensor:

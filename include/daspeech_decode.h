@@ -63,6 +63,14 @@ int dsp_extract_links_bwd(const float* q, const float* k, const float* log_gates
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */
 int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream);
+/* F1 fused with its consumer (:259-262): out[b,t,:] = sum_j score[b,t,j] * features[b,j,:] without the [B,T,L] score tensor.
+ *   features [B,L,D], out [B,T,D] fp32 (D even), lse [B,T] (row log-sum-exp of alpha+beta; -inf for rows without a finite entry,
+ *   whose output is 0) or NULL.  dsp_posterior_features_bwd: grad_features[b,j,:] = sum_t score[b,t,j] * grad_out[b,t,:], the
+ *   score rebuilt from alpha, beta and lse (alpha / beta carry no gradient: the reference detaches them, dag_loss.py:180-186). */
+int dsp_posterior_features(const float* alpha, const float* beta, const float* features, float* out, float* lse,
+                           int B, int T, int L, int D, dsp_stream_t stream);
+int dsp_posterior_features_bwd(const float* alpha, const float* beta, const float* lse, const float* grad_out, float* grad_features,
+                               int B, int T, int L, int D, dsp_stream_t stream);
 
 /* F6a  predicted durations                                                     (fastspeech2.py:202-205)
  *   dur = clamp(round((exp(log_dur) - 1) * factor), 0) as int64, 0 where pad_mask != 0 (uint8/bool). */

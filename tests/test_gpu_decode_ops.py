@@ -100,6 +100,28 @@ def test_posterior_and_expect():
     np.testing.assert_allclose(ex.cpu().numpy(), ex_ref[:, 1:], rtol=1e-3, atol=1e-4)
 
 
+def test_posterior_features_fused_forward_and_backward():
+    """dsp_posterior_features / _bwd (no [B,T,L] score tensor) vs the oracle's posterior + matmul and torch autograd of the two-step form:
+    ragged lengths (rows past T_b are all -inf -> zero output rows), a feature width that needs two passes, gradient to the features."""
+    B, T, L, TR, Dm = 3, 21, 70, 16, 640
+    match, links, ol, tl = make_dag_inputs(23, B, T, L, TR)
+    a = orc.dag_alpha(match, links, ol, tl, np.float32)
+    b = orc.dag_beta(match, links, ol, tl, np.float32)
+    feats = np.random.default_rng(1).standard_normal((B, L, Dm)).astype(np.float32)
+    _, ex_ref = orc.posterior_expect(a, b, feats)
+    ta, tb = torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev())
+    f1 = torch.from_numpy(feats).to(dev()).requires_grad_()
+    out = D().posterior_features(ta, tb, f1)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ex_ref, rtol=1e-4, atol=1e-5)
+    for bb in range(B):
+        assert np.all(out[bb, tl[bb]:].detach().cpu().numpy() == 0)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    f2 = torch.from_numpy(feats).to(dev()).requires_grad_()
+    (torch.matmul(D().posterior(ta, tb), f2) * w).sum().backward()
+    torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_durations_and_bucketize():
     rng = np.random.default_rng(1)
     ld = (rng.standard_normal((4, 37)) * 1.2 + 1.0).astype(np.float32)
