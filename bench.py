@@ -66,7 +66,8 @@ def parse():
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                     help="autocast dtype of the dense Conformer / Transformer / FastSpeech2 layers (default fp32, the mode the mel parity is stated for)")
     ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"])
-    ap.add_argument("--vocoder-group", type=int, default=8, help="s2st: utterances per vocoder call (length-sorted groups)")
+    ap.add_argument("--vocoder-group", type=int, default=None,
+                    help="s2st: utterances per vocoder call (length-sorted groups; default: the whole batch for the fp32 vocoder, 8 for hip_fp16)")
     ap.add_argument("--no-overlap", action="store_true", help="s2st: one batch at a time (generator.generate) instead of the two-deep batch pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
@@ -77,6 +78,15 @@ def parse():
     if args.batch is None:
         args.batch = 64 if args.workload == "s2tt" else 32
     return args
+
+
+def vocoder_group(args):
+    """Utterances per vocoder call.  The kernels skip every tile past an utterance's own length, so a padded group costs the sum of its
+    lengths; the fp32 vocoder's launches are long enough that one call per batch is fastest (r03: 36.5 vs 38.3 ms per batch of 32), the
+    fp16-storage one keeps the groups of 8 its two-deep pipeline was tuned with."""
+    if args.vocoder_group is not None:
+        return args.vocoder_group
+    return 8 if args.vocoder_backend == "hip_fp16" else args.batch
 
 
 # ======================================================================================================================
@@ -409,7 +419,7 @@ def build_model_step(ctx, args, workload):
     elif workload == "s2st":
         model.eval()
         voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
-        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=args.vocoder_group)
+        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=vocoder_group(args))
         state["voc"] = voc
 
         def count(out):
@@ -430,7 +440,7 @@ def build_model_step(ctx, args, workload):
             state["flush"] = lambda: count(gen.flush())
         wl = (f"C4 full S2ST pipeline (s2s_conformer_dag_fastspeech2 + HiFi-GAN V1), {args.decode_strategy} decode: Conformer(12L,256) -> "
               f"DA-Transformer(4L,512) + links -> HIP graph decode -> FFN adapter -> FastSpeech2-NoEmb (HIP variance-adaptor glue + length regulator) "
-              f"-> HiFi-GAN V1 (vocoder arithmetic: {VOCODER_ARITH[args.vocoder_backend]}; groups of {args.vocoder_group} with per-utterance lengths"
+              f"-> HiFi-GAN V1 (vocoder arithmetic: {VOCODER_ARITH[args.vocoder_backend]}; groups of {vocoder_group(args)} with per-utterance lengths"
               + ("" if args.no_overlap else "; vocoder of batch i-1 on a second stream under the acoustic model of batch i") + f"), B={B}/GPU, fbank80 300-800 frames, {prec}")
     else:
         model.train()
@@ -465,7 +475,8 @@ def vocoder_roofline(ctx, args, state):
     if voc is None or args.vocoder_backend not in ("hip", "hip_fp16"):
         return None
     Tm = max(8, int(round(state["mel_frames_per_utt"])))
-    mel = torch.randn(args.vocoder_group, 80, Tm, device=ctx.dev)
+    vg = vocoder_group(args)
+    mel = torch.randn(vg, 80, Tm, device=ctx.dev)
     with torch.no_grad():
         for _ in range(2):
             voc(mel)
@@ -475,11 +486,11 @@ def vocoder_roofline(ctx, args, state):
             voc(mel)
         e1.record(); torch.cuda.synchronize()
     v_ms = e0.elapsed_time(e1) / 5
-    tf = 0.614e9 * args.vocoder_group * Tm / (v_ms * 1e-3) / 1e12
+    tf = 0.614e9 * vg * Tm / (v_ms * 1e-3) / 1e12
     f32 = args.vocoder_backend == "hip"
     kern = ("hifigan_conv_f32 kernels: three fp16 MFMAs per fragment pair, so `achieved` counts the convolution's FLOPs and the matrix cores issue 3x that"
             if f32 else "hifigan_conv / hifigan_resunit kernels")
-    return {"bound": "mfma", "kernel": f"HiFi-GAN V1 generator conv stack ({kern}), one call of {args.vocoder_group} x {Tm} frames",
+    return {"bound": "mfma", "kernel": f"HiFi-GAN V1 generator conv stack ({kern}), one call of {vg} x {Tm} frames",
             "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None, "avg_call_ms": v_ms,
             **({"mfma_issue_factor": 3, "frac_of_issue_peak": 3 * tf / MFMA_F16_PEAK_TFLOPS} if f32 else {})}
 

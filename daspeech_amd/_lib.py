@@ -75,7 +75,8 @@ SIGNATURES = {
     "dsp_hifigan_pack_weights": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_pack_input": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
-    "dsp_hifigan_pack_weights_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_pack_weights_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_hifigan_resunit_f32_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "dsp_hifigan_conv_chain_f32": (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_int, _c_p]),
     "dsp_hifigan_pad_input_f32": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_post_f32": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p, _c_int, _c_p]),

@@ -53,29 +53,28 @@ def pack_weights(w_tap_major: Tensor) -> Tensor:
     return out
 
 
-def pack_weights_f32(w_tap_major: Tensor):
-    """[ntaps][M][CI] fp32 -> (hi, lo) fp16 fragment-order buffers of the split-precision kernels (dsp_hifigan_pack_weights_f32)."""
+def pack_weights_f32(w_tap_major: Tensor) -> Tensor:
+    """[ntaps][M][CI] fp32 -> ONE fp16 buffer [hi | lo] in fragment order for the split-precision kernels (dsp_hifigan_pack_weights_f32)."""
     lib = _lib.load()
     w = w_tap_major.contiguous().float()
     K, M, CI = w.shape
     n = lib.dsp_hifigan_packed_weight_elems(K, M, CI)
-    hi = torch.empty((n,), dtype=torch.float16, device=w.device)
-    lo = torch.empty((n,), dtype=torch.float16, device=w.device)
+    out = torch.empty((2 * n,), dtype=torch.float16, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(lib.dsp_hifigan_pack_weights_f32(_lib.ptr(w), _lib.ptr(hi), _lib.ptr(lo), K, M, CI, _lib.current_stream_handle()),
+        _lib.check(lib.dsp_hifigan_pack_weights_f32(_lib.ptr(w), _lib.ptr(out), K, M, CI, _lib.current_stream_handle()),
                    "dsp_hifigan_pack_weights_f32")
-    return hi, lo
+    return out
 
 
 class HiFiGANHipRunner:
     def __init__(self, gen, fuse_units: bool = True, precision: str = "fp16"):
         """fuse_units: run a ResBlock unit (conv, conv, residual) as ONE launch where dsp_hifigan_resunit supports its shape
         (C <= 128); False keeps the layer-at-a-time chain (same bits, 2.5x the activation traffic) for comparison.
-        precision: "fp16" (fp16 storage, fp32 accumulate) or "fp32" (the reference's arithmetic by operand splitting; layer-at-a-time)."""
+        precision: "fp16" (fp16 storage, fp32 accumulate) or "fp32" (the reference's arithmetic by operand splitting)."""
         assert precision in ("fp16", "fp32")
         self.precision = precision
         self.f32 = precision == "fp32"
-        self.fuse_units = fuse_units and not self.f32
+        self.fuse_units = fuse_units
         dev = next(gen.parameters()).device
         assert dev.type == "cuda", "HiFiGANHipRunner needs the generator on a GPU"
         self.dev = dev
@@ -96,7 +95,7 @@ class HiFiGANHipRunner:
 
     def _pack(self, L, w_tap_major: Tensor):
         if self.f32:
-            L.w, L.w_lo = pack_weights_f32(w_tap_major)
+            L.w, L.w_lo = pack_weights_f32(w_tap_major), None
         else:
             L.w, L.w_lo = pack_weights(w_tap_major.to(torch.float16)), None
 
@@ -152,9 +151,11 @@ class HiFiGANHipRunner:
         sizes, recs, free = [], [], []      # physical buffers (capacity in halves), layer records, released buffer ids
         lib = _lib.load()                   # records: (layer, x_buf, res_buf, out_buf, T, slope, mode, scale[, layer2])
 
+        supported = lib.dsp_hifigan_resunit_f32_supported if self.f32 else lib.dsp_hifigan_resunit_supported
+
         def fusable(c1, c2):
             return (self.fuse_units and c1.CI == c1.M == c2.CI == c2.M and c1.ntaps == c2.ntaps and c2.dil == 1
-                    and bool(lib.dsp_hifigan_resunit_supported(c1.CI, c1.ntaps, c1.dil)))
+                    and bool(supported(c1.CI, c1.ntaps, c1.dil)))
 
         # The launches run in order on one stream, so a buffer can be handed out again as soon as its last reader has been recorded:
         # 5 live buffers per stage (stage input, running MRF sum, two ping-pong unit outputs, the unfused chain's intermediate) instead of
@@ -219,7 +220,7 @@ class HiFiGANHipRunner:
         for d, rec in zip(table, recs):
             L, xb, rb, ob, tt, slope, mode, scale = rec[:8]
             L2 = rec[8] if len(rec) > 8 else None
-            d.w2 = L2.w.data_ptr() if L2 is not None else (L.w_lo.data_ptr() if self.f32 else None)      # fp32 chain: w2 = lo part of w
+            d.w2 = L2.w.data_ptr() if L2 is not None else None
             d.bias2 = L2.bias.data_ptr() if (L2 is not None and L2.bias is not None) else None
             d.x = base + esz * offs[xb]; d.res = (base + esz * offs[rb]) if rb is not None else None; d.out = base + esz * offs[ob]
             d.w = L.w.data_ptr(); d.bias = L.bias.data_ptr() if L.bias is not None else None

@@ -78,12 +78,16 @@ int dsp_hifigan_post_lens(const void* x, const float* w, float bias, float* wav,
 /* ---- the same generator at the REFERENCE's precision (fp32 activations and weights: hifi-gan/models.py:100-119 as run by
  * inference_e2e.py:47-56), still on the fp16 matrix cores: operands are split x = xh + xl/2048, w = wh + wl/2048 and the three
  * significant products accumulate in fp32 (csrc/hifigan_conv_f32.hip; result within 2^-22 relative of an fp32 convolution).
- *   dsp_hifigan_pack_weights_f32   fp32 tap-major [ntaps][M][CI] -> w_hi, w_lo (dsp_hifigan_packed_weight_elems halves each)
- *   dsp_hifigan_conv_chain_f32     a dsp_hg_layer table as above with x / res / out FP32 [B,T,C], w = w_hi and w2 = w_lo of the layer
- *                                  (no fused units); lens / T0 as dsp_hifigan_conv_chain_lens, lens may be NULL
+ *   dsp_hifigan_pack_weights_f32   fp32 tap-major [ntaps][M][CI] -> ONE buffer [hi | lo], 2 * dsp_hifigan_packed_weight_elems halves
+ *   dsp_hifigan_conv_chain_f32     a dsp_hg_layer table as above with x / res / out FP32 [B,T,C] and every weight pointer such a
+ *                                  [hi | lo] buffer; w2 != NULL marks a fused ResBlock unit exactly as in dsp_hifigan_conv_chain
+ *                                  (bit-identical to its two layers, the intermediate stays in LDS); lens / T0 as
+ *                                  dsp_hifigan_conv_chain_lens, lens may be NULL
+ *   dsp_hifigan_resunit_f32_supported   whether a (C, ntaps, dil) unit fits the fused kernel's LDS tiling
  *   dsp_hifigan_pad_input_f32      fp32 [B,T,C] -> fp32 [B,T,Cpad], zero padded channels
  *   dsp_hifigan_post_f32           conv_post + tanh on an fp32 activation tensor (lens may be NULL) */
-int dsp_hifigan_pack_weights_f32(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream);
+int dsp_hifigan_pack_weights_f32(const float* w_tap_major, void* w_hi_lo, int ntaps, int M, int CI, dsp_stream_t stream);
+int dsp_hifigan_resunit_f32_supported(int C, int ntaps, int dil);
 int dsp_hifigan_conv_chain_f32(const dsp_hg_layer* layers, int n_layers, int B, const int* lens, int T0, dsp_stream_t stream);
 int dsp_hifigan_pad_input_f32(const float* x, float* out, int B, int T, int C, int Cpad, dsp_stream_t stream);
 int dsp_hifigan_post_f32(const float* x, const float* w, float bias, float* wav, int B, int T, int C, int K, float slope,

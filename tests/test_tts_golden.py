@@ -303,10 +303,12 @@ def test_hifigan_fp32_mode_grouped_equals_per_utterance_and_tracks_torch_fp32():
         for p in gmod.parameters():
             p.copy_(torch.randn_like(p) / (p.shape[1] * p.shape[2]) ** 0.5 if p.dim() > 1 else torch.randn_like(p) * 0.05)
     run = HiFiGANHipRunner(gmod, precision="fp32")
+    chain = HiFiGANHipRunner(gmod, precision="fp32", fuse_units=False)
     lens = torch.tensor([61, 60, 33, 7, 1], device="cuda")
     mel = torch.randn(5, 80, 61, device="cuda")
     mel = mel.masked_fill(torch.arange(61, device="cuda").view(1, 1, -1) >= lens.view(-1, 1, 1), 0)
     batch = run(mel, lens)
+    assert torch.equal(batch, chain(mel, lens))            # fused ResBlock units (intermediate in LDS) == the layer-at-a-time chain, bit for bit
     with torch.no_grad():
         for b, n in enumerate(lens.tolist()):
             single = run(mel[b:b + 1, :, :n].contiguous())[0, 0]
