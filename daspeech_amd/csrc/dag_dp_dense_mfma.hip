@@ -716,6 +716,34 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                 if (!in_graph || !has_pred) a2 = NEG_INF;
                 if (BETA && (L - 1 - u) < row(tt)) { a2 = NEG_INF; flag = false; }          // K3 only visits columns j >= t (dag_loss.cu loop bounds)
                 if (__any(flag)) {
+                    // ---- second opinion on the row, still in exp space: every lane against ITS OWN reference.  The shared exponents above
+                    // (one per 8 columns, and a column's reference the largest of the groups up to its own) are set by a group's strongest
+                    // vertex; where the previous row climbs steeply — left of the band a trained model's emissions draw, 5 - 60 binades per
+                    // column — the few predecessors that make up a column's sum sit 100+ binades under the vertices to their right in the
+                    // same group and arrive as zeros.  Here lane u uses r_u = max(reference of the source blocks, ceil(max of the block's
+                    // exact previous row over v < u)): no term exceeds 1, the strongest predecessor is within a factor 2 of it, and the
+                    // weights are the register-resident ones.  64 v_exp + 64 FMA per lane, no memory access: about 1.5 fast rows, on the
+                    // rows that need it.  (r02 sent every such cell through the log-space redo below, a chain of gathers per predecessor:
+                    // C1 on such scores 89 ms un-budgeted, 7 - 9 ms after the hand-over to the stand-by kernels, against 1.4 ms.)
+                    {
+                        float pm = A2d[ul];
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(pm, o); pm = (lane >= o) ? fmaxf(pm, y) : pm; }
+                        pm = __shfl_up(pm, 1);
+                        if (lane == 0) pm = NEG_INF;
+                        const float rl = fmaxf(ro, (pm == NEG_INF) ? DM_SENT : ceilf(pm));
+                        float P2 = (ro == DM_SENT) ? 0.f : ldexpf(po, (int)fmaxf(ro - rl, -400.f));
+                        const v4f* a4 = reinterpret_cast<const v4f*>(A2d);
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const v4f a = a4[g];                                                // (v >= u: weight 0; the clamp keeps 2^(.) finite there)
+                            P2 = fmaf(dm_exp2(fminf(a.x - rl, 0.f)), Ec[2 * g].x, P2);
+                            P2 = fmaf(dm_exp2(fminf(a.y - rl, 0.f)), Ec[2 * g].y, P2);
+                            P2 = fmaf(dm_exp2(fminf(a.z - rl, 0.f)), Ec[2 * g + 1].x, P2);
+                            P2 = fmaf(dm_exp2(fminf(a.w - rl, 0.f)), Ec[2 * g + 1].y, P2);
+                        }
+                        if (flag && P2 >= 0x1p-90f && P2 <= 0x1p126f) { a2 = __builtin_amdgcn_logf(P2) + rl + m2; flag = false; }
+                    }
                     const u64 fm = __ballot(flag);
                     if (fm) {
                         // Exact log-space redo of ALL flagged columns of the row at once: the previous row is walked once, 64 columns per
