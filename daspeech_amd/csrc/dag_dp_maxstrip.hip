@@ -11,6 +11,8 @@
 //     reference's tie rule (smallest predecessor index; -1 when every candidate is -inf).
 // Used when the caller passes trace == NULL (the Python operator does); with a trace pointer the eager kernels run.
 #include "common.h"
+#include <string.h>
+#include <stdlib.h>
 
 namespace dsp {
 
@@ -23,6 +25,8 @@ struct MStripParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS;
+    int dbg;                                  // DSP_DEBUG=prof (2): cycle accounting of one compute wave (counters[8..12]); DSP_MX_ABLATE bits 4 / 8 / 16: no alpha
+                                              // store / no max trees / no adds either (timing experiments, results wrong)
 };
 
 constexpr int MX_TRP = 32;
@@ -102,6 +106,9 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
         __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         mx_barrier();                            // prologue barrier: match row 0 is in the ring
 
+        const bool prof = (p.dbg & 2) && b == 0 && s == p.NS - 1 && wave == 0;
+        u64 pf[4] = {0, 0, 0, 0}, pf_last = prof ? __builtin_amdgcn_s_memtime() : 0;
+        auto stamp = [&](int i) { if (prof) { const u64 tn = __builtin_amdgcn_s_memtime(); pf[i] += tn - pf_last; pf_last = tn; } };
         for (int it = 0; it < nrows; ++it) {
             const int t = it;
             const int cur = it & 1, prv = cur ^ 1;
@@ -159,6 +166,8 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                     w[32] = pl.x; w[33] = pl.y;
                     m2[0] = mt.x; m2[1] = mt.y;
                 }
+                stamp(0);                                   // barrier exit -> window and match values in registers
+                if (!(p.dbg & 16))
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     // max over the 32 predecessors: window element c + k, a 3-input max tree (values only — the arg-max is
@@ -172,20 +181,26 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                     m10[10] = fmaxf(x[30], x[31]);
                     const float m4a = fmaxf(fmaxf(m10[0], m10[1]), m10[2]), m4b = fmaxf(fmaxf(m10[3], m10[4]), m10[5]);
                     const float m4c = fmaxf(fmaxf(m10[6], m10[7]), m10[8]), m4d = fmaxf(m10[9], m10[10]);
-                    const float mx = fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                    const float mx = (p.dbg & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
                     const bool act = (j + c >= t) && (j + c < Lb);
                     a[c] = act ? (mx + m2[c]) : NEG_INF;
                 }
             }
+            stamp(1);                                       // adds + max trees
+            const bool st_ok = col_ok && !(p.dbg & 4);
             if constexpr (CPL == 4) {
                 *reinterpret_cast<float4*>(Abuf + cur * RL + 32 + 4 * l) = make_float4(a[0], a[1], a[2], a[3]);
-                if (col_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
+                if (st_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
             } else {
                 *reinterpret_cast<float2*>(Abuf + cur * RL + 32 + 2 * l) = make_float2(a[0], a[1]);
-                if (col_ok) *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(a[0], a[1]);
+                if (st_ok) *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(a[0], a[1]);
             }
+            if (prof) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(2);                                       // stores issued, LDS write done
             mx_barrier();
+            stamp(3);                                       // barrier
         }
+        if (prof && lane == 0) { for (int i = 0; i < 4; ++i) p.counters[8 + i] = (u32)(pf[i] >> 4); p.counters[12] = (u32)nrows; }
         if (col_ok) for (int t = Tb; t < T; ++t) {
             if constexpr (CPL == 4) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
             else *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(NEG_INF, NEG_INF);
@@ -478,6 +493,7 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     MStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS;
+    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; const char* a = getenv("DSP_MX_ABLATE"); if (a) p.dbg |= atoi(a) & 28; }
     const size_t halo_bytes = (size_t)B * NS * T * MX_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;
