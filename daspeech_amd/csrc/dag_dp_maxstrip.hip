@@ -13,6 +13,13 @@
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
+// Cycle accounting / timing ablations of the max-DP (tools/prof_maxstrip.py) exist only in a build with -DDSP_MX_PROF (add it as a
+// `// HIPCC_FLAGS:` line here to reproduce profiles/r03h): even wave-uniform run-time checks of the switches cost the row loop 4 %.
+#ifdef DSP_MX_PROF
+#define MX_DBG(p) ((p).dbg)
+#else
+#define MX_DBG(p) 0
+#endif
 
 namespace dsp {
 
@@ -106,7 +113,7 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
         __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         mx_barrier();                            // prologue barrier: match row 0 is in the ring
 
-        const bool prof = (p.dbg & 2) && b == 0 && s == p.NS - 1 && wave == 0;
+        const bool prof = (MX_DBG(p) & 2) && b == 0 && s == p.NS - 1 && wave == 0;
         u64 pf[4] = {0, 0, 0, 0}, pf_last = prof ? __builtin_amdgcn_s_memtime() : 0;
         auto stamp = [&](int i) { if (prof) { const u64 tn = __builtin_amdgcn_s_memtime(); pf[i] += tn - pf_last; pf_last = tn; } };
         for (int it = 0; it < nrows; ++it) {
@@ -167,7 +174,7 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                     m2[0] = mt.x; m2[1] = mt.y;
                 }
                 stamp(0);                                   // barrier exit -> window and match values in registers
-                if (!(p.dbg & 16))
+                if (!(MX_DBG(p) & 16))
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     // max over the 32 predecessors: window element c + k, a 3-input max tree (values only — the arg-max is
@@ -181,13 +188,13 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                     m10[10] = fmaxf(x[30], x[31]);
                     const float m4a = fmaxf(fmaxf(m10[0], m10[1]), m10[2]), m4b = fmaxf(fmaxf(m10[3], m10[4]), m10[5]);
                     const float m4c = fmaxf(fmaxf(m10[6], m10[7]), m10[8]), m4d = fmaxf(m10[9], m10[10]);
-                    const float mx = (p.dbg & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                    const float mx = (MX_DBG(p) & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
                     const bool act = (j + c >= t) && (j + c < Lb);
                     a[c] = act ? (mx + m2[c]) : NEG_INF;
                 }
             }
             stamp(1);                                       // adds + max trees
-            const bool st_ok = col_ok && !(p.dbg & 4);
+            const bool st_ok = col_ok && !(MX_DBG(p) & 4);
             if constexpr (CPL == 4) {
                 *reinterpret_cast<float4*>(Abuf + cur * RL + 32 + 4 * l) = make_float4(a[0], a[1], a[2], a[3]);
                 if (st_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
@@ -437,12 +444,13 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
                 if (t == 0 || pos < t) { done = true; break; }           // row 0 / under the diagonal: trace = -1
                 const int d = lane, i = pos - 1 - d;
                 float x = NEG_INF;
-                if (d < TR && i >= 0) x = seg[(h - 1) * BT_SEG + (i - (pF - 32 * (BT_HOPS + h)))] + lk[(i - lbase) * TR + d];
+                // (lk offset = pos * TR [scalar multiply] + a per-lane constant: the per-lane v_mul_lo_u32 was a quarter-rate instruction on the hop chain)
+                if (d < TR && i >= 0) x = seg[(h - 1) * BT_SEG + (i - (pF - 32 * (BT_HOPS + h)))] + lk[pos * TR + (d - (1 + d + lbase) * TR)];
                 const float mx = bt_max_lanes32(x);                       // lanes >= TR (and so all of 32..63) hold -inf
                 --t;
                 if (mx == NEG_INF) { pos = -1; done = true; break; }
                 // the LARGEST d (smallest predecessor index) among the lanes that attain the maximum: only candidates can equal a finite mx
-                const unsigned long long hit = __builtin_amdgcn_fcmp(x, mx, 1 /* FCMP_OEQ */);
+                const unsigned long long hit = __builtin_amdgcn_fcmpf(x, mx, 1 /* FCMP_OEQ */);      // (the f32 form: __builtin_amdgcn_fcmp takes doubles — two v_cvt_f64_f32 and a v_cmp_eq_f64 on every hop)
                 pos = pos - 1 - (63 - __builtin_clzll(hit));
             }
             if (lane == 0) { s_state[0] = pos; s_state[1] = t; s_state[2] = done ? 1 : 0; }

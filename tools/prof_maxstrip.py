@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Cycle accounting of one compute wave of the alignment's max-DP (dag_maxstrip_kernel; GPU box, DSP_DEBUG=prof).
+"""Cycle accounting of one compute wave of the alignment's max-DP (dag_maxstrip_kernel; GPU box, DSP_DEBUG=prof; needs a library built
+with -DDSP_MX_PROF: add `// HIPCC_FLAGS: -DDSP_MX_PROF` to the header comment of csrc/dag_dp_maxstrip.hip and rebuild).  DSP_MX_ABLATE=4|8|16
+(bits) times the kernel without its alpha store / max trees / adds.
 usage: DSP_DEBUG=prof python tools/prof_maxstrip.py [B T L TR]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
