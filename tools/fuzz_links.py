@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Randomised sweep of the fused extract_links kernel (csrc/extract_links.hip) against the numpy oracle (oracle/graph_oracle.py,
 s2t_conformer_dag.py:171-212): head geometry, ragged graph sizes (down to 1-2 vertices), banded / full windows.
+r03: the same cases also run the training path (decode_ops.extract_links_autograd: forward with saved soft-max statistics +
+dsp_extract_links_bwd) and compare its gradients w.r.t. q, k and the gate log-probabilities with torch autograd through the band
+formulation, in fp64.
 usage: fuzz_links.py [n_cases] [seed]   (GPU box only)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,6 +40,27 @@ for case in range(n):
         assert np.array_equal(np.isneginf(got), np.isneginf(w)), "-inf pattern"
         f = np.isfinite(w)
         assert np.allclose(got[f], w[f], rtol=1e-4, atol=1e-4), f"max diff {np.abs(got[f] - w[f]).max():.3e}"
+        # ---- training path: forward equal to the inference kernel, gradients against fp64 torch autograd on the band formulation
+        TR = max(1, min(TRmax, L - 1)); olen = t(lens)
+        qa, ka, ga = q.clone().requires_grad_(), k.clone().requires_grad_(), lg.clone().requires_grad_()
+        la = decode_ops.extract_links_autograd(qa, ka, ga, olen, TR)
+        assert np.array_equal(la.detach().cpu().numpy(), got), "training forward != inference forward"
+        cot = torch.from_numpy(rng.standard_normal((B, L, TR)).astype(np.float32)).cuda()
+        fin = torch.isfinite(la)
+        (la.masked_fill(~fin, 0.0) * cot).sum().backward()
+        qd, kd, gd = q.double().clone().requires_grad_(), k.double().clone().requires_grad_(), lg.double().clone().requires_grad_()
+        content = torch.einsum("bicf,bjcf->bijc", qd, kd) / (ck ** 0.5)
+        idx = torch.arange(L, device="cuda").unsqueeze(1) + torch.arange(TR, device="cuda").unsqueeze(0) + 1
+        invalid = idx.unsqueeze(0) >= olen.view(B, 1, 1)
+        band = content.gather(2, idx.unsqueeze(0).masked_fill(invalid, 0).unsqueeze(-1).expand(-1, -1, -1, h))
+        nouse = invalid.all(-1)
+        band = band.masked_fill(invalid.unsqueeze(-1), float("-inf")).masked_fill(nouse.view(B, L, 1, 1), 0.0)
+        band = torch.log_softmax(band, 2).masked_fill(invalid.unsqueeze(-1), -1e30)
+        ld = torch.logsumexp(band + gd.unsqueeze(2), -1).masked_fill(invalid, float("-inf"))
+        (ld.masked_fill(~torch.isfinite(ld), 0.0) * cot.double()).sum().backward()
+        for nm, x, y in (("dq", qa.grad, qd.grad), ("dk", ka.grad, kd.grad), ("dgates", ga.grad, gd.grad)):
+            err = float((x.double() - y).abs().max()); ref = max(1.0, float(y.abs().max()))
+            assert err <= 2e-5 * ref, f"{nm}: max diff {err:.3e} (scale {ref:.2e})"
     except Exception as e:   # noqa
         bad += 1; print("FAIL", tag, "->", repr(e)[:300])
 print(f"{n} cases, {bad} failures")

@@ -42,6 +42,23 @@ for case in range(n):
         assert np.allclose(score, score_ref, rtol=1e-4, atol=1e-6), "posterior"
         ex = D.expect_features(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(feats).to(dev)).cpu().numpy()
         assert np.allclose(ex, ex_ref[:, 1:], rtol=1e-3, atol=1e-4), "expected features"
+        # r03: the fused posterior . features op (no [B,T,L] score tensor) forward and backward against fp64 torch autograd on the
+        # two-step form (softmax over L of alpha + beta - match, masked rows -> 0, then @ features); the feature width varies
+        Cf = int(rng.choice([8, 16, 40, 64]))
+        f2 = rng.standard_normal((B, L, Cf)).astype(np.float32)
+        ta, tb, tf = (torch.from_numpy(x).to(dev) for x in (a, b, f2))
+        fa = tf.clone().requires_grad_()
+        got = D.posterior_features(ta, tb, fa)
+        cot = torch.from_numpy(rng.standard_normal(tuple(got.shape)).astype(np.float32)).to(dev)
+        (got * cot).sum().backward()
+        fd = tf.double().clone().requires_grad_()
+        sc = (ta.double() + tb.double())
+        sc = (sc - torch.logsumexp(sc, -1, keepdim=True)).exp()
+        sc = sc.masked_fill(torch.isnan(sc), 0.0)
+        want = torch.matmul(sc, fd)
+        (want * cot.double()).sum().backward()
+        assert float((got.detach().double() - want.detach()).abs().max()) <= 1e-4 * max(1.0, float(want.detach().abs().max())), "posterior_features forward"
+        assert float((fa.grad.double() - fd.grad).abs().max()) <= 1e-4 * max(1.0, float(fd.grad.abs().max())), "posterior_features backward (features)"
     except Exception as e:   # noqa
         bad += 1; print("FAIL", tag, "->", repr(e)[:300])
 print(f"{n} cases, {bad} failures")
