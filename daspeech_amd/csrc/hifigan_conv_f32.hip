@@ -255,7 +255,7 @@ struct HgsUnitParams {
 };
 
 template <int C, int NT, int WM, int WN>
-__global__ __launch_bounds__(512) void hifigan_resunit_f32_kernel(HgsUnitParams p)
+__global__ __launch_bounds__(512, (C == 32 ? 4 : 2)) void hifigan_resunit_f32_kernel(HgsUnitParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CH = C / 8, NC = C / 32;
