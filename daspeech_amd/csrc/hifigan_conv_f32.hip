@@ -12,6 +12,7 @@
 // Range: |x|, |w| < 65504 (fp16 hi part); values under 6e-5 keep fewer than 22 bits — both far from what a vocoder holds.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include "../../include/daspeech_hifigan.h"
 
 namespace dsp {
@@ -255,7 +256,7 @@ struct HgsUnitParams {
 };
 
 template <int C, int NT, int WM, int WN>
-__global__ __launch_bounds__(512, (C == 32 ? 4 : 2)) void hifigan_resunit_f32_kernel(HgsUnitParams p)
+__global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_resunit_f32_kernel(HgsUnitParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CH = C / 8, NC = C / 32;
@@ -539,9 +540,12 @@ extern "C" int dsp_hifigan_conv_chain_f32(const dsp_hg_layer* layers, int n_laye
             u.lens = lens; u.len_mul = mul;
             if (!u.x || !u.out || u.x == u.out) { set_error("hifigan_conv_chain_f32: null or aliased pointer in unit %d", i); return DSP_EINVAL; }
             int rc;
+            // (tile sweep of r03, ms per 32 x 329-frame call and stage — C=256: NT 32 / 48 / 64 = 5.30 / 4.69 / 5.04; C=128 as 8x1 waves: NT 64 / 80 / 96 /
+            //  112 = 9.34 / 8.82 / 8.93 / 8.71, as 4x2 waves at 132 VGPRs and one workgroup per CU 9.8; C=64: <240,2,4> 4.40, <240,4,2> 4.63,
+            //  <176,4,2> 4.87, <112,4,2> 5.38; C=32: <496,1,8> 2.88, <496,2,4> 3.02, <240,2,4> 3.04, <240,1,8> 3.43)
             switch (l.CI) {
                 case 256: rc = hgs_unit_launch<256, 48, 8, 1>(u, as_stream(stream)); break;
-                case 128: rc = hgs_unit_launch<128, 112, 4, 2>(u, as_stream(stream)); break;
+                case 128: rc = hgs_unit_launch<128, 112, 8, 1>(u, as_stream(stream)); break;
                 case 64:  rc = hgs_unit_launch<64, 240, 2, 4>(u, as_stream(stream)); break;
                 default:  rc = hgs_unit_launch<32, 496, 1, 8>(u, as_stream(stream)); break;
             }
