@@ -284,6 +284,8 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
             return cs_launch<256, 256, 64, 8, 1>(p, st);
         }
         case 512: {
+            // (r03: a 512-wide Linear layer run as two 256-wide slices — 65 KB tiles, two workgroups per CU — is no faster: 14.59 vs 14.55 ms of
+            //  GPU time per acoustic batch.)
             // launches that would leave CUs idle with 64-frame tiles (the Conformer's 2048 -> 256 on 4.4 k positions: 69 workgroups)
             // take 32-frame tiles, two workgroups per CU: 52.7 -> 36.7 us; where the 64-frame tiles fill the chip they are 10-20 % faster
             // (at 192 workgroups the 64-frame tiles still win: 34.3 vs 38.9 us for 1024 -> 256 on 10.6 k positions; 128-channel tiles: no gain)
