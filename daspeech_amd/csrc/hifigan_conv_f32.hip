@@ -544,8 +544,15 @@ extern "C" int dsp_hifigan_conv_chain_f32(const dsp_hg_layer* layers, int n_laye
             //  112 = 9.34 / 8.82 / 8.93 / 8.71, as 4x2 waves at 132 VGPRs and one workgroup per CU 9.8; C=64: <240,2,4> 4.40, <240,4,2> 4.63,
             //  <176,4,2> 4.87, <112,4,2> 5.38; C=32: <496,1,8> 2.88, <496,2,4> 3.02, <240,2,4> 3.04, <240,1,8> 3.43)
             switch (l.CI) {
-                case 256: rc = hgs_unit_launch<256, 48, 8, 1>(u, as_stream(stream)); break;
-                case 128: rc = hgs_unit_launch<128, 112, 8, 1>(u, as_stream(stream)); break;
+                case 256: rc = hgs_unit_launch<256, 48, 8, 1>(u, as_stream(stream)); break;      // (32-column tiles for the wide-halo units, to fit two per CU: slower, 21.9 vs 21.2 ms per call)
+                case 128: {
+                    // two workgroups per CU need <= 80 KB each: the wide-halo units (k = 7 / 11 at dilation 3 / 5) take narrower tiles for it
+                    const int h1u = dil * (l.ntaps - 1) / 2;
+                    if (hgs_unit_lds(128, 112, h1u) <= 80 * 1024) rc = hgs_unit_launch<128, 112, 8, 1>(u, as_stream(stream));
+                    else if (hgs_unit_lds(128, 96, h1u) <= 80 * 1024) rc = hgs_unit_launch<128, 96, 8, 1>(u, as_stream(stream));
+                    else rc = hgs_unit_launch<128, 80, 8, 1>(u, as_stream(stream));
+                    break;
+                }
                 case 64:  rc = hgs_unit_launch<64, 240, 2, 4>(u, as_stream(stream)); break;
                 default:  rc = hgs_unit_launch<32, 496, 1, 8>(u, as_stream(stream)); break;
             }
