@@ -105,7 +105,7 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
     if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
     if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
-        return align256(256 + align256((size_t)B * NJ * 4) + (size_t)B * T * NJ * 4) + 512;
+        return align256(256 + align256((size_t)B * NJ * 4) + align256((size_t)B * T * NJ * 4) + (size_t)B * T * L * 2) + 512;     // (+ the block trace)
     }
     return align256((size_t)B * L * TR * 4) + align256(256 + (size_t)B * 2 * L * 8) + 1024;
 }

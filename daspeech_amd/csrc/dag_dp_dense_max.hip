@@ -12,7 +12,9 @@
 // the sequential scan, whatever the blocking.  The diagonal block is walked row by row by one wave (column per lane, its weights in
 // registers, max3).
 // The back-trace recomputes the arg-max of the T cells it visits from alpha_max and the links (smallest predecessor index among equal
-// maxima: the torch rule): one workgroup per sample scans the up-to-L predecessors of a cell cooperatively.
+// maxima: the torch rule).  r03: the max-DP also leaves, per cell, the index of the 64-column BLOCK that holds its arg-max
+// (2 bytes instead of the reference's 4-byte trace entry), so a hop evaluates 64 candidates instead of up to L
+// (dag_dense_backtrace_blk_kernel; the full scan it replaces took 6 us per hop at C2 / TR = 4095: 0.5 MB of cache lines for one cell).
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +33,7 @@ struct DXParams {
     float* S;                 // [B][T][NJ]     block maximum of the row (-inf = nothing alive)
     u32 tag_base;
     int B, T, L, TR, NJ;
+    unsigned short* btrace;   // [B][T][L]  the 64-column block that holds a cell's arg-max predecessor (0xFFFF: none) — see dag_dense_backtrace_blk_kernel
 };
 
 // chunks of DX_MT x 16 rows.  32-row chunks (DX_MT = 2: a weight read serves 8 rows of a thread, the per-block overhead is paid half
@@ -68,6 +71,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
     float* Vd = Poff + DX_TM * 64;                     // [64]          diagonal block: previous row
     float* Md = Vd + 64;                               // [TM][64]      the chunk's emissions
     int* RDY = reinterpret_cast<int*>(Md + DX_TM * 64);
+    int* Boff = RDY + 4;                               // [TM][64]      block of the off-diagonal maximum (see `bv`)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(&p.counters[0], 1u);
     __syncthreads();
@@ -79,6 +83,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
     const float* K = p.links + (size_t)b * L * TR;
     float* O = p.alpha + (size_t)b * T * L;
     float* S = p.S + (size_t)b * T * NJ;
+    unsigned short* BT = p.btrace + (size_t)b * T * L;
     u32* prog = p.progress + (size_t)b * NJ;
     const int ub = U * DX_BW;
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
@@ -125,6 +130,16 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
         for (int mt = 0; mt < DX_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][r] = NEG_INF;
+        // Which source block holds the maximum.  The back-trace needs, for the T cells it visits, the arg-max predecessor; recomputing
+        // it from alpha_max means scanning up to L predecessors whose transition weights sit in L different cache lines (C2 at
+        // TR = 4095: 0.5 MB of lines and 6 us per hop).  A block index per cell (2 bytes) narrows that to 64.  Blocks arrive in
+        // ascending order and only a STRICT improvement moves the index, so among equal maxima the smallest predecessor index wins,
+        // as in the sequential scan (the back-trace takes the smallest index inside the block).
+        int bv[DX_MT][4];
+#pragma unroll
+        for (int mt = 0; mt < DX_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[mt][r] = 0xFFFF;
         // the chunk's emissions, 4 per thread, requested now and parked in LDS after the products
         float em[DX_MT][4];
 #pragma unroll
@@ -234,8 +249,13 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                     for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = w_ok(vb + 16 * mg + i, ub + n) ? st_w[s][i] : NEG_INF;
                 }
             };
-            auto product = [&](int nb) {       // (+, max) product: acc[mt][r] = max_k ( A[16 mt + 4 mg + r][k] + W[k][n] )
+            auto product = [&](int nb, int Vb) {       // (+, max) product: acc[mt][r] = max_k ( A[16 mt + 4 mg + r][k] + W[k][n] )
                 const float* Ab = At + nb * DX_TM * 64; const float* Wb = Wt + nb * 64 * DX_WP;
+                float old[DX_MT][4];
+#pragma unroll
+                for (int mt = 0; mt < DX_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[mt][r] = acc[mt][r];
 #pragma unroll 2
                 for (int kk = 0; kk < 16; ++kk) {
                     const float w0 = Wb[(4 * kk) * DX_WP + n], w1 = Wb[(4 * kk + 1) * DX_WP + n];
@@ -252,8 +272,12 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                         }
                     }
                 }
+#pragma unroll
+                for (int mt = 0; mt < DX_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[mt][r] = (acc[mt][r] > old[mt][r]) ? Vb : bv[mt][r];
             };
-            int cur = 0; bool have = false;
+            int cur = 0, curV = -1; bool have = false;
             auto step = [&](int s, int V) {
                 if (V < U && !st_ok[s]) {
                     ensure_ready(V); prefetchA(s, V);
@@ -264,9 +288,9 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 const int W = V + 2, Wc = min(W, U - 1);
                 prefetchW(s, Wc); prefetchA(s, Wc);
                 st_ok[s] = W <= ready_hi;
-                if (have) product(cur);
+                if (have) product(cur, curV);
                 if (have || live) __syncthreads();
-                if (live) cur ^= 1;
+                if (live) { cur ^= 1; curV = V; }
                 have = live;
             };
             if (Vmin < U) {
@@ -275,12 +299,12 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 prefetchW(1, W1); prefetchA(1, W1); st_ok[1] = (Vmin + 1) <= ready_hi;
             }
             for (int Vb = Vmin; Vb < U; Vb += 2) { step(0, Vb); step(1, Vb + 1); }
-            if (have) product(cur);
+            if (have) product(cur, curV);
         }
 #pragma unroll
         for (int mt = 0; mt < DX_MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Poff[(16 * mt + 4 * mg + r) * 64 + n] = acc[mt][r];
+            for (int r = 0; r < 4; ++r) { Poff[(16 * mt + 4 * mg + r) * 64 + n] = acc[mt][r]; Boff[(16 * mt + 4 * mg + r) * 64 + n] = bv[mt][r]; }
             *reinterpret_cast<v4f*>(Md + (16 * mt + (tid >> 4)) * 64 + 4 * (tid & 15)) = (v4f){em[mt][0], em[mt][1], em[mt][2], em[mt][3]};
         }
         __syncthreads();
@@ -288,12 +312,12 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
         // ================================================================ diagonal block, row by row (wave 0)
         if (wave == 0) {
             const int m_lo = (tt0 == 0) ? 1 : 0, m_hi = min(DX_TM, Tb - tt0);
-            float n_po = Poff[m_lo * 64 + ul], n_m = Md[m_lo * 64 + ul];
+            float n_po = Poff[m_lo * 64 + ul], n_m = Md[m_lo * 64 + ul]; int n_bo = Boff[m_lo * 64 + ul];
 #pragma unroll 1
             for (int m = m_lo; m < m_hi; ++m) {
                 const int tt = tt0 + m;
-                float best = n_po; const float mm = n_m;
-                { const int mn = min(m + 1, DX_TM - 1); n_po = Poff[mn * 64 + ul]; n_m = Md[mn * 64 + ul]; }       // next row's operands
+                float best = n_po; const float mm = n_m; const float po = n_po; int blk = n_bo;
+                { const int mn = min(m + 1, DX_TM - 1); n_po = Poff[mn * 64 + ul]; n_m = Md[mn * 64 + ul]; n_bo = Boff[mn * 64 + ul]; }       // next row's operands
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const v4f t4 = *reinterpret_cast<const v4f*>(Vd + 4 * q);
@@ -303,6 +327,8 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 // cells outside t <= j < L_b have no live predecessor / only -inf links: -inf by the arithmetic alone
                 const float a = best + mm;                                     // mx + match   (dag_best_alignment.cu:120)
                 if (u < L) dx_st(O + (size_t)tt * L + u, a);
+                if (best > po) blk = U;                                       // (strictly better than every earlier block: the arg-max is in this one)
+                if (u < L) BT[(size_t)tt * L + u] = (unsigned short)blk;
                 Vd[ul] = a;                                                   // (this row's reads are done: same wave, program order)
                 const float bm = dx_wave_max(a);
                 if (lane == 0) dx_st(&S[(size_t)tt * NJ + U], bm);
@@ -320,61 +346,87 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
 __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p) { dag_dense_max_body(p); }
 __global__ __launch_bounds__(256, 2) void dag_dense_max_kernel_occ2(DXParams p) { dag_dense_max_body(p); }
 
-// K7 without a trace tensor: path[b][pos] = t along the chain of arg-max predecessors from (T_b-1, L_b-1), the arg-max recomputed from
-// alpha_max and the links for the one cell per row the chain visits.  Tie rule: smallest predecessor index among equal maxima.
-__global__ __launch_bounds__(256) void dag_dense_backtrace_kernel(const float* __restrict__ alpha, const float* __restrict__ links,
-                                                                  const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-                                                                  int64_t* __restrict__ path, int B, int T, int L, int TR)
+// K7: path[b][pos] = t along the chain of arg-max predecessors from (T_b-1, L_b-1), with the block trace of the max-DP (r03): the arg-max predecessor of cell (t, pos) lies in block V = btrace[t][pos], so a hop
+// evaluates 64 candidates — one wave, one gather of 64 transition weights — instead of every predecessor.  The rows the hops will
+// need (alpha_max[t-1][*] and btrace[t][*]) do not depend on the path: the other waves stream them into an LDS ring NR rows ahead, so
+// that the only memory round trip on the hop chain is the gather of the weights.  Tie rule as before: smallest predecessor index.
+// ring = 0: no LDS ring (L too large for it), the rows are read from memory.
+__global__ __launch_bounds__(256) void dag_dense_backtrace_blk_kernel(const float* __restrict__ alpha, const unsigned short* __restrict__ btrace,
+                                                                      const float* __restrict__ links, const int64_t* __restrict__ out_len,
+                                                                      const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path,
+                                                                      int B, int T, int L, int TR, int ring)
 {
-    extern __shared__ __attribute__((aligned(16))) int lp[];          // [L] path image
-    __shared__ float rv[4]; __shared__ int ri[4]; __shared__ int s_pos;
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    int* lp = reinterpret_cast<int*>(bsm);                                    // [L] path image
+    float* Ar = reinterpret_cast<float*>(lp + L);                             // [ring][L]  alpha_max rows   (row r in slot r % ring)
+    unsigned short* Br = reinterpret_cast<unsigned short*>(Ar + (size_t)ring * L);      // [ring][L]  block-trace rows
+    __shared__ int s_pos;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < L; j += 256) lp[j] = -1;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
     if (tid == 0) s_pos = valid ? Lb - 1 : -1;
+    const float* A = alpha + (size_t)b * T * L;
+    const unsigned short* BT = btrace + (size_t)b * T * L;
+    const float* K = links + (size_t)b * L * TR;
+    // hop t (from row t to row t - 1) reads btrace row t and alpha row t - 1: "row pair t"
+    auto load_pair = [&](int t, int first, int nthr) {
+        if (t < 1) return;
+        float* ar = Ar + (size_t)((t - 1) % ring) * L; unsigned short* br = Br + (size_t)(t % ring) * L;
+        for (int j = tid - first; j < L; j += nthr) { ar[j] = A[(size_t)(t - 1) * L + j]; br[j] = BT[(size_t)t * L + j]; }
+    };
+    // the loader waves (1..3) fetch a pair into REGISTERS during one hop and park it in the ring during the next, so that their memory
+    // round trip never sits between the hop wave and the hop's barrier
+    constexpr int NS = 48;                                                        // ceil(L / 192) for every L that gets a ring
+    float ra[NS]; unsigned short rb[NS]; int rq = 0;
+    const int nsa = (L + 191) / 192;
+    auto issue = [&](int q) {
+        rq = q;
+        if (q < 1) return;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (s2 >= nsa) break;                                                 // (uniform: the unrolled tail is skipped, not predicated)
+            const int j = min((tid - 64) + 192 * s2, L - 1);
+            ra[s2] = A[(size_t)(q - 1) * L + j]; rb[s2] = BT[(size_t)q * L + j];
+        }
+    };
+    auto stash = [&]() {
+        if (rq < 1) return;
+        float* ar = Ar + (size_t)((rq - 1) % ring) * L; unsigned short* br = Br + (size_t)(rq % ring) * L;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (s2 >= nsa) break;
+            const int j = (tid - 64) + 192 * s2;
+            if (j < L) { ar[j] = ra[s2]; br[j] = rb[s2]; }
+        }
+    };
+    if (valid && ring > 0) {
+        for (int k = 0; k < ring - 1; ++k) load_pair(Tb - 1 - k, 0, 256);
+        if (wave != 0) issue(Tb - ring);
+    }
     __syncthreads();
     if (valid) {
-        const float* A = alpha + (size_t)b * T * L;
-        const float* K = links + (size_t)b * L * TR;
-        // the final score must be finite, otherwise there is no alignment (the reference asserts, dag_best_alignment.cu:117-119)
         for (int t = Tb - 1; t >= 0; --t) {
             const int pos = s_pos;
             if (pos < 0) break;
             if (tid == 0) lp[pos] = t;
             if (t == 0) break;
-            const int lo = max(t - 1, pos - TR);
-            float best = NEG_INF; int arg = 1 << 30;
-            // 8 predecessors per thread and pass, all 16 loads requested before the first compare (unconditional, clamped: a loop of
-            // guarded load -> compare pays one memory round trip per predecessor, and the hop is the back-trace's critical path)
-            const float* Arow = A + (size_t)(t - 1) * L;
-            for (int i0 = lo + tid; i0 < pos; i0 += 8 * 256) {
-                float av[8], kv[8];
+            if (ring > 0 && wave != 0) { stash(); issue(t - ring); }         // (waves 1..3) park pair t - ring + 1 (its slots were pair t + 1's: that hop is done), request the next
+            if (wave == 0) {
+                const int V = ring > 0 ? (int)Br[(size_t)(t % ring) * L + pos] : (int)BT[(size_t)t * L + pos];
+                const int lo = max(t - 1, pos - TR);
+                const int i = V * 64 + lane;
+                const bool ok = V != 0xFFFF && i < pos && i >= lo;
+                const float av = ring > 0 ? Ar[(size_t)((t - 1) % ring) * L + (ok ? i : 0)] : A[(size_t)(t - 1) * L + (ok ? i : 0)];
+                const float kv = K[ok ? ((size_t)i * TR + (pos - i - 1)) : (size_t)0];
+                float best = ok ? av + kv : NEG_INF; int arg = ok ? i : (1 << 30);
+                if (best == NEG_INF) arg = 1 << 30;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i = i0 + 256 * e;
-                    const bool ok = i < pos;
-                    av[e] = Arow[ok ? i : 0];
-                    kv[e] = K[ok ? ((size_t)i * TR + (pos - i - 1)) : (size_t)0];
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float b2 = __shfl_xor(best, o, 64); const int a2 = __shfl_xor(arg, o, 64);
+                    if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {                                 // ascending i per thread, strict >: the thread's smallest index
-                    const int i = i0 + 256 * e;
-                    const float v = (i < pos) ? av[e] + kv[e] : NEG_INF;
-                    if (v > best) { best = v; arg = i; }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float b2 = __shfl_xor(best, o, 64); const int a2 = __shfl_xor(arg, o, 64);
-                if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
-            }
-            if (lane == 0) { rv[wave] = best; ri[wave] = arg; }
-            __syncthreads();
-            if (tid == 0) {
-                float bb = rv[0]; int aa = ri[0];
-                for (int w = 1; w < 4; ++w) if (rv[w] > bb || (rv[w] == bb && ri[w] < aa)) { bb = rv[w]; aa = ri[w]; }
-                s_pos = (bb == NEG_INF) ? -1 : aa;
+                if (lane == 0) s_pos = (best == NEG_INF) ? -1 : arg;
             }
             __syncthreads();
         }
@@ -396,13 +448,15 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NJ = NJ;
     const size_t prog_bytes = ((size_t)B * NJ * sizeof(u32) + 255) / 256 * 256;
-    const size_t s_bytes = (size_t)B * T * NJ * sizeof(float);
+    const size_t s_bytes = ((size_t)B * T * NJ * sizeof(float) + 255) / 256 * 256;
+    const size_t bt_bytes = (size_t)B * T * L * sizeof(unsigned short);
     u64* area = nullptr;
-    int rc = banded_acquire_ws(st, prog_bytes + s_bytes, T, &p.counters, &area, &p.tag_base);
+    int rc = banded_acquire_ws(st, prog_bytes + s_bytes + bt_bytes, T, &p.counters, &area, &p.tag_base);
     if (rc) return rc;
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float*>(reinterpret_cast<char*>(area) + prog_bytes);
-    const size_t lds = (size_t)(2 * DX_TM * 64 + 2 * 64 * DX_WP + 2 * DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4) * 4 + 64;
+    p.btrace = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(area) + prog_bytes + s_bytes);
+    const size_t lds = (size_t)(2 * DX_TM * 64 + 2 * 64 * DX_WP + 2 * DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4 + DX_TM * 64) * 4 + 64;
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -411,9 +465,13 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     hipLaunchKernelGGL(k, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");
     if (rc) return rc;
-    const size_t lds2 = (size_t)L * 4;
-    (void)hipFuncSetAttribute((const void*)dag_dense_backtrace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(dag_dense_backtrace_kernel, dim3((unsigned)B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR);
+    // LDS ring of (alpha row, block-trace row) pairs for the back-trace: as deep as fits (5 at L = 4096), none beyond L ~ 9000
+    int ring = 5;
+    while (ring > 1 && (size_t)L * 4 + (size_t)ring * L * 6 > 150 * 1024) --ring;
+    if (ring < 3 || L > 48 * 192) ring = 0;
+    const size_t lds2 = (size_t)L * 4 + (size_t)ring * L * 6;
+    (void)hipFuncSetAttribute((const void*)dag_dense_backtrace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(dag_dense_backtrace_blk_kernel, dim3((unsigned)B), dim3(256), lds2, st, alpha_max, p.btrace, links, out_len, tgt_len, path, B, T, L, TR, ring);
     return check_launch("dag_best_alignment(dense back-trace)");
 }
 
