@@ -39,7 +39,8 @@ struct DXParams {
 // chunks of DX_MT x 16 rows.  32-row chunks (DX_MT = 2: a weight read serves 8 rows of a thread, the per-block overhead is paid half
 // as often) measured WORSE here except at the largest shape — C1 2.12 -> 2.32 ms, B=32 T=100 L=400 0.41 -> 0.45, C2 at TR=4095
 // 22.8 -> 22.1 — unlike the matrix-core kernel: the (+, max) product is VALU work proportional to the rows either way.
-constexpr int DX_BW = 64, DX_MT = 1, DX_TM = 16 * DX_MT, DX_WP = 65;      // weight tile pitch 65: a thread column walks k at a bank stride of 1
+constexpr int DX_BW = 64, DX_MT = 1, DX_TM = 16 * DX_MT, DX_WP = 68;      // weight tile [n = column][k = source], row pitch 68 floats: a thread reads its column's next four k as ONE ds_read_b128
+                                                                          // (16-lane groups land on 16 different 16-byte slots: 272-byte stride); [k][n] with pitch 65 took four ds_read_b32 per four k
 constexpr u32 DX_SPIN_LIMIT = 1u << 24;
 
 // wave-wide maximum, wave-uniform result: 4 DPP steps inside the 16-lane rows, then the four rows through readlane
@@ -65,7 +66,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_ticket;
     float* At = smem;                                  // [2][TM][64]   source rows (previous DP row of block V), row-major
-    float* Wt = At + 2 * DX_TM * 64;                   // [2][64][65]   weights [k = source][n = column]
+    float* Wt = At + 2 * DX_TM * 64;                   // [2][64][68]   weights [n = column][k = source]
     float* Sb = Wt + 2 * 64 * DX_WP;                   // [2][TM]       block maximum per source row
     float* Poff = Sb + 2 * DX_TM;                      // [TM][64]      off-diagonal maxima of the tile
     float* Vd = Poff + DX_TM * 64;                     // [64]          diagonal block: previous row
@@ -243,10 +244,10 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                 float* Wb = Wt + nb * 64 * DX_WP;
                 if (w_full(V)) {                                         // full tile: no predicates at all
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = st_w[s][i];
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<v4f*>(Wb + n * DX_WP + 16 * mg + 4 * i) = (v4f){st_w[s][4 * i], st_w[s][4 * i + 1], st_w[s][4 * i + 2], st_w[s][4 * i + 3]};
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) Wb[(16 * mg + i) * DX_WP + n] = w_ok(vb + 16 * mg + i, ub + n) ? st_w[s][i] : NEG_INF;
+                    for (int i = 0; i < 16; ++i) Wb[n * DX_WP + 16 * mg + i] = w_ok(vb + 16 * mg + i, ub + n) ? st_w[s][i] : NEG_INF;
                 }
             };
             auto product = [&](int nb, int Vb) {       // (+, max) product: acc[mt][r] = max_k ( A[16 mt + 4 mg + r][k] + W[k][n] )
@@ -258,8 +259,8 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
                     for (int r = 0; r < 4; ++r) old[mt][r] = acc[mt][r];
 #pragma unroll 2
                 for (int kk = 0; kk < 16; ++kk) {
-                    const float w0 = Wb[(4 * kk) * DX_WP + n], w1 = Wb[(4 * kk + 1) * DX_WP + n];
-                    const float w2 = Wb[(4 * kk + 2) * DX_WP + n], w3 = Wb[(4 * kk + 3) * DX_WP + n];
+                    const v4f w4 = *reinterpret_cast<const v4f*>(Wb + n * DX_WP + 4 * kk);
+                    const float w0 = w4.x, w1 = w4.y, w2 = w4.z, w3 = w4.w;
 #pragma unroll
                     for (int mt = 0; mt < DX_MT; ++mt) {
                         v4f a4[4];
