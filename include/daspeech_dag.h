@@ -107,7 +107,9 @@ int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* bet
  *   (the reference returns int32 and casts in Python, dag_loss.py:228).  path[b,j] = t or -1.
  *   Tie rule: smallest predecessor index among equal maxima (torch.max rule, dag_loss.py:320).
  *   trace may be NULL where dsp_dag_alignment_trace_optional(L, TR) returns 1: the DP then keeps values only and the
- *   back-trace recomputes the arg-max of the T cells it visits (same tie rule) — no B*T*L trace tensor is produced.
+ *   back-trace recomputes the arg-max of the T cells it visits (same tie rule) — no B*T*L int32 trace tensor is produced
+ *   (for dense windows, TR > 64, the scratch of dsp_dag_alignment_workspace_bytes holds a 2-byte block index per cell that narrows
+ *   that recomputation to 64 candidates).
  */
 int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                            float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
