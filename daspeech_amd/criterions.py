@@ -59,11 +59,12 @@ def _viterbi_path(model, logits: Tensor, tgt_tokens: Tensor, links: Tensor, outp
 
 
 def _top_scored(scores: Tensor, counts: Tensor) -> Tensor:
-    """1.0 where a position's score is among its row's `counts[b]` largest (nothing for a zero count)."""
-    rank = torch.empty_like(scores, dtype=torch.long)
-    order = scores.argsort(dim=-1, descending=True, stable=True)
-    rank.scatter_(-1, order, torch.arange(scores.shape[-1], device=scores.device).expand_as(order))
-    return (rank < counts.unsqueeze(-1)).to(scores.dtype)
+    """1.0 where a position's score reaches its row's `counts[b]`-th largest score (nothing for a zero count) — the reference's
+    threshold form (nat_dag_loss.py:236-239): ties with the threshold are all kept, and a count beyond the number of aligned vertices
+    (a sample without a valid alignment: every score is the -100 fill) keeps every position."""
+    thresh = scores.sort(descending=True)[0].gather(-1, (counts - 1).clip(min=0).unsqueeze(-1)).squeeze(-1)
+    thresh = thresh.masked_fill(counts == 0, 100)
+    return (scores >= thresh.unsqueeze(-1)).to(scores.dtype)
 
 
 @torch.no_grad()
@@ -127,7 +128,13 @@ def glat_function(model, word_ins_out: Tensor, tgt_tokens: Tensor, prev_output_t
 
 DEFAULT_CFG = dict(label_smoothing=0, glat_p="0", glance_strategy=None, no_force_emit=False, torch_dag_logsoftmax_gather=False,
                    torch_dag_best_alignment=False, torch_dag_loss=False, training_strategy="expect", tts_loss_weight=1.0,
-                   dag_freezing_steps=-1)
+                   dag_freezing_steps=-1,
+                   # not a reference flag.  With --training-strategy argmax the reference's GPU path takes the Viterbi alignment on the
+                   # logits buffer AFTER dag_logsoftmax_gather_inplace has overwritten it with its soft-max (s2s_dag_fastspeech2_loss.py:215
+                   # reads outputs["word_ins"]["out"], which :63 mutated), i.e. on log_softmax(softmax(x)); its torch gather leaves the logits
+                   # alone.  False (default) reproduces whichever the --torch-dag-logsoftmax-gather flag selects in the reference; True
+                   # always aligns on the logits.
+                   argmax_on_logits=False)
 
 
 class NATDAGLoss:
@@ -171,7 +178,7 @@ class NATDAGLoss:
         else:
             # `outputs` is never read again (the reference forbids it, dag_loss.py:249-251): keep the gather's backward state as
             # two floats per row instead of an in-place softmax — the forward's B*L*V store disappears, match and gradient unchanged
-            prev_mode = custom_ops.set_lazy_softmax(True)
+            prev_mode = custom_ops.set_lazy_softmax(self._lazy_softmax())
             try:
                 outputs, match_all = custom_ops.dag_logsoftmax_gather_inplace(outputs, idx)
             finally:
@@ -199,6 +206,9 @@ class NATDAGLoss:
         res = {"name": name, "loss": loss * factor, "nll_loss": nll_loss, "factor": factor, "ntokens": ntokens,
                "nvalidtokens": nvalidtokens, "nsentences": nsentences, "loss_nofactor": loss, "invalid_nsentences": invalid_nsentences}
         return res, alpha, beta
+
+    def _lazy_softmax(self) -> bool:
+        return True
 
     def _compute_dag_loss(self, outputs, output_masks, targets, target_masks, links, label_smoothing=0.0, name="loss", factor=1.0,
                           matchmask=None, keep_word_mask=None, model=None):
@@ -258,6 +268,11 @@ def _lengths_to_mask(lens: Tensor, n: int = None) -> Tensor:
 class S2SDAGFastSpeech2Loss(NATDAGLoss):
     """registered name: s2s_dag_fastspeech2_loss (s2s_dag_fastspeech2_loss.py:26)."""
 
+    def _lazy_softmax(self) -> bool:
+        # argmax strategy, reference GPU behaviour: the gather must really overwrite the logits with their soft-max, because the
+        # alignment below reads that buffer (see DEFAULT_CFG["argmax_on_logits"]); everywhere else the buffer is dead after the gather
+        return not (self.cfg.training_strategy == "argmax" and not self.cfg.argmax_on_logits)
+
     def _compute_dag_loss_with_alpha_beta(self, outputs, output_masks, targets, target_masks, links, label_smoothing=0.0, name="loss",
                                           factor=1.0, matchmask=None, keep_word_mask=None, model=None):
         return self._dag_loss_core(outputs, output_masks, targets, target_masks, links, name, factor, matchmask, keep_word_mask, model, True)
@@ -285,18 +300,16 @@ class S2SDAGFastSpeech2Loss(NATDAGLoss):
                 target_length = tgt_tokens.ne(model.pad).sum(1)
                 output_length = prev_output_tokens.ne(model.pad).sum(1)
                 idx = tgt_tokens.unsqueeze(1).expand(-1, prelen, -1)
-                # the alignment is taken on the LOGITS: the loss above keeps its backward state as row statistics (lazy mode) or, with
-                # --torch-dag-logsoftmax-gather, does not touch the buffer at all.  (The reference's CUDA path has already overwritten
-                # the buffer with its softmax at this point, :215, so it aligns on log_softmax(softmax(x)); its torch path does not.
-                # The torch path's behaviour is the one reproduced.)
+                # `out` is the buffer the loss above ran its gather on: soft-max values where the reference's GPU gather would have left
+                # them (HIP gather, gradient required, argmax_on_logits off), the logits otherwise — see DEFAULT_CFG["argmax_on_logits"]
                 logits_d = outputs["word_ins"]["out"].detach()
-                if self.cfg.torch_dag_best_alignment:
-                    _, match = custom_ops.torch_dag_logsoftmax_gather_inplace(logits_d, idx)
-                    path = custom_ops.torch_dag_best_alignment(match.transpose(1, 2).clone(), decode_ops.restore_valid_links(links_d),
-                                                               output_length, target_length)
+                gather = custom_ops.torch_dag_logsoftmax_gather_inplace if self.cfg.torch_dag_logsoftmax_gather \
+                    else custom_ops.dag_logsoftmax_gather_inplace                                            # (:219-222; no gradient: no mutation)
+                match = gather(logits_d, idx)[1].transpose(1, 2)
+                if self.cfg.torch_dag_best_alignment:                                                        # (:226-232)
+                    path = custom_ops.torch_dag_best_alignment(match.clone(), decode_ops.restore_valid_links(links_d), output_length, target_length)
                 else:
-                    _, match = custom_ops.dag_logsoftmax_gather_inplace(logits_d, idx)
-                    path = custom_ops.dag_best_alignment(match.transpose(1, 2), links_d, output_length, target_length)
+                    path = custom_ops.dag_best_alignment(match, links_d, output_length, target_length)
                 path = path.clone()
                 path[:, 0] = -1                                                                              # mask <bos>  (:241)
                 features_mask = path >= 0
@@ -309,15 +322,19 @@ class S2SDAGFastSpeech2Loss(NATDAGLoss):
         else:
             # expect: z_i = sum_j P(a_i = j | x, y) v_j   (:252-265)
             # (fused: the [B,T,L] posterior never exists; gradient to the features through dsp_posterior_features_bwd)
+            # (without a gradient — validation, or --dag-freezing-steps not yet passed — the reference's beta is all zeros, dag_loss.cu:340, and
+            #  so is the one handed back here: the "posterior" is then soft-max_j alpha[t, j], as in the reference)
             input_to_tts = model.adaptor(decode_ops.posterior_features(alpha, beta, features)[:, 1:, :])
             features_padding_mask = ~_lengths_to_mask(sample["target_text_lengths"] - 1, input_to_tts.shape[1])
-        _feat_out, _, log_dur_out, pitch_out, energy_out = model.tts(
+        _feat_out, _feat_out_post, _, log_dur_out, pitch_out, energy_out = model.tts(
             input_to_tts, features_padding_mask, durations=sample["durations"], pitches=sample["pitches"], energies=sample["energies"])
         src_mask = _lengths_to_mask(sample["target_text_lengths"] - 1, log_dur_out.shape[1])                 # -1: no <bos>
         F_ = min(_feat_out.shape[1], sample["target_audio"].shape[1])
         tgt_mask = _lengths_to_mask(sample["target_audio_lengths"].clamp(max=F_), F_)
         feat_out, feat = _feat_out[:, :F_][tgt_mask], sample["target_audio"][:, :F_][tgt_mask]
         l1_loss = F.l1_loss(feat_out, feat, reduction="mean")
+        if _feat_out_post is not None:                                                                       # --add-postnet (:281-282)
+            l1_loss = l1_loss + F.l1_loss(_feat_out_post[:, :F_][tgt_mask], feat, reduction="mean")
         pitch_loss = F.mse_loss(pitch_out[src_mask], sample["pitches"][src_mask], reduction="mean")
         energy_loss = F.mse_loss(energy_out[src_mask], sample["energies"][src_mask], reduction="mean")
         log_dur = torch.log(sample["durations"].to(log_dur_out.dtype) + 1)[src_mask]

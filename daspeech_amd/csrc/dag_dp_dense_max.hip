@@ -361,12 +361,13 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_blk_kernel(const floa
     int* lp = reinterpret_cast<int*>(bsm);                                    // [L] path image
     float* Ar = reinterpret_cast<float*>(lp + L);                             // [ring][L]  alpha_max rows   (row r in slot r % ring)
     unsigned short* Br = reinterpret_cast<unsigned short*>(Ar + (size_t)ring * L);      // [ring][L]  block-trace rows
-    __shared__ int s_pos;
+    __shared__ int s_pos[2];                                                  // hop t reads slot t & 1, its result goes to slot (t - 1) & 1: no wave
+                                                                              // can see the next position before the hop's barrier (every wave takes the same exit)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < L; j += 256) lp[j] = -1;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
-    if (tid == 0) s_pos = valid ? Lb - 1 : -1;
+    if (tid == 0) { s_pos[0] = s_pos[1] = valid ? Lb - 1 : -1; }
     const float* A = alpha + (size_t)b * T * L;
     const unsigned short* BT = btrace + (size_t)b * T * L;
     const float* K = links + (size_t)b * L * TR;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_blk_kernel(const floa
     __syncthreads();
     if (valid) {
         for (int t = Tb - 1; t >= 0; --t) {
-            const int pos = s_pos;
+            const int pos = s_pos[t & 1];
             if (pos < 0) break;
             if (tid == 0) lp[pos] = t;
             if (t == 0) break;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_blk_kernel(const floa
                     const float b2 = __shfl_xor(best, o, 64); const int a2 = __shfl_xor(arg, o, 64);
                     if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
                 }
-                if (lane == 0) s_pos = (best == NEG_INF) ? -1 : arg;
+                if (lane == 0) s_pos[(t - 1) & 1] = (best == NEG_INF) ? -1 : arg;
             }
             __syncthreads();
         }

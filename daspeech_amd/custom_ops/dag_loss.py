@@ -64,6 +64,12 @@ def _check_dp_args(name, match_all, links, output_length, target_length):
 
 
 def _f32c(t: Tensor) -> Tensor:
+    """fp32 working copy (a no-op for the fp32 contiguous tensors the criteria pass).  fp16 / bf16 inputs are WIDENED — the DP runs in
+    fp32 where the reference's half instantiation accumulates in half (dag_loss.cu:160), results go back in the caller's dtype.  float64
+    is refused: the reference dispatches a double instantiation, these kernels have none, and narrowing silently would hand back fp32
+    accuracy in a double tensor (use torch_dag_loss / torch_dag_best_alignment for double)."""
+    if t.dtype == torch.float64:
+        raise RuntimeError("the HIP DAG ops compute in float32: float64 inputs are not supported (cast to float32, or use the torch_* variants)")
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -154,9 +160,11 @@ class DagLossWithAlphaBetaFunc(Function):
         m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
         ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
         ctx.in_dtypes = (match_all.dtype, links.dtype)
-        ctx.mark_non_differentiable(alpha)
-        if beta is not None:
-            ctx.mark_non_differentiable(beta)
+        if beta is None:
+            # no gradient required: the reference launches no beta kernel and hands back the table as allocated, all zeros
+            # (dag_loss.cu:339-340,355-371) — callers (the expect strategy in validation / while the DAG is frozen) compute with it
+            beta = torch.zeros_like(alpha)
+        ctx.mark_non_differentiable(alpha, beta)
         return loss.to(match_all.dtype), (alpha, beta)
 
     @staticmethod

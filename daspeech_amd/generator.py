@@ -51,7 +51,9 @@ class S2SNATGenerator:
         prev = model.initialize_output_tokens_by_src(net["src_lengths"], max_src_len=net["src_tokens"].shape[1])
         dec = model.forward_decoder(prev, enc)
         tts_in = model.adaptor(dec["features"])
-        mel, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
+        mel, mel_post, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
+        if mel_post is not None:                                                                             # s2s_nat_generator.py:254-255
+            mel = mel_post
         return {"mel": self.gcmvn_denormalize(mel), "out_lens": out_lens, "tokens": dec["output_tokens"]}
 
     # ---- stage 2: mel -> waveforms on the CURRENT stream; `lens` = out_lens on the host

@@ -11,6 +11,8 @@ The DAG ops and the graph decode are the HIP kernels of this repo (daspeech_amd.
 Random weights of the released architecture (README.md:288-300) are what the synthetic benchmarks use.
 """
 import math
+import random
+from contextlib import contextmanager
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -29,7 +31,13 @@ DEFAULT_ARGS = dict(
     decoder_layers=4, decoder_embed_dim=512, decoder_ffn_embed_dim=2048, decoder_attention_heads=8,
     vocab_size=512, max_target_positions=1024, src_upsample_scale=0.5, max_transition_length=99999,
     decode_strategy="lookahead", decode_beta=1.0, decode_viterbibeta=1.0, adaptor_ffn_dim=1024,
+    # README.md:241-243,300-302: --dropout 0.1 --attention-dropout 0.1 --relu-dropout 0.1 (active in train() mode only, at the reference's sites)
+    dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
 )
+
+
+def _drop(x: Tensor, p: float, training: bool) -> Tensor:
+    return F.dropout(x, p, True) if training and p > 0 else x
 
 
 # ------------------------------------------------------------------------------------------------ Conformer encoder
@@ -109,9 +117,10 @@ def rel_positional_encoding(T: int, dim: int, device, dtype) -> Tensor:
 
 
 class RelPosSelfAttention(nn.Module):
-    def __init__(self, dim, heads):
+    def __init__(self, dim, heads, dropout=0.0):
         super().__init__()
         self.h, self.dk = heads, dim // heads
+        self.p_attn = dropout                       # on the attention probabilities (espnet_multihead_attention.py:40,82)
         self.linear_q, self.linear_k, self.linear_v, self.linear_out = (nn.Linear(dim, dim) for _ in range(4))
         self.linear_pos = nn.Linear(dim, dim, bias=False)
         self.pos_bias_u = nn.Parameter(torch.zeros(heads, self.dk))
@@ -141,18 +150,19 @@ class RelPosSelfAttention(nn.Module):
         scores = (ac + bd) / math.sqrt(self.dk)
         if pad_mask is not None:
             scores = scores.masked_fill(pad_mask.view(B, 1, 1, T), float("-inf"))
-        att = torch.softmax(scores, dim=-1)
+        att = _drop(torch.softmax(scores, dim=-1), self.p_attn, self.training)
         return decode_ops.linear(torch.matmul(att, v).transpose(1, 2).reshape(B, T, C), self.linear_out, residual=residual)
 
 
 class ConformerLayer(nn.Module):
-    def __init__(self, dim, ffn, heads, dw_kernel):
+    def __init__(self, dim, ffn, heads, dw_kernel, dropout=0.0):
         super().__init__()
+        self.p = dropout                            # one rate for every dropout of the layer (conformer_layer.py:175-227)
         def ffn_block():
             return nn.ModuleDict(dict(layer_norm=nn.LayerNorm(dim), w_1=nn.Linear(dim, ffn), w_2=nn.Linear(ffn, dim)))
         self.ffn1, self.ffn2 = ffn_block(), ffn_block()
         self.self_attn_layer_norm = nn.LayerNorm(dim)
-        self.self_attn = RelPosSelfAttention(dim, heads)
+        self.self_attn = RelPosSelfAttention(dim, heads, dropout)
         self.conv_module = nn.ModuleDict(dict(
             layer_norm=nn.LayerNorm(dim), pointwise_conv1=nn.Conv1d(dim, 2 * dim, 1, bias=False),
             depthwise_conv=nn.Conv1d(dim, dim, dw_kernel, padding=(dw_kernel - 1) // 2, groups=dim, bias=False),
@@ -169,15 +179,17 @@ class ConformerLayer(nn.Module):
         c = self.conv_module
         if self.training or torch.is_grad_enabled():
             # training: plain torch ops only (the step is host-launch bound: every helper indirection and extra view costs)
-            def ffn(m, x):
-                return x + 0.5 * m["w_2"](F.silu(m["w_1"](m["layer_norm"](x))))
+            p, tr = self.p, self.training
+
+            def ffn(m, x):                          # conformer_layer.py:140-146: dropout1 after the activation, dropout2 after w_2
+                return x + 0.5 * _drop(m["w_2"](_drop(F.silu(m["w_1"](m["layer_norm"](x))), p, tr)), p, tr)
             x = ffn(self.ffn1, x)
-            x = x + self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask)
+            x = x + _drop(self.self_attn(self.self_attn_layer_norm(x), pos, pad_mask), p, tr)          # :267
             # the two pointwise (kernel 1) convolutions are GEMMs on the [B,T,C] layout the layer already has: F.linear on the
             # checkpoint's [out, in, 1] weights instead of Conv1d, which MIOpen runs as im2col + GEMM between two transposes
             y = F.glu(F.linear(c["layer_norm"](x), c["pointwise_conv1"].weight.squeeze(-1)), dim=-1)
             y = F.silu(c["batch_norm"](c["depthwise_conv"](y.transpose(1, 2))))
-            x = x + F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1))
+            x = x + _drop(F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1)), p, tr)  # :100
             x = ffn(self.ffn2, x)
             return self.final_layer_norm(x)
         x = self._ffn(self.ffn1, x)
@@ -200,14 +212,15 @@ class ConformerEncoder(nn.Module):
         self.embed_scale = math.sqrt(a.encoder_embed_dim)
         self.linear = nn.Linear(a.encoder_embed_dim, a.encoder_embed_dim)
         self.conformer_layers = nn.ModuleList(
-            ConformerLayer(a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.encoder_attention_heads, a.depthwise_kernel)
+            ConformerLayer(a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.encoder_attention_heads, a.depthwise_kernel, a.dropout)
             for _ in range(a.encoder_layers))
+        self.p = a.dropout
 
     def forward(self, src_tokens: Tensor, src_lengths: Tensor) -> Dict[str, Tensor]:
         x, lens = self.subsample(src_tokens, src_lengths)
         T = x.shape[1]
         pad_mask = torch.arange(T, device=x.device).unsqueeze(0) >= lens.unsqueeze(1)
-        x = decode_ops.linear(self.embed_scale * x, self.linear)
+        x = _drop(decode_ops.linear(self.embed_scale * x, self.linear), self.p, self.training)        # s2t_conformer.py:119-120
         pos = rel_positional_encoding(T, x.shape[-1], x.device, x.dtype)
         for layer in self.conformer_layers:
             x = layer(x, pos, pad_mask)
@@ -216,10 +229,11 @@ class ConformerEncoder(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ NAT decoder + links head
 class _MHA(nn.Module):
-    def __init__(self, dim, heads, kdim=None):
+    def __init__(self, dim, heads, kdim=None, dropout=0.0):
         super().__init__()
         kdim = kdim or dim
         self.h = heads
+        self.p_attn = dropout                       # --attention-dropout, on the attention probabilities (multihead_attention.py)
         self.q_proj, self.out_proj = nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.k_proj, self.v_proj = nn.Linear(kdim, dim), nn.Linear(kdim, dim)
 
@@ -233,24 +247,26 @@ class _MHA(nn.Module):
         mask = None
         if mem_pad is not None:
             mask = torch.zeros(B, 1, 1, M, dtype=x.dtype, device=x.device).masked_fill(mem_pad.view(B, 1, 1, M), float("-inf"))
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.p_attn if self.training else 0.0)
         return decode_ops.linear(o.transpose(1, 2).reshape(B, N, C), self.out_proj, residual=residual)
 
 
 class NATDecoderLayer(nn.Module):
     """Post-norm Transformer decoder layer without causal mask (modules/transformer_layer.py, NAT usage)."""
 
-    def __init__(self, dim, ffn, heads, enc_dim):
+    def __init__(self, dim, ffn, heads, enc_dim, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0):
         super().__init__()
-        self.self_attn, self.self_attn_layer_norm = _MHA(dim, heads), nn.LayerNorm(dim)
-        self.encoder_attn, self.encoder_attn_layer_norm = _MHA(dim, heads, enc_dim), nn.LayerNorm(dim)
+        self.p, self.p_act = dropout, activation_dropout                                  # transformer_layer.py:263-298
+        self.self_attn, self.self_attn_layer_norm = _MHA(dim, heads, dropout=attention_dropout), nn.LayerNorm(dim)
+        self.encoder_attn, self.encoder_attn_layer_norm = _MHA(dim, heads, enc_dim, dropout=attention_dropout), nn.LayerNorm(dim)
         self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
 
     def forward(self, x, self_pad, enc, enc_pad):
         if self.training or torch.is_grad_enabled():
-            x = self.self_attn_layer_norm(x + self.self_attn(x, x, self_pad))
-            x = self.encoder_attn_layer_norm(x + self.encoder_attn(x, enc, enc_pad))
-            return self.final_layer_norm(x + self.fc2(F.gelu(self.fc1(x))))
+            p, tr = self.p, self.training                                                 # transformer_layer.py:467,497,507,511
+            x = self.self_attn_layer_norm(x + _drop(self.self_attn(x, x, self_pad), p, tr))
+            x = self.encoder_attn_layer_norm(x + _drop(self.encoder_attn(x, enc, enc_pad), p, tr))
+            return self.final_layer_norm(x + _drop(self.fc2(_drop(F.gelu(self.fc1(x)), self.p_act, tr)), p, tr))
         x = decode_ops.layer_norm(self.self_attn(x, x, self_pad, residual=x), self.self_attn_layer_norm)
         x = decode_ops.layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x), self.encoder_attn_layer_norm)
         return decode_ops.layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x), self.final_layer_norm)
@@ -264,8 +280,8 @@ class DAGDecoder(nn.Module):
         self.embed_tokens = nn.Embedding(a.vocab_size, d, padding_idx=PAD)
         self.embed_positions = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.embed_scale = math.sqrt(d)
-        self.layers = nn.ModuleList(NATDecoderLayer(d, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.encoder_embed_dim)
-                                    for _ in range(a.decoder_layers))
+        self.layers = nn.ModuleList(NATDecoderLayer(d, a.decoder_ffn_embed_dim, a.decoder_attention_heads, a.encoder_embed_dim,
+                                                    a.dropout, a.attention_dropout, a.activation_dropout) for _ in range(a.decoder_layers))
         # links head (s2t_conformer_dag.py:75-92: links_feature = feature:position)
         self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
@@ -279,6 +295,7 @@ class DAGDecoder(nn.Module):
 
     def extract_features(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]) -> Tensor:
         x = self.embed_scale * self.embed_tokens(prev_output_tokens) + self.embed_positions(self.positions(prev_output_tokens))
+        x = _drop(x, self.a.dropout, self.training)                                       # nonautoregressive_transformer.py:349
         pad = prev_output_tokens.eq(PAD)
         for layer in self.layers:
             x = layer(x, pad, enc["encoder_out"], enc["encoder_padding_mask"])
@@ -298,7 +315,11 @@ class DAGDecoder(nn.Module):
         k = decode_ops.linear(fp, self.key_linear).view(B, L, h, ck).float()
         log_gates = F.log_softmax(decode_ops.linear(fp, self.gate_linear), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
-        if feats.is_cuda and h == 8 and ck in (32, 64, 128) and TR >= 1 and self.fused_links \
+        # the fused kernels keep one tile's scores in LDS: XL_IT = 4 rows x (ck + TR rounded up to 32 + 2) x 8 heads floats <= 150 KB
+        # (csrc/extract_links.hip xl_check) — TR up to ~1100 at ck = 64, i.e. every graph the README's limits produce; wider windows take
+        # the torch band formulation below instead of raising
+        fits_lds = 4 * 8 * (ck + (TR + 31) // 32 * 32 + 2) * 4 <= 150 * 1024
+        if feats.is_cuda and h == 8 and ck in (32, 64, 128) and TR >= 1 and self.fused_links and fits_lds \
                 and not (dist_bias is not None and dist_bias.requires_grad and torch.is_grad_enabled()):
             # the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather; under autograd the backward
             # recomputes the scores tile by tile from q, k and [B,L,h] soft-max state (dsp_extract_links_bwd)
@@ -322,6 +343,21 @@ class DAGDecoder(nn.Module):
         band = band.masked_fill(nouse.view(B, L, 1, 1), float("-inf"))
         from ..custom_ops import logsumexp_keepdim                 # -inf safe (no NaN gradients on fully masked entries)
         return logsumexp_keepdim(band + log_gates.unsqueeze(2), -1).squeeze(-1).masked_fill(invalid, float("-inf"))
+
+
+@contextmanager
+def _same_draws(seed: int, device, active: bool):
+    """The reference runs both decoder passes of the GLAT forward under `torch_seed(rand_seed)` (s2t_conformer_dag.py:39-50,214-215): the
+    same dropout masks in the glancing pass and in the training pass, the surrounding random stream untouched."""
+    if not active or device.type != "cuda":
+        yield
+        return
+    state = torch.cuda.get_rng_state(device)
+    torch.cuda.manual_seed(seed)
+    try:
+        yield
+    finally:
+        torch.cuda.set_rng_state(state, device)
 
 
 # ------------------------------------------------------------------------------------------------ models
@@ -396,9 +432,12 @@ class S2TConformerDAGModel(nn.Module):
         prev_output_tokens, glat, links=links)`, pass 2 produces word_ins / links / features; glat_info is merged into the result."""
         enc = self.encoder(src_tokens, src_lengths)
         glat_info = None
+        seeded = self.training and max(self.args.dropout, self.args.attention_dropout, self.args.activation_dropout) > 0
+        rand_seed = random.randint(0, 19260817) if seeded else 0                                             # s2t_conformer_dag.py:242
         if glat and glat_function is not None and tgt_tokens is not None:
             with torch.set_grad_enabled(bool(glat.get("require_glance_grad", False)) and torch.is_grad_enabled()):
-                logits, links, _ = self.decode_graph(prev_output_tokens, enc)
+                with _same_draws(rand_seed, src_tokens.device, seeded):
+                    logits, links, _ = self.decode_graph(prev_output_tokens, enc)
                 prev_output_tokens, tgt_tokens, glat_info = glat_function(self, logits, tgt_tokens, prev_output_tokens, glat, links=links)
                 logits = None
             # Under torch.autocast the first pass has just filled the autocast cache with low-precision copies of the decoder's
@@ -407,7 +446,8 @@ class S2TConformerDAGModel(nn.Module):
             # pure fp16 model under fairseq's FP16Optimizer and has no such cache.
             if torch.is_autocast_enabled() and torch.is_grad_enabled():
                 torch.clear_autocast_cache()
-        logits, links, feats = self.decode_graph(prev_output_tokens, enc)
+        with _same_draws(rand_seed, src_tokens.device, seeded):
+            logits, links, feats = self.decode_graph(prev_output_tokens, enc)
         ret = {"word_ins": {"out": logits, "tgt": tgt_tokens, "mask": tgt_tokens.ne(self.pad) if tgt_tokens is not None else None,
                             "nll_loss": True, "features": feats},
                "links": links, "prev_output_tokens": prev_output_tokens}
@@ -438,5 +478,6 @@ class S2SConformerDAGFastSpeech2Model(S2TConformerDAGModel):
         tts_kw = kw.pop("tts", {})
         super().__init__(**kw)
         a = self.args
+        tts_kw = {"dropout": a.dropout, "attention_dropout": a.attention_dropout, **tts_kw}                 # one args namespace in the reference
         self.tts = FastSpeech2NoEmb(**tts_kw)
-        self.adaptor = FFNAdapter(a.decoder_embed_dim, a.adaptor_ffn_dim, self.tts.args.embed_dim)
+        self.adaptor = FFNAdapter(a.decoder_embed_dim, a.adaptor_ffn_dim, self.tts.args.embed_dim, a.dropout)  # s2s_conformer_dag_fastspeech2.py:71-76

@@ -23,26 +23,37 @@ DEFAULT_TTS_ARGS = dict(
     adaptor_in=512, adaptor_hidden=1024, embed_dim=256, heads=4, fft_hidden_dim=1024, fft_kernel_size=9, enc_layers=4,
     dec_layers=4, var_pred_hidden_dim=256, var_pred_kernel_size=3, var_pred_n_bins=256, pitch_min=-4.6600, pitch_max=5.7333,
     energy_min=-4.9544, energy_max=3.2244, out_dim=80, max_positions=1200,
+    # --add-postnet and its sizes (s2s_conformer_dag_fastspeech2.py:114-119, defaults :430-435); off in the released recipe
+    # dropout rates (train() mode only): --dropout / --attention-dropout shared with the translation model, var_pred_dropout 0.5
+    # (fastspeech2.py base_architecture)
+    dropout=0.1, attention_dropout=0.1, var_pred_dropout=0.5,
+    add_postnet=False, postnet_dropout=0.5, postnet_layers=5, postnet_conv_dim=512, postnet_conv_kernel_size=5,
 )
 
 
+def _drop(x: Tensor, p: float, training: bool) -> Tensor:
+    return F.dropout(x, p, True) if training and p > 0 else x
+
+
 class FFNAdapter(nn.Module):
-    def __init__(self, input_size: int, hidden_size: int, output_size: int):
+    def __init__(self, input_size: int, hidden_size: int, output_size: int, dropout: float = 0.1):
         super().__init__()
         self.fc1 = nn.Linear(input_size, hidden_size)
         self.fc2 = nn.Linear(hidden_size, output_size)
+        self.p = dropout
 
     def forward(self, x: Tensor) -> Tensor:
         from ..decode_ops import linear
-        return linear(linear(x, self.fc1, act="relu"), self.fc2)
+        return linear(_drop(linear(x, self.fc1, act="relu"), self.p, self.training), self.fc2)
 
 
 class _SelfAttention(nn.Module):
     """fairseq MultiheadAttention parameter names (q_proj / k_proj / v_proj / out_proj), self-attention only."""
 
-    def __init__(self, dim: int, heads: int):
+    def __init__(self, dim: int, heads: int, dropout: float = 0.0):
         super().__init__()
         self.heads = heads
+        self.p_attn = dropout
         self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(dim, dim) for _ in range(4))
 
     def forward(self, x: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
@@ -55,13 +66,14 @@ class _SelfAttention(nn.Module):
         mask = None
         if padding_mask is not None:
             mask = torch.zeros(B, 1, 1, N, dtype=x.dtype, device=x.device).masked_fill(padding_mask.view(B, 1, 1, N), float("-inf"))
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.p_attn if self.training else 0.0)
         return L_(o.transpose(1, 2).reshape(B, N, C), self.out_proj)
 
 
 class _ConvFFN(nn.Module):
-    def __init__(self, dim: int, hidden: int, kernel: int):
+    def __init__(self, dim: int, hidden: int, kernel: int, dropout: float = 0.0):
         super().__init__()
+        self.p = dropout                                     # after the second convolution (fastspeech2.py:62-70)
         pad = (kernel - 1) // 2
         self.ffn = nn.Sequential(nn.Conv1d(dim, hidden, kernel, padding=pad), nn.ReLU(), nn.Conv1d(hidden, dim, kernel, padding=pad))
         self.layer_norm = nn.LayerNorm(dim)
@@ -81,15 +93,15 @@ class _ConvFFN(nn.Module):
                 self._split_key = key
             if self._split is not None:
                 return _dops.layer_norm(self._split[1](self._split[0](x, relu=True), residual=x), self.layer_norm)
-        return self.layer_norm(self.ffn(x.transpose(1, 2)).transpose(1, 2) + x)
+        return self.layer_norm(_drop(self.ffn(x.transpose(1, 2)).transpose(1, 2), self.p, self.training) + x)
 
 
 class FFTLayer(nn.Module):
-    def __init__(self, dim: int, heads: int, hidden: int, kernel: int):
+    def __init__(self, dim: int, heads: int, hidden: int, kernel: int, dropout: float = 0.0, attention_dropout: float = 0.0):
         super().__init__()
-        self.self_attn = _SelfAttention(dim, heads)
+        self.self_attn = _SelfAttention(dim, heads, attention_dropout)
         self.layer_norm = nn.LayerNorm(dim)
-        self.ffn = _ConvFFN(dim, hidden, kernel)
+        self.ffn = _ConvFFN(dim, hidden, kernel, dropout)
 
     def forward(self, x: Tensor, padding_mask: Optional[Tensor] = None) -> Tensor:
         from ..decode_ops import layer_norm as _ln
@@ -100,8 +112,9 @@ class FFTLayer(nn.Module):
 class VariancePredictor(nn.Module):
     """Conv1d-ReLU-LN-Conv1d-ReLU-LN-Linear (fastspeech2.py:117-151); dropout is identity at inference."""
 
-    def __init__(self, dim: int, hidden: int, kernel: int):
+    def __init__(self, dim: int, hidden: int, kernel: int, dropout: float = 0.0):
         super().__init__()
+        self.p = dropout                                     # after each LayerNorm (fastspeech2.py:128-130,147-150)
         self.conv1 = nn.Sequential(nn.Conv1d(dim, hidden, kernel, padding=(kernel - 1) // 2), nn.ReLU())
         self.ln1 = nn.LayerNorm(hidden)
         self.conv2 = nn.Sequential(nn.Conv1d(hidden, hidden, kernel, padding=1), nn.ReLU())
@@ -126,8 +139,8 @@ class VariancePredictor(nn.Module):
                 h = _dops.layer_norm(self._split[0](x, relu=True), self.ln1)
                 h = _dops.layer_norm(self._split[1](h, relu=True), self.ln2)
                 return self.proj(h).squeeze(2)
-        x = self.ln1(self.conv1(x.transpose(1, 2)).transpose(1, 2))
-        x = self.ln2(self.conv2(x.transpose(1, 2)).transpose(1, 2))
+        x = _drop(self.ln1(self.conv1(x.transpose(1, 2)).transpose(1, 2)), self.p, self.training)
+        x = _drop(self.ln2(self.conv2(x.transpose(1, 2)).transpose(1, 2)), self.p, self.training)
         return self.proj(x).squeeze(2)
 
 
@@ -137,11 +150,11 @@ class VarianceAdaptor(nn.Module):
     layers, the adaptor and both embedding tables as in the reference."""
 
     def __init__(self, dim: int, hidden: int, kernel: int, n_bins: int, pitch_min: float, pitch_max: float,
-                 energy_min: float, energy_max: float):
+                 energy_min: float, energy_max: float, dropout: float = 0.0):
         super().__init__()
-        self.duration_predictor = VariancePredictor(dim, hidden, kernel)
-        self.pitch_predictor = VariancePredictor(dim, hidden, kernel)
-        self.energy_predictor = VariancePredictor(dim, hidden, kernel)
+        self.duration_predictor = VariancePredictor(dim, hidden, kernel, dropout)
+        self.pitch_predictor = VariancePredictor(dim, hidden, kernel, dropout)
+        self.energy_predictor = VariancePredictor(dim, hidden, kernel, dropout)
         self.register_buffer("pitch_bins", torch.linspace(pitch_min, pitch_max, n_bins - 1), persistent=False)
         self.register_buffer("energy_bins", torch.linspace(energy_min, energy_max, n_bins - 1), persistent=False)
         self.embed_pitch = nn.Embedding(n_bins, dim)
@@ -184,6 +197,29 @@ class VarianceAdaptor(nn.Module):
         return x, out_lens, log_dur_out, pitch_out, energy_out
 
 
+class Postnet(nn.Module):
+    """fairseq/fairseq/models/text_to_speech/tacotron2.py:111-140: `n_layers` x [Conv1d(k, "same") -> BatchNorm1d -> tanh (all but the
+    last) -> dropout], channels in_dim -> n_channels ... -> in_dim; same parameter names (`convolutions.{i}.0` conv, `.1` batch norm), same
+    initialisation.  Plain torch (MIOpen): the branch is off in the released recipe (README.md:288-323 has no --add-postnet)."""
+
+    def __init__(self, in_dim: int, n_channels: int, kernel_size: int, n_layers: int, dropout: float):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.convolutions = nn.ModuleList()
+        for i in range(n_layers):
+            last = i == n_layers - 1
+            layers = [nn.Conv1d(in_dim if i == 0 else n_channels, in_dim if last else n_channels, kernel_size, padding=(kernel_size - 1) // 2),
+                      nn.BatchNorm1d(in_dim if last else n_channels)] + ([] if last else [nn.Tanh()]) + [nn.Dropout(dropout)]
+            nn.init.xavier_uniform_(layers[0].weight, nn.init.calculate_gain("linear" if last else "tanh"))
+            self.convolutions.append(nn.Sequential(*layers))
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x.transpose(1, 2)
+        for conv in self.convolutions:
+            x = conv(x)
+        return x.transpose(1, 2)
+
+
 def sinusoidal_table(n: int, dim: int, padding_idx: int = 1) -> Tensor:
     """modules/sinusoidal_positional_embedding.py:36-58: [sin | cos] halves, row `padding_idx` zeroed."""
     half = dim // 2
@@ -211,23 +247,28 @@ class FastSpeech2NoEmb(nn.Module):
         self.pos_emb_alpha = nn.Parameter(torch.ones(1))
         self.dec_pos_emb_alpha = nn.Parameter(torch.ones(1))
         self.register_buffer("pos_table", sinusoidal_table(a.max_positions + 2, a.embed_dim), persistent=False)
-        self.encoder_fft_layers = nn.ModuleList(FFTLayer(a.embed_dim, a.heads, a.fft_hidden_dim, a.fft_kernel_size) for _ in range(a.enc_layers))
+        fft = lambda: FFTLayer(a.embed_dim, a.heads, a.fft_hidden_dim, a.fft_kernel_size, a.dropout, a.attention_dropout)   # noqa: E731
+        self.encoder_fft_layers = nn.ModuleList(fft() for _ in range(a.enc_layers))
         self.var_adaptor = VarianceAdaptor(a.embed_dim, a.var_pred_hidden_dim, a.var_pred_kernel_size, a.var_pred_n_bins,
-                                           a.pitch_min, a.pitch_max, a.energy_min, a.energy_max)
-        self.decoder_fft_layers = nn.ModuleList(FFTLayer(a.embed_dim, a.heads, a.fft_hidden_dim, a.fft_kernel_size) for _ in range(a.dec_layers))
+                                           a.pitch_min, a.pitch_max, a.energy_min, a.energy_max, a.var_pred_dropout)
+        self.decoder_fft_layers = nn.ModuleList(fft() for _ in range(a.dec_layers))
         self.out_proj = nn.Linear(a.embed_dim, a.out_dim)
+        self.out_dim = a.out_dim
+        self.postnet = Postnet(a.out_dim, a.postnet_conv_dim, a.postnet_conv_kernel_size, a.postnet_layers, a.postnet_dropout) \
+            if a.add_postnet else None                                                                       # fastspeech2_noemb.py:128-136
 
     def _pos(self, padding_mask: Tensor) -> Tensor:
         idx = positions_from_padding_mask(padding_mask).clamp(max=self.pos_table.shape[0] - 1)
         return self.pos_table[idx]
 
     def forward(self, x: Tensor, padding_mask: Tensor, durations=None, pitches=None, energies=None):
-        """x [B,N,256] adaptor output, padding_mask [B,N] bool -> (mel [B,F,80], out_lens, log_dur, pitch, energy)
-        (fastspeech2_noemb.py:140-174)."""
+        """x [B,N,256] adaptor output, padding_mask [B,N] bool -> (mel [B,F,80], mel_post or None, out_lens, log_dur, pitch, energy):
+        the reference's six values in its order (fastspeech2_noemb.py:140-174; `mel_post = mel + postnet(mel)` only with --add-postnet)."""
         if x.shape[1] == 0:                       # nothing decoded (the reference would fail in torch.cat([]), SURVEY §9.2)
             z = x.new_zeros(x.shape[0], 0)
-            return x.new_zeros(x.shape[0], 0, self.args.out_dim), x.new_zeros(x.shape[0], dtype=torch.long), z, z, z
-        x = x + self.pos_emb_alpha * self._pos(padding_mask)
+            mel0 = x.new_zeros(x.shape[0], 0, self.args.out_dim)
+            return mel0, (mel0 if self.postnet is not None else None), x.new_zeros(x.shape[0], dtype=torch.long), z, z, z
+        x = _drop(x + self.pos_emb_alpha * self._pos(padding_mask), self.args.dropout, self.training)       # fastspeech2_noemb.py:150-151
         for layer in self.encoder_fft_layers:
             x = layer(x, padding_mask)
         x, out_lens, log_dur, pitch, energy = self.var_adaptor(x, padding_mask, durations, pitches, energies)
@@ -237,4 +278,6 @@ class FastSpeech2NoEmb(nn.Module):
         for layer in self.decoder_fft_layers:
             x = layer(x, dec_mask)
         from ..decode_ops import linear as _lin
-        return _lin(x.contiguous(), self.out_proj), out_lens, log_dur, pitch, energy
+        mel = _lin(x.contiguous(), self.out_proj)
+        mel_post = mel + self.postnet(mel) if self.postnet is not None else None                             # :171-173
+        return mel, mel_post, out_lens, log_dur, pitch, energy

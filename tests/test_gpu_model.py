@@ -53,7 +53,7 @@ def test_mel_loss_alone_reaches_adaptor_encoder_and_embeddings():
     feats = torch.randn(2, int(s["target_text_lengths"].max()) - 1, 512, device="cuda")
     tlen = s["target_text_lengths"] - 1
     pmask = torch.arange(feats.shape[1], device="cuda").unsqueeze(0) >= tlen.unsqueeze(1)
-    mel, out_lens, _, _, _ = m.tts(m.adaptor(feats), pmask, durations=s["durations"], pitches=s["pitches"], energies=s["energies"])
+    mel, _, out_lens, _, _, _ = m.tts(m.adaptor(feats), pmask, durations=s["durations"], pitches=s["pitches"], energies=s["energies"])
     assert out_lens.tolist() == s["durations"].sum(1).tolist()
     F.l1_loss(mel, torch.zeros_like(mel)).backward()
     for p in (m.adaptor.fc1.weight, m.tts.encoder_fft_layers[0].ffn.ffn[0].weight, m.tts.var_adaptor.embed_pitch.weight,
@@ -277,7 +277,7 @@ def test_c4_s2st_full_size_properties():
         enc = m.forward_encoder(ni["src_tokens"], ni["src_lengths"])
         prev = m.initialize_output_tokens_by_src(ni["src_lengths"], max_src_len=ni["src_tokens"].shape[1])
         dec = m.forward_decoder(prev, enc)
-        _, out_lens, log_dur, _, _ = m.tts(m.adaptor(dec["features"]), dec["features_padding_mask"])
+        _, _, out_lens, log_dur, _, _ = m.tts(m.adaptor(dec["features"]), dec["features_padding_mask"])
         dur = torch.clamp(torch.round(torch.exp(log_dur) - 1).long(), min=0).masked_fill(dec["features_padding_mask"], 0)
     assert out_lens.tolist() == dur.sum(1).tolist()
     for b, o in enumerate(out):

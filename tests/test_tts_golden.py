@@ -183,8 +183,8 @@ def _noemb_from_seed(g, device):
 def _check_noemb(m, g, device, mel_rtol):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     with torch.no_grad():
-        mel, out_lens, log_dur, pitch, energy = m(t(g["x"]), t(g["pad"]))
-        mel2, out_lens2, log_dur2, pitch2, energy2 = m(t(g["x"]), t(g["pad"]), durations=t(g["tf_dur"]), pitches=t(g["tf_pitch_in"]),
+        mel, _, out_lens, log_dur, pitch, energy = m(t(g["x"]), t(g["pad"]))
+        mel2, _, out_lens2, log_dur2, pitch2, energy2 = m(t(g["x"]), t(g["pad"]), durations=t(g["tf_dur"]), pitches=t(g["tf_pitch_in"]),
                                                        energies=t(g["tf_energy_in"]))
         fft0 = m.encoder_fft_layers[0](t(g["x"]), t(g["pad"]))
     assert out_lens.tolist() == g["inf_out_lens"].tolist() and out_lens2.tolist() == g["tf_out_lens"].tolist()
@@ -218,7 +218,7 @@ def test_variance_adaptor_training_path_is_differentiable(golden_dir):
     g = load(golden_dir, "fastspeech2_noemb_seeded")
     m = _noemb_from_seed(g, "cpu").train()
     x = torch.from_numpy(g["x"]).requires_grad_()
-    mel, out_lens, log_dur, pitch, energy = m(x, torch.from_numpy(g["pad"]), durations=torch.from_numpy(g["tf_dur"]),
+    mel, _, out_lens, log_dur, pitch, energy = m(x, torch.from_numpy(g["pad"]), durations=torch.from_numpy(g["tf_dur"]),
                                               pitches=torch.from_numpy(g["tf_pitch_in"]), energies=torch.from_numpy(g["tf_energy_in"]))
     mel.abs().sum().backward()                      # the mel L1 term ALONE
     for p in (m.encoder_fft_layers[0].ffn.ffn[0].weight, m.var_adaptor.embed_pitch.weight, m.var_adaptor.embed_energy.weight,
