@@ -86,7 +86,9 @@ def test_postnet_branch_vs_reference_tts():
         assert tuple(got.shape) == ref.shape and np.abs(got.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-5
     # without the flag the slot is None and the generator keeps `mel` (s2s_nat_generator.py:254-255)
     from daspeech_amd.models.fastspeech2 import FastSpeech2NoEmb
-    assert FastSpeech2NoEmb(enc_layers=1, dec_layers=1).eval()(torch.randn(1, 4, 256), torch.zeros(1, 4, dtype=torch.bool))[1] is None
+    with torch.no_grad():
+        out = FastSpeech2NoEmb(enc_layers=1, dec_layers=1).eval()(torch.randn(1, 4, 256), torch.zeros(1, 4, dtype=torch.bool), durations=torch.full((1, 4), 2))
+    assert out[1] is None and tuple(out[0].shape) == (1, 8, 80)
 
 
 @pytest.mark.gpu
