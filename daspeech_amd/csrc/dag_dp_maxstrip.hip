@@ -150,6 +150,11 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
 #pragma unroll
                     for (int k = 0; k < 9; ++k) { w[4 * k] = pv[k].x; w[4 * k + 1] = pv[k].y; w[4 * k + 2] = pv[k].z; w[4 * k + 3] = pv[k].w; }
                     m2[0] = mt.x; m2[1] = mt.y; m2[2] = mt.z; m2[3] = mt.w;
+                } else if constexpr (CPL == 1) {
+                    const float* wp = Abuf + prv * RL + l;                      // 33 dwords, 4-byte aligned: ds_read2_b32 pairs
+#pragma unroll
+                    for (int k = 0; k < 33; ++k) w[k] = wp[k];
+                    m2[0] = Mring[(size_t)(it % MX_RING) * W + l];
                 } else {
                     mx_v2f mt, pl; mx_v4f pq[8];          // 17 eight-byte slots: eight ds_read2_b64 + one ds_read_b64
                     asm volatile(
@@ -198,6 +203,9 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
             if constexpr (CPL == 4) {
                 *reinterpret_cast<float4*>(Abuf + cur * RL + 32 + 4 * l) = make_float4(a[0], a[1], a[2], a[3]);
                 if (st_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
+            } else if constexpr (CPL == 1) {
+                Abuf[cur * RL + 32 + l] = a[0];
+                if (st_ok) O[(size_t)t * L + j] = a[0];
             } else {
                 *reinterpret_cast<float2*>(Abuf + cur * RL + 32 + 2 * l) = make_float2(a[0], a[1]);
                 if (st_ok) *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(a[0], a[1]);
@@ -210,6 +218,7 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
         if (prof && lane == 0) { for (int i = 0; i < 4; ++i) p.counters[8 + i] = (u32)(pf[i] >> 4); p.counters[12] = (u32)nrows; }
         if (col_ok) for (int t = Tb; t < T; ++t) {
             if constexpr (CPL == 4) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            else if constexpr (CPL == 1) O[(size_t)t * L + j] = NEG_INF;
             else *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(NEG_INF, NEG_INF);
         }
     } else if (wave == NCW) {
@@ -489,15 +498,19 @@ static int launch_one_mx(const MStripParams& p, int nwg, hipStream_t st)
     return check_launch("dag_best_alignment(maxstrip)");
 }
 
+static int g_mx_cpl = 0;                      // experiment switch (dsp_dag_set_option("mx_cpl", 1 | 2 | 4)): vertices per lane of the max-DP; 0 = auto
+void set_mx_cpl(int v) { g_mx_cpl = v; }
+
 // alpha_max by column strips (values only), then the lazy back-trace: no trace tensor
 int launch_dag_maxstrip(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                         float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
 {
     // one direction only: 4 vertices per lane in 1024-vertex strips when that still fills the chip (>= ~200 workgroups),
     // otherwise 2 vertices per lane in 512-vertex strips (twice the waves for the same vertices)
-    const int ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
-    const bool wide = (long)B * ns1024 >= 200;
-    const int NS = wide ? ns1024 : ns512;
+    const int ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512, ns256 = (L + 255) / 256;
+    const int cpl = g_mx_cpl == 1 || g_mx_cpl == 2 || g_mx_cpl == 4 ? g_mx_cpl : ((long)B * ns1024 >= 200 ? 4 : 2);
+    const bool wide = cpl == 4;
+    const int NS = cpl == 4 ? ns1024 : (cpl == 2 ? ns512 : ns256);
     MStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS;
@@ -509,7 +522,7 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     const size_t halo_bytes = (size_t)B * NS * T * MX_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;
-    rc = wide ? launch_one_mx<256, 4>(p, B * NS, st) : launch_one_mx<256, 2>(p, B * NS, st);
+    rc = wide ? launch_one_mx<256, 4>(p, B * NS, st) : (cpl == 2 ? launch_one_mx<256, 2>(p, B * NS, st) : launch_one_mx<256, 1>(p, B * NS, st));
     if (rc) return rc;
     const size_t lds2 = ((size_t)BT_LW * TR + BT_HOPS * BT_SEG + (size_t)L) * 4;
     (void)hipFuncSetAttribute((const void*)dag_backtrace_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

@@ -316,7 +316,11 @@ class DagLogsoftmaxGatherFunc(Function):
         else:
             buf, stats = _lsg_forward(word_ins_out, select_idx, need), None
         selected = buf.transpose(1, 2)                                         # [B, L, S] view
-        ctx.mark_dirty(word_ins_out)                                           # (lazy: written by the backward)
+        if need:
+            # (lazy: written by the backward.)  Without a gradient nothing is ever written: the buffer is NOT marked dirty, so a caller may
+            # run the gather on a `.detach()` of a tensor another graph still needs — the argmax strategy does (the reference, whose
+            # operator marks dirty unconditionally, dag_loss.py:272, pays a B*L*V clone for it, s2s_dag_fastspeech2_loss.py:215)
+            ctx.mark_dirty(word_ins_out)
         ctx.set_materialize_grads(False)
         if need:
             if ctx.lazy:
