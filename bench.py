@@ -125,6 +125,15 @@ class Ctx:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="nccl", device_id=self.dev)
             self.world = dist.get_world_size()            # n_gpus of the line comes from RCCL's world, not from the flag
+            assert self.world == args.gpus, f"RCCL world size {self.world} != --gpus {args.gpus}"
+            # one collective before anything is timed: every rank really is in the RCCL communicator, on its own device
+            probe = torch.tensor([1.0, float(torch.cuda.current_device())], device=self.dev)
+            dist.all_reduce(probe)
+            assert int(probe[0].item()) == self.world, f"all-reduce over {self.world} ranks summed to {probe[0].item()}"
+            if torch.cuda.device_count() >= self.world:
+                assert int(probe[1].item()) == self.world * (self.world - 1) // 2, "ranks share a device"
+            print(f"[bench] rank {self.rank}/{self.world} on cuda:{self.local_rank} ({torch.cuda.get_device_name(self.dev)}), RCCL all-reduce ok",
+                  file=sys.stderr, flush=True)
 
     def barrier(self):
         if self.world > 1:

@@ -204,6 +204,20 @@ def test_oracle_logsoftmax_gather(dtype, V):
 
 # ---------------------------------------------------------------------------------------------- full-size properties
 
+def _check_grads_against_oracle(match, links, ol, tl, gm, gl, bs, rtol=2e-3):
+    """grad_match / grad_links of utterance `bs` (d loss.sum()) against orc.dag_grad on fp64 alpha / beta of the same inputs."""
+    mm, kk = np.asarray(match[bs:bs + 1], np.float64), np.asarray(links[bs:bs + 1], np.float64)
+    o1, t1 = ol[bs:bs + 1].cpu().numpy(), tl[bs:bs + 1].cpu().numpy()
+    a64, b64 = orc.dag_alpha(mm, kk, o1, t1, np.float64), orc.dag_beta(mm, kk, o1, t1, np.float64)
+    gm64, gl64 = orc.dag_grad(np.ones(1), a64, b64, mm, kk, o1, t1, np.float64)
+    got_m, got_l = gm[bs].detach().cpu().numpy(), gl[bs].detach().cpu().numpy()
+    # a posterior is exp(alpha + beta - match - Z) with |alpha|, |Z| in the thousands: an fp32 ulp of those is the error floor
+    floor = 8 * np.spacing(np.float32(np.abs(a64[np.isfinite(a64)]).max()))
+    np.testing.assert_allclose(got_m, gm64[0], rtol=rtol + floor, atol=1e-7)
+    np.testing.assert_allclose(got_l, gl64[0], rtol=rtol + floor, atol=1e-7)
+    assert got_m.sum() == pytest.approx(float(t1[0]), rel=1e-3) and got_l.sum() == pytest.approx(float(t1[0] - 1), rel=1e-3)
+
+
 def _c2_inputs(TR, B=32, T=512, L=4096, seed=0):
     gen = torch.Generator(device="cpu").manual_seed(seed)
     out_len = L - torch.randint(0, 5, (B,), generator=gen)
@@ -260,6 +274,8 @@ def test_full_size_properties(TR):
     # compare with the max-DP score recomputed by torch on a banded formulation for a few samples
     ref = orc.dag_best_alignment(mc[:2], kc[:2], ol.cpu().numpy()[:2], tl.cpu().numpy()[:2], np.float32)
     np.testing.assert_array_equal(pc[:2], ref)
+    # ... and one utterance's GRADIENTS element by element against the fp64 oracle (K4 / K5 at full size, not only their row sums)
+    _check_grads_against_oracle(mc, kc, ol, tl, gm, gl, bs=7)
 
 
 # ---------------------------------------------------------------------------------------------- fast path vs generic
@@ -593,7 +609,9 @@ def test_dense_window_full_size_c1_and_readme_shape(shape):
     rows = gm.sum(-1)                                          # [B, T]: 1 on rows < T_b, 0 beyond
     want = (torch.arange(T, device=m.device).unsqueeze(0) < t.unsqueeze(1)).float()
     torch.testing.assert_close(rows, want, rtol=0, atol=2e-3)
+    _check_grads_against_oracle(match, links, o, t, gm, gk, bs=1)              # K4 / K5 element by element vs the fp64 oracle
     path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+    np.testing.assert_array_equal(path[:1], orc.dag_best_alignment(match[:1], links[:1], ol[:1], tl[:1], np.float32))
     for b in range(B):
         pos = np.nonzero(path[b] >= 0)[0]
         Tb, Lb = int(tl[b]), int(ol[b])
@@ -652,6 +670,9 @@ def test_dense_window_full_size_c2_tr4095():
             score = match[b, torch.arange(int(t[b]), device=m.device), pos].double().sum() + \
                 links[b, pos[:-1], pos[1:] - pos[:-1] - 1].double().sum()
             assert float(score) <= float(loss[b]) + 1e-3 * abs(float(loss[b]))
+        # ... and utterance 5's path against the ORACLE's sequential max-DP + back-trace, bit for bit (4.3e9 add / compare steps, fp32, the
+        # oracle's columns on all host cores)
+        np.testing.assert_array_equal(path[bs:bs + 1].cpu().numpy(), orc.dag_best_alignment(mm, kk, ol1, tl1, np.float32))
 
 
 def test_workspace_sizes_are_reported_and_library_scratch_still_works():
