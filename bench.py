@@ -455,26 +455,39 @@ def build_model_step(ctx, args, workload):
               + ("" if args.no_overlap else "; vocoder of batch i-1 on a second stream under the acoustic model of batch i") + f"), B={B}/GPU, fbank80 300-800 frames, {prec}")
     else:
         model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
-        # the reference trains with fairseq's --fp16 (README.md:241,274: fp16 compute, dynamic loss scaling); --amp bf16 selects bf16 autocast
-        use_fp16 = args.amp != "bf16"
-        train_dtype = torch.float16 if use_fp16 else torch.bfloat16
-        scaler = torch.amp.GradScaler("cuda", enabled=use_fp16, init_scale=2.0 ** 7)
+        if args.amp == "bf16":
+            # torch.autocast(bf16) over an fp32 model — NOT the reference's scheme, kept as a comparison leg
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
 
-        def step(i):
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=train_dtype):
-                loss, log = s2s_dag_fastspeech2_loss(model, batches[i % len(batches)], glat_p="0.5:0.1@200k", update_num=100000 + i)
-            scaler.scale(loss).backward()
-            all_reduce_gradients(model.parameters(), world)            # ONE flat bucket per dtype
-            scaler.unscale_(opt)
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-            scaler.step(opt)
-            scaler.update()
-            return loss
-        wl = (f"C5 DASpeech training step: s2s_dag_fastspeech2_loss (GLAT two-pass with number-random glancing, HIP DAG ops, expect strategy) fwd+bwd + "
-              f"flat-bucket gradient all-reduce + Adam, B={B}/GPU (global {B * world}), " + ("fp16 autocast + loss scaling" if use_fp16 else "bf16 autocast")
-              + " dense layers / fp32 DAG ops")
+            def step(i):
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss, log = s2s_dag_fastspeech2_loss(model, batches[i % len(batches)], glat_p="0.5:0.1@200k", update_num=100000 + i)
+                loss.backward()
+                all_reduce_gradients(model.parameters(), world)
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                return loss
+            scheme = "bf16 autocast over fp32 weights, Adam"
+        else:
+            # the reference's --fp16 (README.md:241,274): model.half(), fp16 batch, flat fp32 master + Adam, dynamic loss scaling
+            from daspeech_amd.fp16_trainer import FP16FlatOptimizer, half_sample
+            model.half()
+            hb = [half_sample(b) for b in batches]
+            state["batches"] = hb
+            opt = FP16FlatOptimizer(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, clip_norm=1.0, init_scale=2.0 ** 7)
+            state["opt"] = opt
+
+            def step(i):
+                opt.zero_grad()
+                loss, log = s2s_dag_fastspeech2_loss(model, hb[i % len(hb)], glat_p="0.5:0.1@200k", update_num=100000 + i)
+                opt.backward(loss)
+                all_reduce_gradients(model.parameters(), world)            # ONE flat fp16 bucket: sum / world
+                opt.step()                                                 # (x world / total sample_size = 1: sample_size is 1 per rank)
+                return loss
+            scheme = "fp16 model + fp16 batch, flat fp32 master weights, Adam (decoupled decay), dynamic loss scaling, clip-norm 1 — fairseq's --fp16"
+        wl = (f"C5 DASpeech training step: s2s_dag_fastspeech2_loss (GLAT two-pass with number-random glancing, HIP DAG ops in fp32, expect strategy, dropout "
+              f"0.1 / 0.1 / 0.1 as README) fwd+bwd + flat-bucket gradient all-reduce + optimizer, B={B}/GPU (global {B * world}), {scheme}")
     return step, wl, state
 
 
@@ -524,6 +537,9 @@ def run_model(ctx, args, workload, steps, warmup, sustain=0):
             rep["roofline"] = vocoder_roofline(ctx, args, state)
     if workload == "train":
         rep["peak_memory_GB"] = ctx.torch.cuda.max_memory_allocated() / 2 ** 30
+        if state.get("opt") is not None:
+            rep["loss_scale"] = state["opt"].scaler.loss_scale
+            rep["last_grad_norm"] = state["opt"].last_grad_norm
         rep["workload"] += ("; extract_links: torch [B,L,L,h] formulation" if getattr(args, "torch_links", False)
                             else "; extract_links: fused compact-band HIP forward + backward")
     state.clear()

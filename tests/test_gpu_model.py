@@ -337,3 +337,41 @@ def test_glat_two_pass_reaches_every_decoder_weight(amp):
     missing = [n for n, p in model.named_parameters() if p.grad is None]
     assert not missing, missing[:8]
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_fp16_model_training_step_as_the_reference_trains():
+    """The reference's --fp16 scheme (fairseq FP16Optimizer: model.half(), fp16 batch, flat fp32 master, dynamic loss scale — not autocast):
+    three steps of the released objective on a small model: finite loss, a gradient for every parameter, the loss on the same batch goes
+    down, the fp16 parameters follow the fp32 master, and an overflow halves the scale and skips the update."""
+    from daspeech_amd.criterions import s2s_dag_fastspeech2_loss
+    from daspeech_amd.fp16_trainer import FP16FlatOptimizer, half_sample
+    from daspeech_amd.synthetic import make_s2st_batch
+    model = small_model().half().train()
+    batch = half_sample(make_s2st_batch(3, "cuda", seed=2, min_frames=120, max_frames=160))
+    assert batch["net_input"]["src_tokens"].dtype == torch.float16 and batch["durations"].dtype == torch.long
+    opt = FP16FlatOptimizer(model.parameters(), lr=3e-4, init_scale=2.0 ** 7)
+    w0 = model.tts.out_proj.weight.detach().clone()
+    losses = []
+    for i in range(3):
+        opt.zero_grad()
+        torch.manual_seed(7)                                   # same glancing and dropout draws: comparable losses
+        loss, log = s2s_dag_fastspeech2_loss(model, batch, glat_p="0.5:0.1@200k", update_num=100000)
+        assert torch.isfinite(loss)
+        opt.backward(loss)
+        missing = [n for n, p in model.named_parameters() if p.grad is None]
+        assert not missing, missing[:8]
+        assert all(p.grad.dtype == torch.float16 for p in model.parameters())
+        assert opt.step() and np.isfinite(opt.last_grad_norm)
+        losses.append(float(loss))
+    assert losses[2] < losses[0], losses
+    assert not torch.equal(model.tts.out_proj.weight, w0)
+    n = model.tts.out_proj.weight.numel()
+    views = dict(zip((id(p) for p in opt.params), opt._mviews))
+    torch.testing.assert_close(model.tts.out_proj.weight.float(), views[id(model.tts.out_proj.weight)].half().float(), rtol=0, atol=0)
+    # overflow: an inf gradient -> the step is skipped, the scale halves, the master is untouched
+    scale, before = opt.scaler.loss_scale, opt.master.detach().clone()
+    opt.zero_grad()
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    model.tts.out_proj.weight.grad[0, 0] = float("inf")
+    assert opt.step() is False and opt.scaler.loss_scale == scale / 2 and torch.equal(opt.master.detach(), before)
