@@ -58,10 +58,6 @@ SIGNATURES = {
     "dsp_conv1d_split_packed_elems": (ctypes.c_long, [_c_int, _c_int, _c_int]),
     "dsp_conv1d_split_pack": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_conv1d_split": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
-    "dsp_conv1d_stream_packed_elems": (ctypes.c_long, [_c_int, _c_int, _c_int]),
-    "dsp_conv1d_stream_pack": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
-    "dsp_conv1d_stream": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_int,
-                                   _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_conv1d_split_residual": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_int,
                                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_relpos_attention": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),

@@ -443,16 +443,6 @@ class SplitConv1d:
         Cout, Cin, K = weight.shape
         self.Cout, self.Cin, self.K = Cout, Cin, K
         self.bias = None if bias is None else bias.detach().float().contiguous()
-        # r04: the K-streaming kernel (csrc/conv1d_stream.hip) serves every layer with >= 128 output channels and a multiple of 64 inputs
-        self.stream = bool(STREAM_CONV and Cin % 64 == 0 and Cout >= 128 and Cout % 4 == 0 and K % 2 == 1 and K <= 31)
-        if self.stream:
-            with torch.cuda.device(weight.device):
-                n = lib.dsp_conv1d_stream_packed_elems(K, Cout, Cin)
-                self.hi = torch.empty((n,), dtype=torch.float16, device=weight.device); self.lo = torch.empty_like(self.hi)
-                wt = weight.detach().float().permute(2, 0, 1).contiguous()                                              # [K][Cout][Cin]
-                _lib.check(lib.dsp_conv1d_stream_pack(_lib.ptr(wt), _lib.ptr(self.hi), _lib.ptr(self.lo), K, Cout, Cin, _lib.current_stream_handle()),
-                           "dsp_conv1d_stream_pack")
-            return
         step = Cin if Cin <= 512 else 512          # (256-channel slices with 128-row tiles were slower: 125 vs 95 us for 2048 -> 256)
         assert Cin % step == 0 and step in (128, 256, 512) and Cout % 4 == 0 and K % 2 == 1, (Cin, Cout, K)
         self.step, self.nslices = step, Cin // step
@@ -477,16 +467,6 @@ class SplitConv1d:
         with torch.cuda.device(x.device):
             st = _lib.current_stream_handle()
             out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
-            if self.stream:
-                r = None
-                if residual is not None:
-                    r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
-                    assert tuple(r.shape) == (B, T, self.Cout)
-                # a Linear layer (one tap) over a contiguous batch is ONE [B*T, Cin] matrix: no per-sample tile remainders
-                Bk, Tk = (1, B * T) if (self.K == 1 and x.stride(1) == self.Cin) else (B, T)
-                _lib.check(lib.dsp_conv1d_stream(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(r), self.Cout,
-                                                 float(alpha), _lib.ptr(out), self.Cout, Bk, Tk, self.Cin, self.Cout, self.K, code, st), "dsp_conv1d_stream")
-                return out
             if residual is not None or alpha != 1.0:
                 r = None
                 if residual is not None:
@@ -501,7 +481,6 @@ class SplitConv1d:
         return out
 
 
-STREAM_CONV = True         # False: SplitConv1d objects built afterwards use the r01-r03 whole-slice kernel (csrc/conv1d_split.hip) everywhere
 SPLIT_GEMM = True          # set_split_gemm(False): every Linear / FFT convolution goes back to torch (hipBLASLt / MIOpen fp32)
 
 

@@ -117,15 +117,6 @@ int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const 
                               float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
                               dsp_stream_t stream);
 
-/* The same arithmetic as a K-STREAMING kernel (csrc/conv1d_stream.hip, r04): the input goes through LDS in double-buffered 64-channel chunks
- * (any CI that is a multiple of 64, no slices), 32x32x16 MFMAs, 128 output channels x 128 / 64 time rows per workgroup, workgroups ordered so
- * that the output-channel tiles of a time tile share an XCD's L2.  Own weight order: dsp_conv1d_stream_pack ([ntaps][CI/16][ceil(M/32)][64][8]).
- *   out = [res + alpha *] act(bias + conv(x))      act: 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf); res may be NULL
- * Same layer interface the reference's modules have (fairseq/models/text_to_speech/fastspeech2.py:42-70 Conv1d, nn.Linear as ntaps = 1). */
-long dsp_conv1d_stream_packed_elems(int ntaps, int M, int CI);
-int dsp_conv1d_stream_pack(const float* w_tap_major, void* w_hi, void* w_lo, int ntaps, int M, int CI, dsp_stream_t stream);
-int dsp_conv1d_stream(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr,
-                      float alpha, float* out, long ldo, int B, int T, int CI, int M, int ntaps, int act, dsp_stream_t stream);
 
 /* LayerNorm over the last dimension (torch.nn.LayerNorm semantics: biased variance, eps inside the square root), one wave per row:
  * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */

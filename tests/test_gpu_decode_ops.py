@@ -368,46 +368,6 @@ def test_split_precision_conv1d_is_fp32_accurate(shape):
         torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(3, 131, 512, 2048, 1), (2, 333, 2048, 512, 1), (32, 37, 256, 256, 1), (2, 129, 64, 200, 5), (1, 700, 1024, 256, 9),
-                                   (5, 1, 512, 128, 3), (2, 65, 192, 132, 31)])
-def test_streaming_split_conv_vs_fp64_and_vs_the_slice_kernel(shape):
-    """dsp_conv1d_stream (r04: 64-channel chunks double-buffered through LDS, 32x32x16 MFMAs, XCD-ordered workgroups) against an fp64 reference —
-    Linear layers as ONE flattened [B*T, Cin] matrix, convolutions per sample with zero padding at both ends, time lengths that are no multiple
-    of the 32-row MFMA tile, output widths that are no multiple of the 128-channel workgroup tile, every epilogue (bias, ReLU / SiLU / GELU,
-    residual, alpha) — and against the r01-r03 whole-slice kernel where that one serves the shape."""
-    from daspeech_amd import decode_ops
-    from daspeech_amd.decode_ops import SplitConv1d
-    B, T, Cin, Cout, K = shape
-    torch.manual_seed(5 + T + Cin)
-    conv = torch.nn.Conv1d(Cin, Cout, K, padding=(K - 1) // 2).cuda()
-    x = torch.randn(B, T, Cin, device="cuda") * torch.exp2(torch.randint(-8, 5, (B, T, 1), device="cuda").float())
-    res = torch.randn(B, T, Cout, device="cuda")
-    sc = SplitConv1d(conv.weight, conv.bias)
-    assert sc.stream
-    acts = {None: lambda v: v, "relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}
-    with torch.no_grad():
-        ref64 = torch.nn.functional.conv1d(x.double().transpose(1, 2), conv.weight.double(), conv.bias.double(), padding=(K - 1) // 2).transpose(1, 2)
-        ref32 = conv(x.transpose(1, 2)).transpose(1, 2)
-        err32 = (ref32.double() - ref64).abs().max().item() / ref64.abs().max().item()
-        for act, fn in acts.items():
-            for r, alpha in ((None, 1.0), (res, 0.5)):
-                got = sc(x, act=act, residual=r, alpha=alpha)
-                want = fn(ref64) * alpha + (r.double() if r is not None else 0)
-                scale = max(ref64.abs().max().item(), 1.0)
-                err = (got.double() - want).abs().max().item() / scale
-                assert got.shape == (B, T, Cout) and torch.isfinite(got).all()
-                assert err < 4e-6 and err < 8 * err32 + 1e-6, (act, alpha, err, err32)
-        if Cin in (128, 256, 512) or Cin % 512 == 0:
-            old = decode_ops.STREAM_CONV
-            decode_ops.STREAM_CONV = False
-            try:
-                sc_old = SplitConv1d(conv.weight, conv.bias)
-            finally:
-                decode_ops.STREAM_CONV = old
-            assert not sc_old.stream
-            torch.testing.assert_close(sc(x, relu=True), sc_old(x, relu=True), rtol=2e-6, atol=2e-6 * ref64.abs().max().item())
-
-
 @pytest.mark.parametrize("shape", [(5, 77, 256), (3, 1, 512), (2, 33, 1024), (7, 3, 80), (1, 130, 2048), (4, 9, 36)])
 def test_layer_norm_kernel_matches_torch(shape):
     """dsp_layer_norm (one wave per row, values in registers) vs torch.nn.LayerNorm in eval-mode fp32."""
