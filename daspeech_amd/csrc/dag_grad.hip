@@ -203,30 +203,40 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
         const int rows = min(GX_TC, thi - tb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this pass's rows have landed
         // ---- convert beta rows tb+1 .. tb+rows: columns i0 .. i0+291 as 73 groups of 4 (window element q <-> column i0 + q)
+        // (r04: every raw read of the pass leaves as ONE batch — twelve ds_read_b128, unconditional, masked afterwards — before the first
+        //  conversion; the branchy per-row form this replaces cost one exposed LDS round trip per (row, group) and pass: ten per pass)
+        float4 ra[GX_TC], rb0[GX_TC], rb1[GX_TC];
+        const int g1 = lane + 64, g1c = g1 < 73 ? g1 : 72;
 #pragma unroll
         for (int r = 0; r < GX_TC; ++r) {
-            float4 a4 = *reinterpret_cast<const float4*>(Araw + r * 256 + 4 * lane);
-            if (!(r < rows && v0 < L)) a4 = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-            *reinterpret_cast<float4*>(Aq + r * 256 + 4 * lane) = a4;
+            ra[r] = *reinterpret_cast<const float4*>(Araw + r * 256 + 4 * lane);
+            rb0[r] = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * lane);
+            rb1[r] = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * g1c);
         }
+        const float4 ninf4 = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+        auto convert = [&](float4 v, bool live, int r, int g, bool store) {
+            if (!live) v = ninf4;
+            const float x0 = v.x * LOG2E, x1 = v.y * LOG2E, x2 = v.z * LOG2E, x3 = v.w * LOG2E;
+            const float gm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+            const bool gd = gm == NEG_INF;
+            const float cf = gd ? 0.f : ceilf(gm);
+            const float4 o = make_float4(__builtin_amdgcn_exp2f(x0 - cf), __builtin_amdgcn_exp2f(x1 - cf), __builtin_amdgcn_exp2f(x2 - cf),
+                                         __builtin_amdgcn_exp2f(x3 - cf));
+            if (store) {
+                *reinterpret_cast<float4*>(Bq + r * GX_P + 4 * g) = o;
+                Xq[r * GX_G + g] = gd ? GX_NEG : (int)cf;
+            }
+        };
 #pragma unroll
         for (int r = 0; r < GX_TC; ++r) {
+            float4 a4 = ra[r];
+            if (!(r < rows && v0 < L)) a4 = ninf4;
+            *reinterpret_cast<float4*>(Aq + r * 256 + 4 * lane) = a4;
+            convert(rb0[r], r < rows && i0 + 4 * lane < L, r, lane, true);
+        }
+        if (g1 < 73) {
 #pragma unroll
-            for (int pss = 0; pss < 2; ++pss) {
-                const int g = lane + 64 * pss;
-                if (g < 73) {
-                    const int col = i0 + 4 * g;
-                    float4 v = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * g);
-                    if (!(r < rows && col < L)) v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-                    const float x0 = v.x * LOG2E, x1 = v.y * LOG2E, x2 = v.z * LOG2E, x3 = v.w * LOG2E;
-                    const float gm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
-                    const bool gd = gm == NEG_INF;
-                    const float cf = gd ? 0.f : ceilf(gm);
-                    *reinterpret_cast<float4*>(Bq + r * GX_P + 4 * g) = make_float4(
-                        __builtin_amdgcn_exp2f(x0 - cf), __builtin_amdgcn_exp2f(x1 - cf), __builtin_amdgcn_exp2f(x2 - cf), __builtin_amdgcn_exp2f(x3 - cf));
-                    Xq[r * GX_G + g] = gd ? GX_NEG : (int)cf;
-                }
-            }
+            for (int r = 0; r < GX_TC; ++r) convert(rb1[r], r < rows && i0 + 4 * g1 < L, r, g1, true);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations execute in order
         if (tb + GX_TC < thi) request(tb + GX_TC);               // the raw rows are free again: next pass streams in meanwhile
