@@ -104,12 +104,23 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
         const int l = tid;
         const int j = j0 + CPL * l;
         const bool col_ok = j < L;
-        float E[CPL][32];                        // E[c][k]: link of predecessor j + c - 32 + k into vertex j + c (k ascending = index ascending)
+        // E[c][k]: link of predecessor j + c - 32 + k into vertex j + c (k ascending = index ascending).
+        // CPL == 2 (r04): the window is read as nine ds_read_b128 from the 16-byte aligned base 4 * (l >> 1) (256 B/clk; the eight-byte aligned
+        // ds_read2_b64 form it replaces runs at 128 B/clk, and the four compute waves read right after the barrier: the LDS pipe, not the
+        // latency, paced the row head), so a lane's weights are stored against THAT window: EW[c][q], q = 0..35, -inf where window element q
+        // is no predecessor of vertex c (odd lanes sit two elements into the window).  add / max only: bit-identical to the 32-term form.
+        constexpr int NW = (CPL == 2) ? 36 : 32;
+        float E[CPL][NW];
         const float* tile = reinterpret_cast<const float*>(smem_raw);
+        const int woff = (CPL == 2) ? 2 * (l & 1) : 0;           // the lane's own window starts woff elements into the aligned one
 #pragma unroll
         for (int c = 0; c < CPL; ++c)
 #pragma unroll
-            for (int k = 0; k < 32; ++k) E[c][k] = tile[(CPL * l + c + k) * 33 + (31 - k)];   // row (j+c-32+k) - (j0-32), transition d-1 = 31-k
+            for (int q = 0; q < NW; ++q) {
+                const int k = q - woff - (CPL == 2 ? c : 0);     // CPL == 2: element q of the aligned window is predecessor index k of vertex c
+                if constexpr (CPL == 2) E[c][q] = (k >= 0 && k < 32) ? tile[(CPL * l + c + (k >= 0 && k < 32 ? k : 0)) * 33 + (31 - (k >= 0 && k < 32 ? k : 0))] : NEG_INF;
+                else E[c][q] = tile[(CPL * l + c + q) * 33 + (31 - q)];   // row (j+c-32+k) - (j0-32), transition d-1 = 31-k
+            }
         __syncthreads();                         // tile consumed: the loader may start filling the ring over it
         mx_barrier();                            // prologue barrier: match row 0 is in the ring
 
@@ -126,7 +137,7 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                 if (j == 0) a[0] = Mring[(size_t)(it % MX_RING) * W];        // the start vertex
             } else {
                 // row head: the match values and the (32 + CPL)-value window leave as one issue group (see dag_dp_strip4g.hip)
-                float w[32 + CPL], m2[CPL];
+                float w[(CPL == 2) ? 36 : 32 + CPL], m2[CPL];
                 const u32 maddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Mring + (size_t)(it % MX_RING) * W + CPL * l);
                 const u32 vaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Abuf + prv * RL + CPL * l);
                 if constexpr (CPL == 4) {
@@ -155,8 +166,30 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
 #pragma unroll
                     for (int k = 0; k < 33; ++k) w[k] = wp[k];
                     m2[0] = Mring[(size_t)(it % MX_RING) * W + l];
+                } else if constexpr (CPL == 2) {
+                    mx_v2f mt; mx_v4f pv[9];
+                    const u32 vaddr16 = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(Abuf + prv * RL + 4 * (l >> 1));
+                    asm volatile(
+                        "ds_read_b64 %0, %10\n\t"
+                        "ds_read_b128 %1, %11\n\t"
+                        "ds_read_b128 %2, %11 offset:16\n\t"
+                        "ds_read_b128 %3, %11 offset:32\n\t"
+                        "ds_read_b128 %4, %11 offset:48\n\t"
+                        "ds_read_b128 %5, %11 offset:64\n\t"
+                        "ds_read_b128 %6, %11 offset:80\n\t"
+                        "ds_read_b128 %7, %11 offset:96\n\t"
+                        "ds_read_b128 %8, %11 offset:112\n\t"
+                        "ds_read_b128 %9, %11 offset:128\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(mt), "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]),
+                          "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8])
+                        : "v"(maddr), "v"(vaddr16)
+                        : "memory");
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { w[4 * k] = pv[k].x; w[4 * k + 1] = pv[k].y; w[4 * k + 2] = pv[k].z; w[4 * k + 3] = pv[k].w; }
+                    m2[0] = mt.x; m2[1] = mt.y;
                 } else {
-                    mx_v2f mt, pl; mx_v4f pq[8];          // 17 eight-byte slots: eight ds_read2_b64 + one ds_read_b64
+                    mx_v2f mt, pl; mx_v4f pq[8];          // (CPL == 2 before r04) 17 eight-byte slots: eight ds_read2_b64 + one ds_read_b64
                     asm volatile(
                         "ds_read_b64 %0, %10\n\t"
                         "ds_read2_b64 %1, %11 offset1:1\n\t"
@@ -184,18 +217,32 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
                 for (int c = 0; c < CPL; ++c) {
                     // max over the 32 predecessors: window element c + k, a 3-input max tree (values only — the arg-max is
                     // recomputed by the back-trace for the 1 cell per row that needs it)
-                    float x[32];
+                    float mx;
+                    if constexpr (CPL == 2) {
+                        float x[36];
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) x[k] = w[c + k] + E[c][k];
-                    float m10[11];
+                        for (int q = 0; q < 36; ++q) x[q] = w[q] + E[c][q];
+                        float m12[12];
 #pragma unroll
-                    for (int g = 0; g < 10; ++g) m10[g] = fmaxf(fmaxf(x[3 * g], x[3 * g + 1]), x[3 * g + 2]);
-                    m10[10] = fmaxf(x[30], x[31]);
-                    const float m4a = fmaxf(fmaxf(m10[0], m10[1]), m10[2]), m4b = fmaxf(fmaxf(m10[3], m10[4]), m10[5]);
-                    const float m4c = fmaxf(fmaxf(m10[6], m10[7]), m10[8]), m4d = fmaxf(m10[9], m10[10]);
-                    const float mx = (MX_DBG(p) & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                        for (int g = 0; g < 12; ++g) m12[g] = fmaxf(fmaxf(x[3 * g], x[3 * g + 1]), x[3 * g + 2]);
+                        const float m4a = fmaxf(fmaxf(m12[0], m12[1]), m12[2]), m4b = fmaxf(fmaxf(m12[3], m12[4]), m12[5]);
+                        const float m4c = fmaxf(fmaxf(m12[6], m12[7]), m12[8]), m4d = fmaxf(fmaxf(m12[9], m12[10]), m12[11]);
+                        mx = (MX_DBG(p) & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                    } else {
+                        float x[32];
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) x[k] = w[c + k] + E[c][k];
+                        float m10[11];
+#pragma unroll
+                        for (int g = 0; g < 10; ++g) m10[g] = fmaxf(fmaxf(x[3 * g], x[3 * g + 1]), x[3 * g + 2]);
+                        m10[10] = fmaxf(x[30], x[31]);
+                        const float m4a = fmaxf(fmaxf(m10[0], m10[1]), m10[2]), m4b = fmaxf(fmaxf(m10[3], m10[4]), m10[5]);
+                        const float m4c = fmaxf(fmaxf(m10[6], m10[7]), m10[8]), m4d = fmaxf(m10[9], m10[10]);
+                        mx = (MX_DBG(p) & 8) ? x[5 + c] : fmaxf(fmaxf(m4a, m4b), fmaxf(m4c, m4d));
+                    }
                     const bool act = (j + c >= t) && (j + c < Lb);
-                    a[c] = act ? (mx + m2[c]) : NEG_INF;
+                    const float cand = mx + m2[c];
+                    a[c] = act ? cand : NEG_INF;                 // (a select, not a branch: the two vertices' trees interleave)
                 }
             }
             stamp(1);                                       // adds + max trees
