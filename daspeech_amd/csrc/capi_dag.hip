@@ -21,6 +21,7 @@ struct CallerWsScope {
 };
 void set_k5_path(int v);
 void set_mx_cpl(int v);
+void set_bt_ring(int v);
 int k5_diag(unsigned int* out);
 int launch_dag_banded(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 int banded_last_error_word(hipStream_t st, unsigned int* word);
@@ -232,6 +233,7 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
     if (name && !strcmp(name, "mx_cpl")) { set_mx_cpl(value); return DSP_OK; }
+    if (name && !strcmp(name, "bt_ring")) { set_bt_ring(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_depth")) { set_dm_depth(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_mt")) { set_dm_mt(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_budget")) { set_dm_budget(value); return DSP_OK; }

@@ -521,6 +521,128 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
     for (int j = tid; j < L; j += 256) path[(size_t)b * L + j] = lp[j];
 }
 
+// ---- r04: the same lazy back-trace with NOTHING but the hops on its critical path (TR == 32) --------------------------------------------------
+// dag_backtrace_lazy_kernel above stops the hop wave twice per iteration (segments: registers -> LDS after the hops; a second barrier) and
+// every few dozen hops for a synchronous 96 KB refill of the transition window (9 refills of ~4 us at C2: a quarter of the kernel).  Here
+//   * the transition rows live in a RING of 512 rows (64 KB, row r in slot r & 511): every iteration the three helper waves request the
+//     rows the NEXT iteration can need, [pos - 64 H, pos - 32 H), as LDS-DMA (1 KB = 8 rows per request, no registers) — they land while
+//     wave 0 hops.  With H = 7 the slots they overwrite belong to rows >= pos + 57: already behind the path;
+//   * the alpha_max segments of the next iteration are LDS-DMA too (4-byte requests: 64 consecutive columns per request), into the OTHER of two
+//     segment buffers: no staging registers, no stash phase, ONE barrier per iteration;
+//   * lanes whose column / row falls outside the table request a clamped address: what lands there is never read (a hop only reads
+//     predecessors i >= 0 of a row t - 1 >= 0, inside the segment's range by the 1..32-vertices-per-row bound).
+constexpr int BR_H = 7;                        // hops per iteration
+constexpr int BR_RW = 512;                     // ring rows (>= 64 H + 8 + 32 spare: see above)
+constexpr int BR_SEG = 448;                    // segment pitch: >= 62 H + 1 = 435, a multiple of 64 (one request = 64 columns)
+
+__global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
+    const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len,
+    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L)
+{
+    constexpr int TR = 32;
+    extern __shared__ __attribute__((aligned(16))) char br_smem[];
+    float* ring = reinterpret_cast<float*>(br_smem);                          // [BR_RW][32]
+    float* seg = ring + (size_t)BR_RW * TR;                                   // [2][BR_H][BR_SEG]
+    int32_t* lp = reinterpret_cast<int32_t*>(seg + 2 * BR_H * BR_SEG);        // [L]
+    __shared__ int s_state[2][4];                                             // per iteration parity: pos, t, done
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < L; j += 256) lp[j] = -1;
+    const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
+    const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
+    const float* A = amax + (size_t)b * T * L;
+    const float* K = links + (size_t)b * L * TR;
+    int pos = Lb - 1, t = Tb - 1;
+    bool done = !valid;
+
+    // alpha_max segments for the iteration AFTER the one that starts at frame (tF, pF): slot k - 1 = row tF - H - k, columns pF - 32 (H + k) ...
+    auto request_segments = [&](int tF, int pF, int buf, int w, int nw) {   // wave w of nw takes every nw-th request
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k <= BR_H; ++k) {
+            const int row = tF - BR_H - k, col0 = pF - 32 * (BR_H + k), nreq = (31 * (BR_H + k) + 64) >> 6;
+            const float* rowp = A + (size_t)(row < 0 ? 0 : row) * L;          // wave-uniform
+            float* dst = seg + ((size_t)buf * BR_H + (k - 1)) * BR_SEG;
+#pragma unroll
+            for (int j = 0; j < (31 * (2 * BR_H) + 64) / 64; ++j) {
+                if (j < nreq) {
+                    if (r % nw == w) {
+                        int col = col0 + 64 * j + lane;
+                        col = col < 0 ? 0 : (col >= L ? L - 1 : col);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + col),
+                                                         (__attribute__((address_space(3))) void*)(dst + 64 * j), 4, 0, 0);
+                    }
+                    ++r;
+                }
+            }
+        }
+    };
+    // transition rows [8 c0, 8 c1) into the ring, 8 rows (1 KB) per request
+    auto request_rows = [&](int c0, int c1, int w, int nw) {
+        for (int c = c0 + w; c < c1; c += nw) {
+            const int row = 8 * c + (lane >> 3);                              // lane = 16-byte quad (lane & 7) of row 8 c + (lane >> 3)
+            const float* src = K + (size_t)(row < L ? row : L - 1) * TR + 4 * (lane & 7);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ring + (size_t)((8 * c) & (BR_RW - 1)) * TR), 16, 0, 0);
+        }
+    };
+    int lo_chunk = 0;                                                         // rows >= 8 * lo_chunk (up to the start vertex) are in the ring
+    if (!done) {
+        const int c1 = (pos >> 3) + 1;
+        lo_chunk = max(0, (pos - 64 * BR_H) >> 3);
+        if (pos - 64 * BR_H < 0) lo_chunk = 0;
+        request_rows(lo_chunk, c1, wave, 4);
+        request_segments(t + BR_H, pos + BR_H, 0, wave, 4);                   // pretend frame of "the iteration before the first"
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int tF = t + BR_H, pF = pos + BR_H;                                       // frame of the segments in buffer (it & 1)
+    for (int it = 0; !done; ++it) {
+        const int t0 = t, p0 = pos;
+        if (wave != 0) {
+            // ---- helpers: everything the NEXT iteration reads, requested now
+            request_segments(t0, p0, (it + 1) & 1, wave - 1, 3);
+            const int want = (p0 - 64 * BR_H) < 0 ? 0 : ((p0 - 64 * BR_H) >> 3);
+            if (want < lo_chunk) request_rows(want, lo_chunk, wave - 1, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // ---- wave 0: up to H hops out of LDS (segments of frame (tF, pF), buffer it & 1).  The hop is a chain of dependent instructions on
+            // one wave, so every instruction and every taken branch is latency: unconditional clamped reads + a select instead of an exec-mask
+            // region, the visited positions collected in ONE register (lane h = position of hop h) and written to the path image after the
+            // hops, the end test on the scalar bits of the maximum.
+            const float* sg = seg + (size_t)(it & 1) * BR_H * BR_SEG;
+            const int tstart = t;
+            int hist = -1, nh = 0;                                            // lane h - 1: the vertex visited at row tstart - (h - 1)
+#pragma unroll
+            for (int h = 1; h <= BR_H; ++h) {
+                hist = (lane == h - 1) ? pos : hist;                             // (off the chain: pos is known when the hop starts)
+                nh = h;
+                if (t == 0 || pos < t) { done = true; break; }               // row 0 / under the diagonal: trace = -1
+                const int i = pos - 1 - lane;
+                const int ic = i < 0 ? 0 : i;
+                const float av = sg[(h - 1) * BR_SEG + (ic - (pF - 32 * (BR_H + h)))];
+                const float kv = ring[((ic & (BR_RW - 1)) << 5) + (lane & 31)];
+                const float x = (lane < TR && i >= 0) ? av + kv : NEG_INF;
+                const float mx = bt_max_lanes32(x);                           // lanes >= 32 hold -inf
+                --t;
+                if (__builtin_bit_cast(unsigned, mx) == 0xff800000u) { pos = -1; done = true; break; }
+                const unsigned long long hit = __builtin_amdgcn_fcmpf(x, mx, 1 /* FCMP_OEQ */);
+                pos = pos - 1 - (63 - __builtin_clzll(hit));                  // the LARGEST d = smallest predecessor index among the maxima
+            }
+            if (lane < nh) lp[hist] = tstart - lane;
+            if (lane == 0) { s_state[it & 1][0] = pos; s_state[it & 1][1] = t; s_state[it & 1][2] = done ? 1 : 0; }
+        }
+        {
+            const int want = (p0 - 64 * BR_H) < 0 ? 0 : ((p0 - 64 * BR_H) >> 3);
+            if (want < lo_chunk) lo_chunk = want;
+        }
+        __syncthreads();
+        pos = s_state[it & 1][0]; t = s_state[it & 1][1]; done = s_state[it & 1][2] != 0;
+        tF = t0; pF = p0;
+    }
+    __syncthreads();
+    for (int j = tid; j < L; j += 256) path[(size_t)b * L + j] = lp[j];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
@@ -545,6 +667,8 @@ static int launch_one_mx(const MStripParams& p, int nwg, hipStream_t st)
     return check_launch("dag_best_alignment(maxstrip)");
 }
 
+static int g_bt_ring = 1;                     // dsp_dag_set_option("bt_ring", 0): the r01-r03 back-trace kernel (cross-check)
+void set_bt_ring(int v) { g_bt_ring = v; }
 static int g_mx_cpl = 0;                      // experiment switch (dsp_dag_set_option("mx_cpl", 1 | 2 | 4)): vertices per lane of the max-DP; 0 = auto
 void set_mx_cpl(int v) { g_mx_cpl = v; }
 
@@ -571,6 +695,12 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     if (rc) return rc;
     rc = wide ? launch_one_mx<256, 4>(p, B * NS, st) : (cpl == 2 ? launch_one_mx<256, 2>(p, B * NS, st) : launch_one_mx<256, 1>(p, B * NS, st));
     if (rc) return rc;
+    if (TR == 32 && g_bt_ring && (((uintptr_t)links) & 15) == 0) {
+        const size_t lds3 = ((size_t)BR_RW * 32 + 2 * BR_H * BR_SEG + (size_t)L) * 4;
+        (void)hipFuncSetAttribute((const void*)dag_backtrace_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        hipLaunchKernelGGL(dag_backtrace_ring_kernel, dim3(B), dim3(256), lds3, st, alpha_max, links, out_len, tgt_len, path, B, T, L);
+        return check_launch("dag_best_alignment(ring back-trace)");
+    }
     const size_t lds2 = ((size_t)BT_LW * TR + BT_HOPS * BT_SEG + (size_t)L) * 4;
     (void)hipFuncSetAttribute((const void*)dag_backtrace_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(dag_backtrace_lazy_kernel, dim3(B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR);
