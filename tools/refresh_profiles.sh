@@ -49,13 +49,19 @@ if f and w:
     json.dump(rec, open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_dag_fwd.json"), "w"), indent=1)
     print("pmc_dag_fwd.json: FETCH", f, "WRITE", w)
 PY
-HGCMD="python $GRAFT_REPO_ROOT/tools/hifigan_bench.py 8 329"
+HGCMD="python $GRAFT_REPO_ROOT/tools/hifigan_f32_prof.py 32 329 3"      # the bench's vocoder call: fp32-accurate, fused ResBlock units, whole batch
 rm -rf /tmp/kh; rocprofv3 --kernel-trace --stats -d /tmp/kh -o k --output-format csv -- $HGCMD > $OUT/hifigan_bench.txt 2>&1
 cp /tmp/kh/k_kernel_stats.csv $OUT/hifigan_kernel_stats.csv
 {
 echo "# rocprofv3 --pmc passes over: $HGCMD"
-echo "## MFMA busy / LDS (hifigan_conv_f32_kernel = the fp32-accurate default, hifigan_conv / resunit = fp16 storage)"; pmc "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES" "hifigan" $HGCMD
+echo "## MFMA busy / LDS (hifigan_resunit_f32_kernel = fused ResBlock units, hifigan_conv_f32_kernel = conv_pre and the upsamplers)"; pmc "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "hifigan" $HGCMD
 pmc "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "hifigan" $HGCMD
 echo "## FETCH_SIZE (raw KB)"; pmc FETCH_SIZE "hifigan" $HGCMD
 echo "## WRITE_SIZE (KB)"; pmc WRITE_SIZE "hifigan" $HGCMD
 } > $OUT/pmc_hifigan.txt 2>&1
+
+# the other workloads of the bench (one line each), the training-step and acoustic-stage kernel breakdowns
+cd $GRAFT_REPO_ROOT
+{ python bench.py --workload train --steps 10 --warmup 4 2>/dev/null | tail -1; python bench.py --workload s2tt --steps 10 --warmup 4 2>/dev/null | tail -1; } > $OUT/bench_train_s2tt.txt
+bash tools/train_step_prof.sh 10 > $OUT/train_step_kernels.txt 2>&1
+bash tools/acoustic_stage_prof.sh > $OUT/acoustic_stage_kernels.txt 2>&1
