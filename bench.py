@@ -328,7 +328,10 @@ def dag_report(ctx, args, steps, warmup):
             pass
     roofline = {"bound": "hbm", "kernel": "dag_loss forward DP (alpha||beta, one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-                "algorithmic_bytes": alg_bytes, "avg_launch_ms": ms}
+                "algorithmic_bytes": alg_bytes, "avg_launch_ms": ms,
+                # the banded DP is T dependent rows per launch — latency per row beside the bandwidth figure (the launch is paced by
+                # this chain, not by HBM: profiles/r04_dp_coresidency.txt)
+                "us_per_row": ms * 1e3 / T, "rows_per_launch": T}
     step_ms = sum(phases.values())
     rep = {
         "workload": f"C2 DAG training hot path: logsoftmax_gather + dag_loss fwd+bwd + dag_best_alignment, B={B}/GPU, graph_len={L}, "
