@@ -145,6 +145,9 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   "dm_budget": the dense kernel hands a batch exp space cannot hold (finite transitions under e^-86, or more exact-redo work than
  *   one visited predecessor per (row, 64-column block)) to log-space stand-by kernels queued behind it — 0 = auto, n > 0 = that many
  *   visited predecessors, -1 = no stand-by (diagnostics only: such batches are then slow and their weakest terms unguarded).
+ *   "mx_cpl" 0|1|2|4 (r04): vertices per lane of the banded max-DP (0 = auto: 4 when that still gives >= 200 workgroups, else 2; 1 exists
+ *   for the co-residency measurement of profiles/r04_dp_coresidency.txt), "bt_ring" 1|0 (r04): the LDS-ring back-trace (TR == 32) or the
+ *   r01-r03 window kernel — every combination returns bit-identical paths.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);
