@@ -17,7 +17,7 @@ def _latest(pattern):
 
 
 def test_committed_dag_bench_line_has_the_contract_fields():
-    d = json.loads(open(_latest("r02*_bench_headline.json")).read().strip().split("\n")[-1])     # `python bench.py`, the driver's command
+    d = json.loads(open(_latest("r0*_bench_headline.json")).read().strip().split("\n")[-1])     # `python bench.py`, the driver's command
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
