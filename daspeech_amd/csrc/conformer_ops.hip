@@ -180,7 +180,7 @@ constexpr int RA_U = 7;                                             // global re
 __global__ __launch_bounds__(512) void relpos_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ p,
     const float* __restrict__ bias_u, const float* __restrict__ bias_v, const unsigned char* __restrict__ pad_mask,
-    float* __restrict__ out, int B, int T, int H, float scale)
+    float* __restrict__ out, int B, int T, int H, float scale, long ld)
 {
     extern __shared__ __attribute__((aligned(16))) float ra_smem[];
     const int Tp = (T + 3) & ~3;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * RA_QT, h = blockIdx.y, b = blockIdx.z;
     const int P = 2 * T - 1, C = H * RA_DK, SP = Tp + 4;
-    const size_t rowstride = (size_t)C;
+    const size_t rowstride = (size_t)ld, prow = (size_t)C;             // q / k / v rows (slices of a fused projection: ld = 3C), p / out rows
     const float* Qb = q + (size_t)b * T * rowstride + (size_t)h * RA_DK;
     const float* Kb = k + (size_t)b * T * rowstride + (size_t)h * RA_DK;
     const float* Vb = v + (size_t)b * T * rowstride + (size_t)h * RA_DK;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(
 #pragma unroll
             for (int u = 0; u < RA_U; ++u) {
                 const int e = e0 + u * 512, rr = e >> 3, c = (e & 7) * 4, r = r0 + rr;
-                x[u] = *reinterpret_cast<const float4*>(Pb + (size_t)((r >= 0 && r < P) ? r : 0) * rowstride + c0 + c);
+                x[u] = *reinterpret_cast<const float4*>(Pb + (size_t)((r >= 0 && r < P) ? r : 0) * prow + c0 + c);
             }
 #pragma unroll
             for (int u = 0; u < RA_U; ++u) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(
             o0.x = fmaf(w4.w, a3.x, o0.x); o0.y = fmaf(w4.w, a3.y, o0.y); o0.z = fmaf(w4.w, a3.z, o0.z); o0.w = fmaf(w4.w, a3.w, o0.w);
         }
         if (i0 + i < T) {
-            float* O = out + ((size_t)b * T + i0 + i) * rowstride + (size_t)h * RA_DK + c;
+            float* O = out + ((size_t)b * T + i0 + i) * prow + (size_t)h * RA_DK + c;
             *reinterpret_cast<float4*>(O) = o0;
         }
     }
@@ -347,13 +347,14 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(
 
 }  // namespace dsp
 
-extern "C" int dsp_relpos_attention(const float* q, const float* k, const float* v, const float* p, const float* bias_u, const float* bias_v,
+extern "C" int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld, const float* p, const float* bias_u, const float* bias_v,
                                     const unsigned char* pad_mask, float* out, int B, int T, int H, int DK, dsp_stream_t stream)
 {
     using namespace dsp;
     if (B < 0 || T < 1 || H < 1 || DK != RA_DK || T > 256) { set_error("relpos_attention: needs head width 64 and T <= 256 (got T=%d, dk=%d)", T, DK); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
     if (!q || !k || !v || !p || !bias_u || !bias_v || !out) { set_error("relpos_attention: null pointer"); return DSP_EINVAL; }
+    if (ld < (long)H * DK || (ld & 3)) { set_error("relpos_attention: row stride %ld must be >= H * dk and a multiple of 4", ld); return DSP_EINVAL; }
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)p) | ((uintptr_t)out) | ((uintptr_t)bias_u) | ((uintptr_t)bias_v)) & 15) {
         set_error("relpos_attention: pointers must be 16-byte aligned"); return DSP_EINVAL; }
     const int Tp = (T + 3) & ~3;
@@ -362,6 +363,6 @@ extern "C" int dsp_relpos_attention(const float* q, const float* k, const float*
     if (lds > 160 * 1024) { set_error("relpos_attention: T=%d needs %zu bytes of LDS", T, lds); return DSP_EINVAL; }
     (void)hipFuncSetAttribute((const void*)relpos_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(relpos_attention_kernel, dim3((T + RA_QT - 1) / RA_QT, H, B), dim3(512), lds, as_stream(stream),
-                       q, k, v, p, bias_u, bias_v, pad_mask, out, B, T, H, 1.f / sqrtf((float)DK));
+                       q, k, v, p, bias_u, bias_v, pad_mask, out, B, T, H, 1.f / sqrtf((float)DK), ld);
     return check_launch("relpos_attention");
 }

@@ -528,6 +528,37 @@ def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor]
     return y if residual is None else residual + y
 
 
+class _CatLinear:
+    """the weights / biases of several nn.Linear over the same input stacked into one [sum(out), in] projection"""
+
+    def __init__(self, lins):
+        self.weight = torch.cat([l.weight.detach() for l in lins], 0)
+        self.bias = torch.cat([(l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], dtype=l.weight.dtype, device=l.weight.device))
+                               for l in lins], 0)
+        self.training = False
+
+
+def linear_fused(x: Tensor, lins) -> tuple:
+    """(lin(x) for lin in lins) for nn.Linear modules sharing the input x: in eval-mode fp32 inference on the GPU ONE split GEMM over the
+    stacked weights (cached on the first module) whose output columns are returned as row-strided views — every output column sees the
+    same reduction as in its own GEMM, so the values are bit-identical to separate calls; separate `linear` calls otherwise."""
+    first = lins[0]
+    if (SPLIT_GEMM and not first.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and x.dim() == 3 and x.is_contiguous() and x.shape[0] * x.shape[1] >= 128 and all(l.weight.dim() == 2 and l.weight.dtype == torch.float32 for l in lins)):
+        key = tuple((l.weight.data_ptr(), l.weight._version, None if l.bias is None else l.bias._version) for l in lins)
+        cache = getattr(first, "_dsp_cat", None)
+        if cache is None or cache[0] != key:
+            cache = (key, _CatLinear(lins))
+            first._dsp_cat = cache
+        y = split_linear(x, cache[1])
+        if y is not None:
+            outs, o = [], 0
+            for l in lins:
+                outs.append(y[..., o:o + l.weight.shape[0]]); o += l.weight.shape[0]
+            return tuple(outs)
+    return tuple(linear(x, l) for l in lins)
+
+
 def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
     """ln(x): the one-wave-per-row HIP kernel (dsp_layer_norm) in eval-mode fp32 inference on the GPU, torch otherwise."""
     C = x.shape[-1]
@@ -543,11 +574,13 @@ def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
 
 
 def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor, bias_v: Tensor, pad_mask: Optional[Tensor], heads: int) -> Optional[Tensor]:
-    """Fused Conformer relative-position attention (dsp_relpos_attention): q, k, v [B,T,C] fp32 (C = heads * 64), p [1 or none, 2T-1, C],
-    bias_u / bias_v [heads, 64], pad_mask [B,T] bool.  Returns [B,T,C], or None when the shape / mode is not served."""
+    """Fused Conformer relative-position attention (dsp_relpos_attention): q, k, v [B,T,C] fp32 (C = heads * 64) with one common row stride
+    (contiguous tensors or the three column slices of a fused projection), p [1 or none, 2T-1, C], bias_u / bias_v [heads, 64], pad_mask
+    [B,T] bool.  Returns [B,T,C] contiguous, or None when the shape / mode is not served."""
     B, T, C = q.shape
+    ld = q.stride(1)
     if (not SPLIT_GEMM or torch.is_grad_enabled() or not q.is_cuda or q.dtype != torch.float32 or torch.is_autocast_enabled() or C != heads * 64 or T > 256
-            or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous())):
+            or any(t.stride(2) != 1 or t.stride(1) != ld or t.stride(0) != T * ld or t.data_ptr() % 16 or t.shape != q.shape for t in (q, k, v)) or ld % 4):
         return None
     pp = p.reshape(-1, C).contiguous()
     if pp.shape[0] != 2 * T - 1:
@@ -556,8 +589,29 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
     pm = None if pad_mask is None else pad_mask.to(torch.uint8).contiguous()
     bu, bv = bias_u.detach().float().contiguous(), bias_v.detach().float().contiguous()      # named: must outlive the launch
     with torch.cuda.device(q.device):
-        out = torch.empty_like(q)
-        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(pp), _lib.ptr(bu),
+        out = torch.empty((B, T, C), dtype=torch.float32, device=q.device)
+        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ld, _lib.ptr(pp), _lib.ptr(bu),
                                             _lib.ptr(bv), _lib.ptr(pm), _lib.ptr(out), B, T, heads, 64,
                                             _lib.current_stream_handle()), "dsp_relpos_attention")
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, key_pad_mask: Optional[Tensor], heads: int) -> Optional[Tensor]:
+    """softmax(q k^T / sqrt(dk) + key padding) v per head at fp32 accuracy on the fp16 matrix cores (dsp_attention_split): q [B,N,C],
+    k / v [B,M,C] fp32, possibly column slices of a wider projection output (row-strided views; unit stride inside a row), C = heads * dk
+    with dk 64 or 128, key_pad_mask [B,M] bool or None.  Returns [B,N,C] contiguous, or None when the shape / mode is not served
+    (training, autocast, other head widths: the caller keeps torch's scaled_dot_product_attention)."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    dk = C // heads
+    if (not SPLIT_GEMM or torch.is_grad_enabled() or not q.is_cuda or torch.is_autocast_enabled() or dk * heads != C or dk not in (64, 128)
+            or any(t.dtype != torch.float32 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.stride(1) % 4 or t.data_ptr() % 16
+                   for t in (q, k, v)) or k.shape != v.shape or k.shape[0] != B or k.shape[2] != C or N < 1 or M < 1):
+        return None
+    lib = _lib.load()
+    pm = None if key_pad_mask is None else key_pad_mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(q.device):
+        out = torch.empty((B, N, C), dtype=torch.float32, device=q.device)
+        _lib.check(lib.dsp_attention_split(_lib.ptr(q), q.stride(1), _lib.ptr(k), k.stride(1), _lib.ptr(v), v.stride(1), _lib.ptr(pm), _lib.ptr(out),
+                                           B, N, M, heads, dk, float(dk) ** -0.5, _lib.current_stream_handle()), "dsp_attention_split")
     return out

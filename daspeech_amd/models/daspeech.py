@@ -137,13 +137,16 @@ class RelPosSelfAttention(nn.Module):
         B, T, C = x.shape
         L_ = decode_ops.linear
         if not self.training and self.dk == 64:
-            qf, kf, vf = L_(x, self.linear_q), L_(x, self.linear_k), L_(x, self.linear_v)
+            qf, kf, vf = decode_ops.linear_fused(x, (self.linear_q, self.linear_k, self.linear_v))
             o = decode_ops.relpos_attention(qf, kf, vf, L_(pos, self.linear_pos), self.pos_bias_u, self.pos_bias_v, pad_mask, self.h)
             if o is not None:                                         # one fused HIP kernel for scores, shift, soft-max and the value product
                 return L_(o, self.linear_out, residual=residual)
-        q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
-        k = L_(x, self.linear_k).view(B, T, self.h, self.dk).transpose(1, 2)
-        v = L_(x, self.linear_v).view(B, T, self.h, self.dk).transpose(1, 2)
+            qf, kf, vf = qf.contiguous(), kf.contiguous(), vf.contiguous()
+            q, k, v = qf.view(B, T, self.h, self.dk), kf.view(B, T, self.h, self.dk).transpose(1, 2), vf.view(B, T, self.h, self.dk).transpose(1, 2)
+        else:
+            q = L_(x, self.linear_q).view(B, T, self.h, self.dk)
+            k = L_(x, self.linear_k).view(B, T, self.h, self.dk).transpose(1, 2)
+            v = L_(x, self.linear_v).view(B, T, self.h, self.dk).transpose(1, 2)
         p = L_(pos, self.linear_pos).view(1, -1, self.h, self.dk).transpose(1, 2)
         ac = torch.matmul((q + self.pos_bias_u).transpose(1, 2), k.transpose(-2, -1))
         bd = self.rel_shift(torch.matmul((q + self.pos_bias_v).transpose(1, 2), p.transpose(-2, -1)))
@@ -241,9 +244,21 @@ class _MHA(nn.Module):
         B, N, C = x.shape
         M = mem.shape[1]
         L_ = decode_ops.linear
-        q = L_(x, self.q_proj).view(B, N, self.h, -1).transpose(1, 2)
-        k = L_(mem, self.k_proj).view(B, M, self.h, -1).transpose(1, 2)
-        v = L_(mem, self.v_proj).view(B, M, self.h, -1).transpose(1, 2)
+        if not self.training:
+            # eval: stacked projections (q|k|v of self-attention, k|v of the encoder attention) and the fp32-accurate matrix-core attention
+            if mem is x:
+                qf, kf, vf = decode_ops.linear_fused(x, (self.q_proj, self.k_proj, self.v_proj))
+            else:
+                qf = L_(x, self.q_proj)
+                kf, vf = decode_ops.linear_fused(mem, (self.k_proj, self.v_proj))
+            o = decode_ops.attention(qf, kf, vf, mem_pad, self.h)
+            if o is not None:
+                return L_(o, self.out_proj, residual=residual)
+            q, k, v = (t.reshape(B, -1, self.h, C // self.h).transpose(1, 2) for t in (qf, kf, vf))
+        else:
+            q = L_(x, self.q_proj).view(B, N, self.h, -1).transpose(1, 2)
+            k = L_(mem, self.k_proj).view(B, M, self.h, -1).transpose(1, 2)
+            v = L_(mem, self.v_proj).view(B, M, self.h, -1).transpose(1, 2)
         mask = None
         if mem_pad is not None:
             mask = torch.zeros(B, 1, 1, M, dtype=x.dtype, device=x.device).masked_fill(mem_pad.view(B, 1, 1, M), float("-inf"))

@@ -60,9 +60,17 @@ class _SelfAttention(nn.Module):
         B, N, C = x.shape
         h = self.heads
         from ..decode_ops import linear as L_                 # fp32-accurate split GEMM in eval-mode fp32 inference, torch otherwise
-        q = L_(x, self.q_proj).view(B, N, h, C // h).transpose(1, 2)
-        k = L_(x, self.k_proj).view(B, N, h, C // h).transpose(1, 2)
-        v = L_(x, self.v_proj).view(B, N, h, C // h).transpose(1, 2)
+        if not self.training:
+            from ..decode_ops import attention, linear_fused   # eval: one stacked q|k|v projection + the fp32-accurate matrix-core attention
+            qf, kf, vf = linear_fused(x, (self.q_proj, self.k_proj, self.v_proj))
+            o = attention(qf, kf, vf, padding_mask, h)
+            if o is not None:
+                return L_(o, self.out_proj)
+            q, k, v = (t.reshape(B, N, h, C // h).transpose(1, 2) for t in (qf, kf, vf))
+        else:
+            q = L_(x, self.q_proj).view(B, N, h, C // h).transpose(1, 2)
+            k = L_(x, self.k_proj).view(B, N, h, C // h).transpose(1, 2)
+            v = L_(x, self.v_proj).view(B, N, h, C // h).transpose(1, 2)
         mask = None
         if padding_mask is not None:
             mask = torch.zeros(B, 1, 1, N, dtype=x.dtype, device=x.device).masked_fill(padding_mask.view(B, 1, 1, N), float("-inf"))

@@ -124,11 +124,21 @@ int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, fl
 
 /* Conformer relative-position self-attention (fairseq conformer_layer.py / espnet RelPositionMultiHeadedAttention), fused, fp32:
  *   out[b,i,h,:] = sum_j softmax_j( ((q_i + u_h).k_j + (q_i + v_h).p_{(T-1)-i+j}) / sqrt(dk) ; keys with pad_mask[b,j] != 0 -> -inf ) v_j
- * q, k, v, out [B,T,H,dk] fp32 (the linear_q / linear_k / linear_v outputs viewed per head, no transposes), p [2T-1,H,dk] (linear_pos of
+ * q, k, v [B,T,H,dk] fp32 with `ld` floats between consecutive positions (H*dk for separate linear_q / linear_k / linear_v outputs,
+ * 3*H*dk for the slices of a fused projection; samples T*ld apart), out [B,T,H,dk] contiguous, p [2T-1,H,dk] (linear_pos of
  * the relative positional encoding, rows for relative positions T-1 .. -(T-1)), bias_u / bias_v [H,dk], pad_mask [B,T] bytes or NULL.
  * dk = 64, T <= 256 (longer sequences: the torch formulation). */
-int dsp_relpos_attention(const float* q, const float* k, const float* v, const float* p, const float* bias_u, const float* bias_v,
+int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld, const float* p, const float* bias_u, const float* bias_v,
                          const unsigned char* pad_mask, float* out, int B, int T, int H, int DK, dsp_stream_t stream);
+
+/* Multi-head attention with a key padding mask (fairseq modules/multihead_attention.py in eval mode: softmax(q k^T * scale + mask) v), at fp32
+ * accuracy on the fp16 matrix cores (every operand split into an fp16 hi / lo pair, three MFMAs per product):
+ *   out[b,i,h,:] = sum_j softmax_j( scale * q[b,i,h,:] . k[b,j,h,:] ; keys with key_pad_mask[b,j] != 0 -> -inf ) v[b,j,h,:]
+ * q [B,N,H,dk], k / v [B,M,H,dk] fp32 as row-strided views (ldq / ldk / ldv floats between consecutive positions, >= H*dk, %4 == 0;
+ * samples N*ldq / M*ldk / M*ldv apart: the slices of a fused q|k|v projection are served without a copy), key_pad_mask [B,M] bytes or
+ * NULL, out [B,N,H*dk] contiguous.  dk = 64 or 128.  A sample whose keys are all masked gets NaN rows, as torch's soft-max does. */
+int dsp_attention_split(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const unsigned char* key_pad_mask,
+                        float* out, int B, int N, int M, int H, int DK, float scale, dsp_stream_t stream);
 
 #ifdef __cplusplus
 }

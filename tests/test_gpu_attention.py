@@ -1,0 +1,92 @@
+"""dsp_attention_split (fp32-accurate matrix-core attention) against an fp64 torch restatement of fairseq's eval-mode
+MultiheadAttention core (modules/multihead_attention.py: softmax(q k^T * dk^-0.5 + key_padding_mask) v)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, pad, heads):
+    B, N, C = q.shape
+    M = k.shape[1]
+    dk = C // heads
+    qd, kd, vd = (t.double().view(B, -1, heads, dk).transpose(1, 2) for t in (q, k, v))
+    s = qd @ kd.transpose(-1, -2) * dk ** -0.5
+    if pad is not None:
+        s = s.masked_fill(pad.view(B, 1, 1, M), float("-inf"))
+    return (torch.softmax(s, -1) @ vd).transpose(1, 2).reshape(B, N, C)
+
+
+def _lengths_mask(lens, M, dev):
+    return torch.arange(M, device=dev)[None, :] >= torch.tensor(lens, device=dev)[:, None]
+
+
+CASES = [
+    # B, N, M, heads, dk, key lengths (None: no mask)
+    (3, 77, 77, 4, 64, [77, 40, 5]),
+    (2, 130, 45, 8, 64, [45, 31]),
+    (2, 33, 200, 2, 128, [200, 129]),
+    (4, 354, 354, 8, 64, [354, 300, 211, 97]),
+    (2, 500, 500, 2, 128, None),
+    (1, 1, 1, 1, 64, None),
+    (2, 128, 32, 2, 64, [32, 1]),
+]
+
+
+@pytest.mark.parametrize("B,N,M,H,dk,lens", CASES)
+def test_attention_split_matches_fp64(B, N, M, H, dk, lens):
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + N + M)
+    C = H * dk
+    q = (torch.randn(B, N, C, generator=g) * 1.5).to(dev)
+    k = (torch.randn(B, M, C, generator=g) * 1.5).to(dev)
+    v = (torch.randn(B, M, C, generator=g) * 2.0 + 0.3).to(dev)
+    pad = None if lens is None else _lengths_mask(lens, M, dev)
+    with torch.no_grad():
+        out = decode_ops.attention(q, k, v, pad, H)
+        assert out is not None and out.shape == (B, N, C) and out.is_contiguous()
+        ref = _ref(q, k, v, pad, H)
+        sd = torch.nn.functional.scaled_dot_product_attention(
+            *(t.view(B, -1, H, dk).transpose(1, 2) for t in (q, k, v)),
+            attn_mask=None if pad is None else torch.zeros(B, 1, 1, M, device=dev).masked_fill(pad.view(B, 1, 1, M), float("-inf")))
+        sd = sd.transpose(1, 2).reshape(B, N, C)
+    scale = ref.abs().max().item()
+    err = (out.double() - ref).abs().max().item() / scale
+    err_sd = (sd.double() - ref).abs().max().item() / scale
+    assert err < 3e-6, (err, err_sd)          # fp32 level: torch's own fp32 attention sits at ~1e-6 on these inputs
+    assert err < 4 * max(err_sd, 5e-7), (err, err_sd)
+
+
+def test_attention_split_serves_slices_of_a_fused_projection():
+    """q | k | v as column slices of one [B,N,3C] buffer (row stride 3C) give the same bits as contiguous copies."""
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, N, H, dk = 3, 150, 4, 64
+    C = H * dk
+    qkv = torch.randn(B, N, 3 * C, device=dev)
+    pad = _lengths_mask([150, 90, 33], N, dev)
+    with torch.no_grad():
+        a = decode_ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], pad, H)
+        b = decode_ops.attention(qkv[..., :C].contiguous(), qkv[..., C:2 * C].contiguous(), qkv[..., 2 * C:].contiguous(), pad, H)
+    assert a is not None and torch.equal(a, b)
+
+
+def test_attention_split_all_keys_masked_gives_nan_rows_like_torch():
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    q = torch.randn(2, 40, 128, device=dev); k = torch.randn(2, 50, 128, device=dev); v = torch.randn(2, 50, 128, device=dev)
+    pad = _lengths_mask([50, 0], 50, dev)
+    with torch.no_grad():
+        out = decode_ops.attention(q, k, v, pad, 2)
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1]).all()
+
+
+def test_attention_split_rejects_unsupported_head_width():
+    from daspeech_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 4, 96, device="cuda:0")
+    rc = lib.dsp_attention_split(_lib.ptr(x), 96, _lib.ptr(x), 96, _lib.ptr(x), 96, None, _lib.ptr(x), 1, 4, 4, 1, 96, 0.1, None)
+    assert rc != 0 and b"head width" in lib.dsp_last_error()
