@@ -14,6 +14,12 @@
 //         V^T fragments are written to LDS in that same order, so no transpose of P ever happens.
 // K and V tiles are read from global fp32, split and laid out as MFMA A-fragments in LDS by all four waves (double-buffered, one
 // barrier per tile); trailing key tiles that are padding for the whole sample are skipped (exact: their weights are 0).
+//
+// REL = true is the Conformer's relative-position attention (fairseq/modules/espnet_multihead_attention.py:172-254
+// RelPositionMultiHeadedAttention):  score(i, j) = (q_i + u) . k_j + (q_i + v) . pos[T-1 - i + j].  The second term is formed per wave
+// and key tile as G^T = pos[rbase .. rbase + 63] . (Q + v)^T (two 32-row blocks of the position projection, kept in an LDS ring that
+// takes one new block per tile) and read back from a per-wave scratch at [query][key - query + 31]: the rel_shift of the torch
+// formulation without its [B,h,T,2T-1] tensor.  (r03's fp32-FMA kernel for this: 113 us per layer at B=32, T=200; this one ~15.)
 #include "common.h"
 #include "../../include/daspeech_decode.h"
 
@@ -27,6 +33,7 @@ struct AtParams {
     const float* q; const float* k; const float* v; const unsigned char* kmask; float* out;
     long ldq, ldk, ldv, bq, bk, bv;      // row strides and sample strides (floats)
     int B, N, M, H, ntq; float scale;
+    const float* pos; const float* bias_u; const float* bias_v;      // relative-position variant: pos [2T-1][H*dk], biases [H][dk]
 };
 
 constexpr int AT_QW = 32, AT_WAVES = 4, AT_QT = AT_QW * AT_WAVES, AT_KT = 32;
@@ -37,6 +44,9 @@ template <int DK> struct AtLds {
     static constexpr int KF = (DK / 16) * 2 * AT_FRAG;             // K fragments: [dk/16 steps][hi, lo]
     static constexpr int VF = (DK / 32) * 2 * 2 * AT_FRAG;         // V^T fragments: [dk/32 row blocks][2 key steps][hi, lo]
     static constexpr int STAGE = KF + VF + AT_KT * 4;              // + additive key bias (0 / -inf)
+    // relative-position variant: a ring of 32-row blocks of the position projection (K's fragment layout) and a [32][64] (+4) score
+    // scratch per wave for the shift of the [query][relative position] product into [query][key]
+    static constexpr int PRING = 6, PBLK = KF, SCR_PITCH = 68, SCR = 32 * SCR_PITCH * 4;
 };
 
 __device__ __forceinline__ void at_split8(const float* x, at_h8& hi, at_h8& lo) {
@@ -44,7 +54,7 @@ __device__ __forceinline__ void at_split8(const float* x, at_h8& hi, at_h8& lo) 
     for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)x[e]; lo[e] = (_Float16)((x[e] - (float)hi[e]) * 2048.f); }
 }
 
-template <int DK>
+template <int DK, bool REL>
 __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
@@ -76,7 +86,8 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
     const int nt = s_last < 0 ? 1 : (s_last + AT_KT) / AT_KT;
 
     // ---- this lane's query as B fragments (k = d, column = query), hi / lo
-    at_h8 qh[NC], ql[NC];
+    at_h8 qh[NC], ql[NC];                              // REL: q + u (content term)
+    at_h8 rh[REL ? NC : 1], rl[REL ? NC : 1];          // REL: q + v (position term)
     {
         const int qi = min(q0 + col, p.N - 1);
         const float* Q = p.q + (size_t)b * p.bq + (size_t)qi * p.ldq + (size_t)h * DK + 8 * g;
@@ -85,13 +96,48 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
             float x[8];
             *reinterpret_cast<float4*>(x) = *reinterpret_cast<const float4*>(Q + c * 16);
             *reinterpret_cast<float4*>(x + 4) = *reinterpret_cast<const float4*>(Q + c * 16 + 4);
+            if constexpr (REL) {
+                float bu[8], bw[8], y[8];
+                *reinterpret_cast<float4*>(bu) = *reinterpret_cast<const float4*>(p.bias_u + h * DK + 8 * g + c * 16);
+                *reinterpret_cast<float4*>(bu + 4) = *reinterpret_cast<const float4*>(p.bias_u + h * DK + 8 * g + c * 16 + 4);
+                *reinterpret_cast<float4*>(bw) = *reinterpret_cast<const float4*>(p.bias_v + h * DK + 8 * g + c * 16);
+                *reinterpret_cast<float4*>(bw + 4) = *reinterpret_cast<const float4*>(p.bias_v + h * DK + 8 * g + c * 16 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { y[e] = x[e] + bw[e]; x[e] += bu[e]; }
+                at_split8(y, rh[c], rl[c]);
+            }
             at_split8(x, qh[c], ql[c]);
         }
     }
-
     // ---- staging registers: K rows (8 floats per pass) and V columns (4 keys of one d per item)
     float kr[KP][8], vr[VJ][4]; unsigned char mb = 0;
     const int k_kl = tid & 3, k_d8 = (tid >> 2) & 7, k_kh = tid >> 5, k_key = k_kh * 4 + k_kl;
+    // REL: block u of the position projection holds its rows R0 + 32 (u - 3) .. + 31 in K's fragment layout.  The row for (query i,
+    // key j) is T-1 - i + j, so tile t of wave w reads blocks u = t - w + 3 and u + 1, the workgroup blocks t .. t + 4: a ring of 6
+    // with one new block per tile.  The wave's [relative position][query] product goes through a per-wave scratch for the shift.
+    char* pring = at_smem + 2 * L::STAGE;
+    float* scr = reinterpret_cast<float*>(pring + L::PRING * L::PBLK + wave * L::SCR);
+    const int R0 = p.N - 32 - qt * AT_QT, nrel = 2 * p.N - 1;
+    const float* Pb = REL ? p.pos + (size_t)h * DK + k_d8 * 8 : nullptr;
+    const long ldp = (long)p.H * DK;
+    float pr[8]; bool pr_ok = false;
+    auto pos_load = [&](int u, float* dst) -> bool {
+        const int r = R0 + 32 * (u - 3) + k_key;
+        const bool ok = r >= 0 && r < nrel;
+        const float* src = Pb + (size_t)(ok ? r : 0) * ldp;
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+        return ok;
+    };
+    auto pos_store = [&](int u, const float* x, bool ok) {
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = ok ? x[e] : 0.f;
+        at_h8 hi, lo; at_split8(z, hi, lo);
+        char* dst = pring + (u % L::PRING) * L::PBLK + ((k_d8 >> 1) * 2) * AT_FRAG + (k_d8 & 1) * AT_HALF + k_key * 16;
+        *reinterpret_cast<at_h8*>(dst) = hi;
+        *reinterpret_cast<at_h8*>(dst + AT_FRAG) = lo;
+    };
     auto stage_load = [&](int t) {
         const int key0 = t * AT_KT;
         {
@@ -110,8 +156,10 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
             for (int i = 0; i < 4; ++i) vr[j][i] = Vb[(size_t)min(key0 + 4 * kq + i, p.M - 1) * p.ldv + d];
         }
         if (tid < AT_KT) { const int kj = key0 + tid; mb = (kj >= p.M) ? 1 : (mk ? mk[kj] : 0); }
+        if constexpr (REL) pr_ok = pos_load(t + 4, pr);
     };
-    auto stage_store = [&](char* st) {
+    auto stage_store = [&](char* st, int t) {
+        if constexpr (REL) pos_store(t + 4, pr, pr_ok);
 #pragma unroll
         for (int ps = 0; ps < KP; ++ps) {
             at_h8 hi, lo; at_split8(kr[ps], hi, lo);
@@ -142,8 +190,15 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
     float m_run = NEG_INF, l_run = 0.f;
     const int lane_off = g * AT_HALF + col * 16;
 
+    if constexpr (REL) {                               // blocks 0 .. 3 (tile 0 adds block 4)
+        float x[4][8]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ok[u] = pos_load(u, x[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pos_store(u, x[u], ok[u]);
+    }
     stage_load(0);
-    stage_store(at_smem);
+    stage_store(at_smem, 0);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         char* cur = at_smem + (t & 1) * L::STAGE;
@@ -164,12 +219,45 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
             const float* bias = reinterpret_cast<const float*>(cur + L::KF + L::VF);
             float s[16], mx = NEG_INF;
 #pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = shh[r] + slo[r] * (1.f / 2048.f);
+            if constexpr (REL) {
+                // G^T[rr][query] = pos[rbase + rr] . (q + v), rr = 0 .. 63 (two row blocks); the score of key jj wants rr = jj - query + 31
+                const int u0 = t - wave + 3;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const char* pf = pring + ((u0 + blk) % L::PRING) * L::PBLK;
+                    at_f16 ghh, glo;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ghh[r] = 0.f; glo[r] = 0.f; }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const at_h8 ph_ = *reinterpret_cast<const at_h8*>(pf + (c * 2) * AT_FRAG + lane_off);
+                        const at_h8 pl_ = *reinterpret_cast<const at_h8*>(pf + (c * 2 + 1) * AT_FRAG + lane_off);
+                        ghh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph_, rh[c], ghh, 0, 0, 0);
+                        glo = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl_, rh[c], glo, 0, 0, 0);
+                        glo = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph_, rl[c], glo, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float4 o;
+                        o.x = ghh[4 * j + 0] + glo[4 * j + 0] * (1.f / 2048.f); o.y = ghh[4 * j + 1] + glo[4 * j + 1] * (1.f / 2048.f);
+                        o.z = ghh[4 * j + 2] + glo[4 * j + 2] * (1.f / 2048.f); o.w = ghh[4 * j + 3] + glo[4 * j + 3] * (1.f / 2048.f);
+                        *reinterpret_cast<float4*>(scr + col * L::SCR_PITCH + 32 * blk + 8 * j + 4 * g) = o;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float* sq = scr + col * (L::SCR_PITCH - 1) + 31 + 4 * g;      // [query][jj - query + 31]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] += sq[8 * (r >> 2) + (r & 3)];
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 b4 = *reinterpret_cast<const float4*>(bias + 8 * j + 4 * g);
-                s[4 * j + 0] = (shh[4 * j + 0] + slo[4 * j + 0] * (1.f / 2048.f)) * p.scale + b4.x;
-                s[4 * j + 1] = (shh[4 * j + 1] + slo[4 * j + 1] * (1.f / 2048.f)) * p.scale + b4.y;
-                s[4 * j + 2] = (shh[4 * j + 2] + slo[4 * j + 2] * (1.f / 2048.f)) * p.scale + b4.z;
-                s[4 * j + 3] = (shh[4 * j + 3] + slo[4 * j + 3] * (1.f / 2048.f)) * p.scale + b4.w;
+                s[4 * j + 0] = s[4 * j + 0] * p.scale + b4.x;
+                s[4 * j + 1] = s[4 * j + 1] * p.scale + b4.y;
+                s[4 * j + 2] = s[4 * j + 2] * p.scale + b4.z;
+                s[4 * j + 3] = s[4 * j + 3] * p.scale + b4.w;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -208,7 +296,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
                     olo[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[c2], olo[db], 0, 0, 0);
                 }
         }
-        if (t + 1 < nt) stage_store(at_smem + ((t + 1) & 1) * L::STAGE);
+        if (t + 1 < nt) stage_store(at_smem + ((t + 1) & 1) * L::STAGE, t + 1);
         __syncthreads();
     }
     // ---- out[b, q, h, d] = O^T[d][q] / l   (a lane: one query, d = 32 db + 8 j + 4 g + 0..3)
@@ -233,11 +321,12 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
     }
 }
 
-template <int DK>
+template <int DK, bool REL>
 static int at_launch(const AtParams& p, hipStream_t st)
 {
-    const size_t lds = 2 * (size_t)AtLds<DK>::STAGE;
-    auto k = attention_split_kernel<DK>;
+    using L = AtLds<DK>;
+    const size_t lds = 2 * (size_t)L::STAGE + (REL ? (size_t)L::PRING * L::PBLK + (size_t)AT_WAVES * L::SCR : 0);
+    auto k = attention_split_kernel<DK, REL>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(p.ntq * p.H * p.B)), dim3(256), lds, st, p);
     return check_launch("attention_split");
@@ -261,5 +350,24 @@ extern "C" int dsp_attention_split(const float* q, long ldq, const float* k, lon
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bq = (long)N * ldq; p.bk = (long)M * ldk; p.bv = (long)M * ldv;
     p.B = B; p.N = N; p.M = M; p.H = H; p.ntq = (N + AT_QT - 1) / AT_QT; p.scale = scale;
     hipStream_t st = as_stream(stream);
-    return DK == 64 ? at_launch<64>(p, st) : at_launch<128>(p, st);
+    p.pos = nullptr; p.bias_u = nullptr; p.bias_v = nullptr;
+    return DK == 64 ? at_launch<64, false>(p, st) : at_launch<128, false>(p, st);
+}
+
+extern "C" int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld, const float* pos, const float* bias_u, const float* bias_v,
+                                          const unsigned char* pad_mask, float* out, int B, int T, int H, int DK, dsp_stream_t stream)
+{
+    using namespace dsp;
+    if (B < 0 || T < 1 || H < 1 || DK != 64) { set_error("relpos_attention: bad sizes B=%d T=%d H=%d dk=%d (head width 64)", B, T, H, DK); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!q || !k || !v || !pos || !bias_u || !bias_v || !out) { set_error("relpos_attention: null pointer"); return DSP_EINVAL; }
+    if (((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out) | ((uintptr_t)pos) | ((uintptr_t)bias_u) | ((uintptr_t)bias_v)) & 15) || (ld & 3)
+        || ld < (long)H * DK) {
+        set_error("relpos_attention: pointers must be 16-byte aligned, row stride >= H * dk and %% 4 == 0"); return DSP_EINVAL; }
+    AtParams p;
+    p.q = q; p.k = k; p.v = v; p.kmask = pad_mask; p.out = out;
+    p.ldq = p.ldk = p.ldv = ld; p.bq = p.bk = p.bv = (long)T * ld;
+    p.B = B; p.N = T; p.M = T; p.H = H; p.ntq = (T + AT_QT - 1) / AT_QT; p.scale = 1.f / sqrtf((float)DK);
+    p.pos = pos; p.bias_u = bias_u; p.bias_v = bias_v;
+    return at_launch<64, true>(p, as_stream(stream));
 }

@@ -579,7 +579,7 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
     [B,T] bool.  Returns [B,T,C] contiguous, or None when the shape / mode is not served."""
     B, T, C = q.shape
     ld = q.stride(1)
-    if (not SPLIT_GEMM or torch.is_grad_enabled() or not q.is_cuda or q.dtype != torch.float32 or torch.is_autocast_enabled() or C != heads * 64 or T > 256
+    if (not SPLIT_GEMM or torch.is_grad_enabled() or not q.is_cuda or q.dtype != torch.float32 or torch.is_autocast_enabled() or C != heads * 64
             or any(t.stride(2) != 1 or t.stride(1) != ld or t.stride(0) != T * ld or t.data_ptr() % 16 or t.shape != q.shape for t in (q, k, v)) or ld % 4):
         return None
     pp = p.reshape(-1, C).contiguous()
@@ -590,9 +590,8 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
     bu, bv = bias_u.detach().float().contiguous(), bias_v.detach().float().contiguous()      # named: must outlive the launch
     with torch.cuda.device(q.device):
         out = torch.empty((B, T, C), dtype=torch.float32, device=q.device)
-        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ld, _lib.ptr(pp), _lib.ptr(bu),
-                                            _lib.ptr(bv), _lib.ptr(pm), _lib.ptr(out), B, T, heads, 64,
-                                            _lib.current_stream_handle()), "dsp_relpos_attention")
+        _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ld, _lib.ptr(pp), _lib.ptr(bu), _lib.ptr(bv), _lib.ptr(pm),
+                                            _lib.ptr(out), B, T, heads, 64, _lib.current_stream_handle()), "dsp_relpos_attention")
     return out
 
 

@@ -127,7 +127,8 @@ int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, fl
  * q, k, v [B,T,H,dk] fp32 with `ld` floats between consecutive positions (H*dk for separate linear_q / linear_k / linear_v outputs,
  * 3*H*dk for the slices of a fused projection; samples T*ld apart), out [B,T,H,dk] contiguous, p [2T-1,H,dk] (linear_pos of
  * the relative positional encoding, rows for relative positions T-1 .. -(T-1)), bias_u / bias_v [H,dk], pad_mask [B,T] bytes or NULL.
- * dk = 64, T <= 256 (longer sequences: the torch formulation). */
+ * dk = 64, any T.  Runs on the fp16 matrix cores at fp32 accuracy like dsp_attention_split (below); the [query][relative position]
+ * product is formed per 32-query x 64-position block and shifted into [query][key] through LDS. */
 int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld, const float* p, const float* bias_u, const float* bias_v,
                          const unsigned char* pad_mask, float* out, int B, int T, int H, int DK, dsp_stream_t stream);
 
@@ -139,6 +140,7 @@ int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld
  * NULL, out [B,N,H*dk] contiguous.  dk = 64 or 128.  A sample whose keys are all masked gets NaN rows, as torch's soft-max does. */
 int dsp_attention_split(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const unsigned char* key_pad_mask,
                         float* out, int B, int N, int M, int H, int DK, float scale, dsp_stream_t stream);
+
 
 #ifdef __cplusplus
 }

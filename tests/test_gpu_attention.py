@@ -90,3 +90,33 @@ def test_attention_split_rejects_unsupported_head_width():
     x = torch.zeros(1, 4, 96, device="cuda:0")
     rc = lib.dsp_attention_split(_lib.ptr(x), 96, _lib.ptr(x), 96, _lib.ptr(x), 96, None, _lib.ptr(x), 1, 4, 4, 1, 96, 0.1, None)
     assert rc != 0 and b"head width" in lib.dsp_last_error()
+
+
+@pytest.mark.parametrize("B,T,H,lens", [(3, 77, 4, [77, 40, 5]), (2, 200, 4, [200, 131]), (1, 5, 2, None), (2, 256, 1, [256, 255]),
+                                        (2, 300, 4, [300, 170]), (1, 513, 2, None), (32, 177, 4, None)])
+def test_relpos_attention_split_matches_fp64(B, T, H, lens):
+    """dsp_relpos_attention_split against an fp64 restatement of espnet's RelPositionMultiHeadedAttention core
+    (fairseq/modules/espnet_multihead_attention.py:172-254: matrix_ac + rel_shift(matrix_bd), masked soft-max, value product)."""
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(T)
+    C = H * 64
+    q, k, v = ((torch.randn(B, T, C, generator=g) * 1.2).to(dev) for _ in range(3))
+    pos = torch.randn(2 * T - 1, C, generator=g).to(dev)
+    bu, bv = (torch.randn(H, 64, generator=g) * 0.5).to(dev), (torch.randn(H, 64, generator=g) * 0.5).to(dev)
+    pad = None if lens is None else _lengths_mask(lens, T, dev)
+    with torch.no_grad():
+        out = decode_ops.relpos_attention(q, k, v, pos.unsqueeze(0), bu, bv, pad, H)
+    assert out is not None
+    qd, kd, vd = (t.double().view(B, T, H, 64) for t in (q, k, v))
+    pd = pos.double().view(2 * T - 1, H, 64)
+    ac = torch.einsum("bihd,bjhd->bhij", qd + bu.double(), kd)
+    bd_full = torch.einsum("bihd,rhd->bhir", qd + bv.double(), pd)                      # [B,H,T,2T-1]
+    idx = (T - 1) - torch.arange(T, device=dev)[:, None] + torch.arange(T, device=dev)[None, :]
+    bd = torch.gather(bd_full, 3, idx.expand(B, H, T, T))
+    s = (ac + bd) / 8.0
+    if pad is not None:
+        s = s.masked_fill(pad.view(B, 1, 1, T), float("-inf"))
+    ref = torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1), vd).reshape(B, T, C)
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6, err

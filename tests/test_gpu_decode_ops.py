@@ -381,7 +381,7 @@ def test_layer_norm_kernel_matches_torch(shape):
     torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("shape", [(3, 77, 4), (2, 200, 4), (1, 5, 2), (2, 256, 1), (4, 33, 8)])
+@pytest.mark.parametrize("shape", [(3, 77, 4), (2, 200, 4), (1, 5, 2), (2, 256, 1), (4, 33, 8), (2, 300, 4)])
 def test_fused_relpos_attention_matches_torch_formulation(shape):
     """dsp_relpos_attention vs the torch formulation of the Conformer's relative-position attention (two batched GEMMs, rel_shift,
     masked soft-max, value GEMM) on ragged batches: fp32, tolerance 2e-5 (different summation order)."""

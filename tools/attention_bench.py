@@ -38,3 +38,16 @@ for name, B, N, M, H, dk in SHAPES:
     fl = 4.0 * B * H * N * M * dk
     print(f"{name:14s} B={B} N={N} M={M} H={H} dk={dk}: torch sdpa {t_sd:7.1f} us  split {t_us:7.1f} us  ({fl / t_us * 1e-6:6.1f} TFLOP/s nominal)  "
           f"max err split {e_us:.2e} sdpa {e_sd:.2e}")
+
+
+# Conformer relative-position attention (r03's fp32-FMA kernel: 83.5 / 48.4 / 112.7 us at T = 177 / 120 / 200)
+for B, T, H in [(32, 177, 4), (32, 120, 4), (32, 200, 4)]:
+    C = H * 64
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(B, T, C, device=dev) for _ in range(3))
+    pos = torch.randn(1, 2 * T - 1, C, device=dev); bu, bv = torch.randn(H, 64, device=dev), torch.randn(H, 64, device=dev)
+    lens = torch.randint(int(0.45 * T), T + 1, (B,), device=dev); lens[0] = T
+    pad = torch.arange(T, device=dev)[None] >= lens[:, None]
+    with torch.no_grad():
+        t_us = timeit(lambda: decode_ops.relpos_attention(q, k, v, pos, bu, bv, pad, H))
+    print(f"relpos B={B} T={T} H={H}: {t_us:7.1f} us")
