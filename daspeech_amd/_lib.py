@@ -60,8 +60,11 @@ SIGNATURES = {
     "dsp_conv1d_split": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_conv1d_split_residual": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_int,
                                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_conv1d_split_ragged": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_int,
+                                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p]),
     "dsp_relpos_attention": (_c_int, [_c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
-    "dsp_attention_split": (_c_int, [_c_p, ctypes.c_long, _c_p, ctypes.c_long, _c_p, ctypes.c_long, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
+    "dsp_attention_split": (_c_int, [_c_p, ctypes.c_long, _c_p, ctypes.c_long, _c_p, ctypes.c_long, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                                     _c_p, _c_int, _c_p]),
     "dsp_layer_norm": (_c_int, [_c_p, _c_p, _c_p, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_p]),
     "dsp_dwconv_bn_silu": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_conv": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int),

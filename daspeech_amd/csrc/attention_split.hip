@@ -34,6 +34,7 @@ struct AtParams {
     long ldq, ldk, ldv, bq, bk, bv;      // row strides and sample strides (floats)
     int B, N, M, H, ntq; float scale;
     const float* pos; const float* bias_u; const float* bias_v;      // relative-position variant: pos [2T-1][H*dk], biases [H][dk]
+    const int* qlens; int qslack;        // ragged batch: queries >= qlens[b] + qslack are padding nobody reads: zeros, not computed
 };
 
 constexpr int AT_QW = 32, AT_WAVES = 4, AT_QT = AT_QW * AT_WAVES, AT_KT = 32;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void at_split8(const float* x, at_h8& hi, at_h8& lo) 
 }
 
 template <int DK, bool REL>
-__global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
+__global__ __launch_bounds__(256, (DK == 64 && !REL) ? 2 : 1) void attention_split_kernel(AtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
     __shared__ int s_last;
@@ -69,7 +70,15 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
     if ((nwork & 7) == 0) w = (blockIdx.x & 7) * (nwork >> 3) + (blockIdx.x >> 3);
     const int qt = w % p.ntq, h = (w / p.ntq) % p.H, b = w / (p.ntq * p.H);
     const int q0 = qt * AT_QT + wave * AT_QW;
-    const bool live = q0 < p.N;                        // wave-uniform: waves past the last query only help staging
+    const int qlim = p.qlens ? min(p.N, p.qlens[b] + p.qslack) : p.N;
+    const bool live = q0 < qlim;                       // wave-uniform: waves past the last query only help staging
+    if (!live && q0 < p.N) {                           // padding queries of a ragged batch: zero rows (finite for the layers that follow)
+        for (int e = lane; e < AT_QW * (DK / 4); e += 64) {
+            const int r = e / (DK / 4), c4 = e - r * (DK / 4);
+            if (q0 + r < p.N) *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + q0 + r) * ((size_t)p.H * DK) + (size_t)h * DK + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (qt * AT_QT >= qlim) return;                    // block-uniform: nothing to compute for this tile
     const float* Kb = p.k + (size_t)b * p.bk + (size_t)h * DK;
     const float* Vb = p.v + (size_t)b * p.bv + (size_t)h * DK;
     const unsigned char* mk = p.kmask ? p.kmask + (size_t)b * p.M : nullptr;
@@ -110,7 +119,9 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
         }
     }
     // ---- staging registers: K rows (8 floats per pass) and V columns (4 keys of one d per item)
-    float kr[KP][8], vr[VJ][4]; unsigned char mb = 0;
+    struct Stg { float kr[KP][8], vr[VJ][4], pr[REL ? 8 : 1]; unsigned char mb; bool pr_ok; };
+    Stg sA, sB;                                        // two sets: the loads of a tile are issued TWO tiles ahead (one iteration is shorter
+                                                       // than a trip to HBM: with one set in flight every tile waited for its loads)
     const int k_kl = tid & 3, k_d8 = (tid >> 2) & 7, k_kh = tid >> 5, k_key = k_kh * 4 + k_kl;
     // REL: block u of the position projection holds its rows R0 + 32 (u - 3) .. + 31 in K's fragment layout.  The row for (query i,
     // key j) is T-1 - i + j, so tile t of wave w reads blocks u = t - w + 3 and u + 1, the workgroup blocks t .. t + 4: a ring of 6
@@ -120,7 +131,6 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
     const int R0 = p.N - 32 - qt * AT_QT, nrel = 2 * p.N - 1;
     const float* Pb = REL ? p.pos + (size_t)h * DK + k_d8 * 8 : nullptr;
     const long ldp = (long)p.H * DK;
-    float pr[8]; bool pr_ok = false;
     auto pos_load = [&](int u, float* dst) -> bool {
         const int r = R0 + 32 * (u - 3) + k_key;
         const bool ok = r >= 0 && r < nrel;
@@ -138,31 +148,32 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
         *reinterpret_cast<at_h8*>(dst) = hi;
         *reinterpret_cast<at_h8*>(dst + AT_FRAG) = lo;
     };
-    auto stage_load = [&](int t) {
+    auto stage_load = [&](int t, Stg& r) {
         const int key0 = t * AT_KT;
         {
             const int kj = min(key0 + k_key, p.M - 1);
             const float* src = Kb + (size_t)kj * p.ldk + k_d8 * 8;
 #pragma unroll
             for (int ps = 0; ps < KP; ++ps) {
-                *reinterpret_cast<float4*>(kr[ps]) = *reinterpret_cast<const float4*>(src + ps * 64);
-                *reinterpret_cast<float4*>(kr[ps] + 4) = *reinterpret_cast<const float4*>(src + ps * 64 + 4);
+                *reinterpret_cast<float4*>(r.kr[ps]) = *reinterpret_cast<const float4*>(src + ps * 64);
+                *reinterpret_cast<float4*>(r.kr[ps] + 4) = *reinterpret_cast<const float4*>(src + ps * 64 + 4);
             }
         }
 #pragma unroll
         for (int j = 0; j < VJ; ++j) {
             const int it = tid + 256 * j, d = it % DK, kq = it / DK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vr[j][i] = Vb[(size_t)min(key0 + 4 * kq + i, p.M - 1) * p.ldv + d];
+            for (int i = 0; i < 4; ++i) r.vr[j][i] = Vb[(size_t)min(key0 + 4 * kq + i, p.M - 1) * p.ldv + d];
         }
-        if (tid < AT_KT) { const int kj = key0 + tid; mb = (kj >= p.M) ? 1 : (mk ? mk[kj] : 0); }
-        if constexpr (REL) pr_ok = pos_load(t + 4, pr);
+        r.mb = 0;
+        if (tid < AT_KT) { const int kj = key0 + tid; r.mb = (kj >= p.M) ? 1 : (mk ? mk[kj] : 0); }
+        if constexpr (REL) r.pr_ok = pos_load(t + 4, r.pr);
     };
-    auto stage_store = [&](char* st, int t) {
-        if constexpr (REL) pos_store(t + 4, pr, pr_ok);
+    auto stage_store = [&](char* st, int t, const Stg& r) {
+        if constexpr (REL) pos_store(t + 4, r.pr, r.pr_ok);
 #pragma unroll
         for (int ps = 0; ps < KP; ++ps) {
-            at_h8 hi, lo; at_split8(kr[ps], hi, lo);
+            at_h8 hi, lo; at_split8(r.kr[ps], hi, lo);
             const int d8 = k_d8 + 8 * ps, c = d8 >> 1, gk = d8 & 1;
             char* dst = st + (c * 2) * AT_FRAG + gk * AT_HALF + k_key * 16;
             *reinterpret_cast<at_h8*>(dst) = hi;
@@ -174,12 +185,12 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
             const int db = d >> 5, c2 = kq >> 2, e4 = (kq >> 1) & 1, gv = kq & 1;
             at_h4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)vr[j][i]; lo[i] = (_Float16)((vr[j][i] - (float)hi[i]) * 2048.f); }
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)r.vr[j][i]; lo[i] = (_Float16)((r.vr[j][i] - (float)hi[i]) * 2048.f); }
             char* dst = st + L::KF + ((db * 2 + c2) * 2) * AT_FRAG + gv * AT_HALF + (d & 31) * 16 + e4 * 8;
             *reinterpret_cast<at_h4*>(dst) = hi;
             *reinterpret_cast<at_h4*>(dst + AT_FRAG) = lo;
         }
-        if (tid < AT_KT) reinterpret_cast<float*>(st + L::KF + L::VF)[tid] = mb ? NEG_INF : 0.f;
+        if (tid < AT_KT) reinterpret_cast<float*>(st + L::KF + L::VF)[tid] = r.mb ? NEG_INF : 0.f;
     };
 
     at_f16 ohh[NDB], olo[NDB];
@@ -197,12 +208,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
 #pragma unroll
         for (int u = 0; u < 4; ++u) pos_store(u, x[u], ok[u]);
     }
-    stage_load(0);
-    stage_store(at_smem, 0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        char* cur = at_smem + (t & 1) * L::STAGE;
-        if (t + 1 < nt) stage_load(t + 1);
+    auto tile = [&](int t, const char* cur) {
         if (live) {
             // ---- S^T tile: 32 keys x 32 queries
             at_f16 shh, slo;
@@ -296,7 +302,20 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AtParams p)
                     olo[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[c2], olo[db], 0, 0, 0);
                 }
         }
-        if (t + 1 < nt) stage_store(at_smem + ((t + 1) & 1) * L::STAGE, t + 1);
+    };
+    stage_load(0, sA);
+    stage_store(at_smem, 0, sA);
+    if (nt > 1) stage_load(1, sB);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        if (t + 2 < nt) stage_load(t + 2, sA);
+        tile(t, at_smem);
+        if (t + 1 >= nt) break;
+        stage_store(at_smem + L::STAGE, t + 1, sB);
+        __syncthreads();
+        if (t + 3 < nt) stage_load(t + 3, sB);
+        tile(t + 1, at_smem + L::STAGE);
+        if (t + 2 < nt) stage_store(at_smem, t + 2, sA);
         __syncthreads();
     }
     // ---- out[b, q, h, d] = O^T[d][q] / l   (a lane: one query, d = 32 db + 8 j + 4 g + 0..3)
@@ -335,7 +354,7 @@ static int at_launch(const AtParams& p, hipStream_t st)
 }  // namespace dsp
 
 extern "C" int dsp_attention_split(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const unsigned char* key_pad_mask,
-                                   float* out, int B, int N, int M, int H, int DK, float scale, dsp_stream_t stream)
+                                   float* out, int B, int N, int M, int H, int DK, float scale, const int* q_lens, int q_slack, dsp_stream_t stream)
 {
     using namespace dsp;
     if (B < 0 || N < 1 || M < 1 || H < 1 || (DK != 64 && DK != 128)) {
@@ -350,7 +369,7 @@ extern "C" int dsp_attention_split(const float* q, long ldq, const float* k, lon
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bq = (long)N * ldq; p.bk = (long)M * ldk; p.bv = (long)M * ldv;
     p.B = B; p.N = N; p.M = M; p.H = H; p.ntq = (N + AT_QT - 1) / AT_QT; p.scale = scale;
     hipStream_t st = as_stream(stream);
-    p.pos = nullptr; p.bias_u = nullptr; p.bias_v = nullptr;
+    p.pos = nullptr; p.bias_u = nullptr; p.bias_v = nullptr; p.qlens = q_lens; p.qslack = q_slack < 0 ? 0 : q_slack;
     return DK == 64 ? at_launch<64, false>(p, st) : at_launch<128, false>(p, st);
 }
 
@@ -368,6 +387,6 @@ extern "C" int dsp_relpos_attention(const float* q, const float* k, const float*
     p.q = q; p.k = k; p.v = v; p.kmask = pad_mask; p.out = out;
     p.ldq = p.ldk = p.ldv = ld; p.bq = p.bk = p.bv = (long)T * ld;
     p.B = B; p.N = T; p.M = T; p.H = H; p.ntq = (T + AT_QT - 1) / AT_QT; p.scale = 1.f / sqrtf((float)DK);
-    p.pos = pos; p.bias_u = bias_u; p.bias_v = bias_v;
+    p.pos = pos; p.bias_u = bias_u; p.bias_v = bias_v; p.qlens = nullptr; p.qslack = 0;
     return at_launch<64, true>(p, as_stream(stream));
 }

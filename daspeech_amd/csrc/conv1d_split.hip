@@ -24,7 +24,8 @@ struct CsParams {
     int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
     int nslices; long wslice;      // the input is nslices x CI channels wide; slice s uses weights + s * wslice (halves)
     const float* res; long ldr; float alpha;      // out = res + alpha * act(bias + conv)   (res may be NULL: out = alpha * act(...))
-};
+    const int* lens; int slack;                   // ragged batch: rows >= lens[b] + slack of sample b are padding nobody reads — their
+};                                                // tiles are not computed, the output rows are written as zeros
 
 template <int CI>
 __device__ __forceinline__ int cs_swz(int row, int chunk) {
@@ -54,6 +55,16 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     const int wm = wave % WM, wn = wave / WM;
     const int lr = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z, t0 = blockIdx.x * NT, m0 = blockIdx.y * MT;
+    if (p.lens && t0 >= p.lens[b] + p.slack) {          // a tile of padding rows (block-uniform): zeros, so that they stay finite
+        if (p.accumulate) return;
+        const int cw = min(MT, p.M - m0) >> 2;          // float4 columns of this tile
+        const int rows = min(NT, p.T - t0);
+        for (int e = tid; e < rows * cw; e += 512) {
+            const int r = e / cw, c4 = e - r * cw;
+            *reinterpret_cast<float4*>(p.out + ((size_t)b * p.T + t0 + r) * p.ldo + m0 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const int P = (p.ntaps - 1) / 2;
     const int R = NT + p.ntaps - 1;
     char* th = cs_smem;                                   // hi tile  [R][CI] halves, 16-byte chunks XOR-swizzled
@@ -255,7 +266,7 @@ extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void*
 
 static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
                   int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, const float* res, long ldr, float alpha,
-                  dsp_stream_t stream)
+                  dsp_stream_t stream, const int* lens = nullptr, int slack = 0)
 {
     if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || nslices < 1 || ldx < (long)CI * nslices || ldo < M ||
         (ldx & 3) || (ldo & 3)) {
@@ -267,7 +278,7 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
     p.x = x; p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.bias = bias; p.out = out;
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
     p.nslices = nslices; p.wslice = dsp_conv1d_split_packed_elems(ntaps, M, CI);
-    p.res = res; p.ldr = ldr; p.alpha = alpha;
+    p.res = res; p.ldr = ldr; p.alpha = alpha; p.lens = lens; p.slack = slack;
     if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     switch (CI) {
@@ -310,4 +321,12 @@ extern "C" int dsp_conv1d_split_residual(const float* x, long ldx, const void* w
                                          int relu, dsp_stream_t stream)
 {
     return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, CI, nslices, M, ntaps, relu, 0, res, ldr, alpha, stream);
+}
+
+extern "C" int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res,
+                                       long ldr, float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps,
+                                       int relu, const int* lens, int slack, dsp_stream_t stream)
+{
+    if (lens && slack < 0) { set_error("conv1d_split_ragged: negative slack"); return DSP_EINVAL; }
+    return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, CI, nslices, M, ntaps, relu, 0, res, ldr, alpha, stream, lens, slack);
 }

@@ -21,6 +21,15 @@ def _gpu(name, *ts):
             raise RuntimeError(f"{name}: expected GPU tensors (HIP op, no CPU path)")
 
 
+def _mask_bytes(m: Optional[Tensor]) -> Optional[Tensor]:
+    """a [B,T] padding mask as bytes for the C ABI: contiguous bool tensors are reinterpreted (no launch), anything else is converted"""
+    if m is None:
+        return None
+    if m.dtype == torch.bool and m.is_contiguous():
+        return m.view(torch.uint8)
+    return m.to(torch.uint8).contiguous()
+
+
 def _code(t: Tensor) -> int:
     c = _lib.DTYPE_CODES.get(str(t.dtype))
     if c is None:
@@ -457,8 +466,10 @@ class SplitConv1d:
 
     ACT = {None: 0, "relu": 1, "silu": 2, "gelu": 3}
 
-    def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
-        """act(conv(x) + bias), or residual + alpha * that when a residual [B,T,Cout] is given."""
+    def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0,
+                 lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
+        """act(conv(x) + bias), or residual + alpha * that when a residual [B,T,Cout] is given.  lens [B] int32 (ragged batch): time tiles
+        starting at or after lens[b] + slack are padding and come back as zeros without being computed (dsp_conv1d_split_ragged)."""
         _gpu("SplitConv1d", x)
         code = 1 if relu else self.ACT[act]
         assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == self.Cin and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
@@ -467,7 +478,16 @@ class SplitConv1d:
         with torch.cuda.device(x.device):
             st = _lib.current_stream_handle()
             out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
-            if residual is not None or alpha != 1.0:
+            if lens is not None:
+                r = None
+                if residual is not None:
+                    r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
+                    assert tuple(r.shape) == (B, T, self.Cout)
+                assert lens.dtype == torch.int32 and lens.is_cuda and lens.is_contiguous() and lens.numel() == B
+                _lib.check(lib.dsp_conv1d_split_ragged(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(r),
+                                                       self.Cout, float(alpha), _lib.ptr(out), self.Cout, B, T, self.step, self.nslices, self.Cout,
+                                                       self.K, code, _lib.ptr(lens), int(slack), st), "dsp_conv1d_split_ragged")
+            elif residual is not None or alpha != 1.0:
                 r = None
                 if residual is not None:
                     r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
@@ -491,7 +511,16 @@ def set_split_gemm(on: bool) -> bool:
     return old
 
 
-def split_linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Optional[Tensor]:
+def valid_lengths(pad_mask: Optional[Tensor]) -> Optional[Tensor]:
+    """[B] int32: one past the last position that is not padding (a ragged batch's row bounds for the `lens` arguments below)"""
+    if pad_mask is None or not pad_mask.is_cuda:
+        return None
+    T = pad_mask.shape[1]
+    return ((~pad_mask) * torch.arange(1, T + 1, device=pad_mask.device, dtype=torch.int32)).amax(1).to(torch.int32).contiguous()
+
+
+def split_linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0,
+                 lens: Optional[Tensor] = None, slack: int = 0) -> Optional[Tensor]:
     """act(x @ W^T + b) at fp32 accuracy on the fp16 matrix cores (a SplitConv1d with one tap), or None when the shape / mode is not
     served (caller falls back to F.linear): eval-mode inference in fp32 on the GPU, in_features 128 / 256 / 512 or a multiple of 512,
     out_features % 4 == 0, at least 128 rows.  The packed weight is cached on the module."""
@@ -510,14 +539,16 @@ def split_linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[T
     if cache is None or cache[0] != key:
         cache = (key, SplitConv1d(wt if wt.dim() == 3 else wt.unsqueeze(-1), bias))
         lin._dsp_split = cache
-    return cache[1](x, act=act, residual=residual, alpha=alpha)
+    return cache[1](x, act=act, residual=residual, alpha=alpha, lens=lens, slack=slack)
 
 
-def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+def linear(x: Tensor, lin, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0, lens: Optional[Tensor] = None,
+           slack: int = 0) -> Tensor:
     """[residual + alpha *] act(lin(x)): through split_linear where it applies (eval-mode fp32 inference on the GPU), torch otherwise.
-    `lin` is an nn.Linear or a kernel-1 nn.Conv1d (applied on the channels-last x)."""
+    `lin` is an nn.Linear or a kernel-1 nn.Conv1d (applied on the channels-last x).  lens [B] int32: rows from lens[b] + slack on are padding
+    that may come back as zeros (whole tiles are skipped on the split path; the torch path computes them)."""
     if not lin.training:
-        y = split_linear(x, lin, act, residual, alpha)
+        y = split_linear(x, lin, act, residual, alpha, lens, slack)
         if y is not None:
             return y
     y = torch.nn.functional.linear(x, lin.weight if lin.weight.dim() == 2 else lin.weight.squeeze(-1), getattr(lin, "bias", None))
@@ -538,7 +569,7 @@ class _CatLinear:
         self.training = False
 
 
-def linear_fused(x: Tensor, lins) -> tuple:
+def linear_fused(x: Tensor, lins, lens: Optional[Tensor] = None, slack: int = 0) -> tuple:
     """(lin(x) for lin in lins) for nn.Linear modules sharing the input x: in eval-mode fp32 inference on the GPU ONE split GEMM over the
     stacked weights (cached on the first module) whose output columns are returned as row-strided views — every output column sees the
     same reduction as in its own GEMM, so the values are bit-identical to separate calls; separate `linear` calls otherwise."""
@@ -550,13 +581,13 @@ def linear_fused(x: Tensor, lins) -> tuple:
         if cache is None or cache[0] != key:
             cache = (key, _CatLinear(lins))
             first._dsp_cat = cache
-        y = split_linear(x, cache[1])
+        y = split_linear(x, cache[1], lens=lens, slack=slack)
         if y is not None:
             outs, o = [], 0
             for l in lins:
                 outs.append(y[..., o:o + l.weight.shape[0]]); o += l.weight.shape[0]
             return tuple(outs)
-    return tuple(linear(x, l) for l in lins)
+    return tuple(linear(x, l, lens=lens, slack=slack) for l in lins)
 
 
 def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
@@ -586,7 +617,7 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
     if pp.shape[0] != 2 * T - 1:
         return None
     lib = _lib.load()
-    pm = None if pad_mask is None else pad_mask.to(torch.uint8).contiguous()
+    pm = _mask_bytes(pad_mask)
     bu, bv = bias_u.detach().float().contiguous(), bias_v.detach().float().contiguous()      # named: must outlive the launch
     with torch.cuda.device(q.device):
         out = torch.empty((B, T, C), dtype=torch.float32, device=q.device)
@@ -595,11 +626,13 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
     return out
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, key_pad_mask: Optional[Tensor], heads: int) -> Optional[Tensor]:
+def attention(q: Tensor, k: Tensor, v: Tensor, key_pad_mask: Optional[Tensor], heads: int, q_lens: Optional[Tensor] = None,
+              q_slack: int = 0) -> Optional[Tensor]:
     """softmax(q k^T / sqrt(dk) + key padding) v per head at fp32 accuracy on the fp16 matrix cores (dsp_attention_split): q [B,N,C],
     k / v [B,M,C] fp32, possibly column slices of a wider projection output (row-strided views; unit stride inside a row), C = heads * dk
     with dk 64 or 128, key_pad_mask [B,M] bool or None.  Returns [B,N,C] contiguous, or None when the shape / mode is not served
-    (training, autocast, other head widths: the caller keeps torch's scaled_dot_product_attention)."""
+    (training, autocast, other head widths: the caller keeps torch's scaled_dot_product_attention).  q_lens [B] int32: queries from
+    q_lens[b] + q_slack on are padding; their 32-query groups are skipped and come back as zeros."""
     B, N, C = q.shape
     M = k.shape[1]
     dk = C // heads
@@ -608,9 +641,10 @@ def attention(q: Tensor, k: Tensor, v: Tensor, key_pad_mask: Optional[Tensor], h
                    for t in (q, k, v)) or k.shape != v.shape or k.shape[0] != B or k.shape[2] != C or N < 1 or M < 1):
         return None
     lib = _lib.load()
-    pm = None if key_pad_mask is None else key_pad_mask.to(torch.uint8).contiguous()
+    pm = _mask_bytes(key_pad_mask)
     with torch.cuda.device(q.device):
         out = torch.empty((B, N, C), dtype=torch.float32, device=q.device)
         _lib.check(lib.dsp_attention_split(_lib.ptr(q), q.stride(1), _lib.ptr(k), k.stride(1), _lib.ptr(v), v.stride(1), _lib.ptr(pm), _lib.ptr(out),
-                                           B, N, M, heads, dk, float(dk) ** -0.5, _lib.current_stream_handle()), "dsp_attention_split")
+                                           B, N, M, heads, dk, float(dk) ** -0.5, _lib.ptr(q_lens), int(q_slack), _lib.current_stream_handle()),
+                   "dsp_attention_split")
     return out

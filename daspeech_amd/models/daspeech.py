@@ -240,20 +240,22 @@ class _MHA(nn.Module):
         self.q_proj, self.out_proj = nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.k_proj, self.v_proj = nn.Linear(kdim, dim), nn.Linear(kdim, dim)
 
-    def forward(self, x, mem, mem_pad, residual=None):
+    def forward(self, x, mem, mem_pad, residual=None, lens=None, mem_lens=None):
+        """lens / mem_lens [B] int32 (eval-mode GPU inference, optional): rows of x / mem from there on are padding nothing valid depends
+        on — a Transformer layer has no path from a padded position to a valid one — and the matrix-core kernels skip their tiles."""
         B, N, C = x.shape
         M = mem.shape[1]
         L_ = decode_ops.linear
         if not self.training:
             # eval: stacked projections (q|k|v of self-attention, k|v of the encoder attention) and the fp32-accurate matrix-core attention
             if mem is x:
-                qf, kf, vf = decode_ops.linear_fused(x, (self.q_proj, self.k_proj, self.v_proj))
+                qf, kf, vf = decode_ops.linear_fused(x, (self.q_proj, self.k_proj, self.v_proj), lens=lens)
             else:
-                qf = L_(x, self.q_proj)
-                kf, vf = decode_ops.linear_fused(mem, (self.k_proj, self.v_proj))
-            o = decode_ops.attention(qf, kf, vf, mem_pad, self.h)
+                qf = L_(x, self.q_proj, lens=lens)
+                kf, vf = decode_ops.linear_fused(mem, (self.k_proj, self.v_proj), lens=mem_lens)
+            o = decode_ops.attention(qf, kf, vf, mem_pad, self.h, q_lens=lens)
             if o is not None:
-                return L_(o, self.out_proj, residual=residual)
+                return L_(o, self.out_proj, residual=residual, lens=lens)
             q, k, v = (t.reshape(B, -1, self.h, C // self.h).transpose(1, 2) for t in (qf, kf, vf))
         else:
             q = L_(x, self.q_proj).view(B, N, self.h, -1).transpose(1, 2)
@@ -276,15 +278,16 @@ class NATDecoderLayer(nn.Module):
         self.encoder_attn, self.encoder_attn_layer_norm = _MHA(dim, heads, enc_dim, dropout=attention_dropout), nn.LayerNorm(dim)
         self.fc1, self.fc2, self.final_layer_norm = nn.Linear(dim, ffn), nn.Linear(ffn, dim), nn.LayerNorm(dim)
 
-    def forward(self, x, self_pad, enc, enc_pad):
+    def forward(self, x, self_pad, enc, enc_pad, lens=None, enc_lens=None):
         if self.training or torch.is_grad_enabled():
             p, tr = self.p, self.training                                                 # transformer_layer.py:467,497,507,511
             x = self.self_attn_layer_norm(x + _drop(self.self_attn(x, x, self_pad), p, tr))
             x = self.encoder_attn_layer_norm(x + _drop(self.encoder_attn(x, enc, enc_pad), p, tr))
             return self.final_layer_norm(x + _drop(self.fc2(_drop(F.gelu(self.fc1(x)), self.p_act, tr)), p, tr))
-        x = decode_ops.layer_norm(self.self_attn(x, x, self_pad, residual=x), self.self_attn_layer_norm)
-        x = decode_ops.layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x), self.encoder_attn_layer_norm)
-        return decode_ops.layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu"), self.fc2, residual=x), self.final_layer_norm)
+        x = decode_ops.layer_norm(self.self_attn(x, x, self_pad, residual=x, lens=lens, mem_lens=lens), self.self_attn_layer_norm)
+        x = decode_ops.layer_norm(self.encoder_attn(x, enc, enc_pad, residual=x, lens=lens, mem_lens=enc_lens), self.encoder_attn_layer_norm)
+        return decode_ops.layer_norm(decode_ops.linear(decode_ops.linear(x, self.fc1, act="gelu", lens=lens), self.fc2, residual=x, lens=lens),
+                                     self.final_layer_norm)
 
 
 class DAGDecoder(nn.Module):
@@ -301,6 +304,7 @@ class DAGDecoder(nn.Module):
         self.link_positional = nn.Embedding(a.max_target_positions + PAD + 1, d, padding_idx=PAD)
         self.query_linear, self.key_linear = nn.Linear(2 * d, d), nn.Linear(2 * d, d)
         self.gate_linear = nn.Linear(2 * d, a.decoder_attention_heads)
+        self.ragged = True                      # eval-mode GPU inference: skip the tiles of padded graph positions (they reach no valid one)
         self.fused_links = True                 # fused compact-band HIP kernels, forward and backward (False: the torch formulation)
 
     @staticmethod
@@ -308,26 +312,33 @@ class DAGDecoder(nn.Module):
         keep = tokens.ne(PAD).int()
         return (torch.cumsum(keep, dim=1) * keep).long() + PAD
 
-    def extract_features(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]) -> Tensor:
+    def ragged_lengths(self, prev_output_tokens: Tensor) -> Optional[Tensor]:
+        """[B] int32 valid graph lengths for the tile-skipping kernels of eval-mode GPU inference (None: compute every padded row)"""
+        if self.ragged and not self.training and not torch.is_grad_enabled() and prev_output_tokens.is_cuda:
+            return decode_ops.valid_lengths(prev_output_tokens.eq(PAD))
+        return None
+
+    def extract_features(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor], lens: Optional[Tensor] = None) -> Tensor:
         x = self.embed_scale * self.embed_tokens(prev_output_tokens) + self.embed_positions(self.positions(prev_output_tokens))
         x = _drop(x, self.a.dropout, self.training)                                       # nonautoregressive_transformer.py:349
         pad = prev_output_tokens.eq(PAD)
+        enc_lens = None if lens is None else decode_ops.valid_lengths(enc["encoder_padding_mask"])
         for layer in self.layers:
-            x = layer(x, pad, enc["encoder_out"], enc["encoder_padding_mask"])
+            x = layer(x, pad, enc["encoder_out"], enc["encoder_padding_mask"], lens, enc_lens)
         return x
 
-    def output_layer(self, feats: Tensor) -> Tensor:
-        return decode_ops.linear(feats, self.embed_tokens)        # --share-decoder-input-output-embed (weight [V, d], no bias)
+    def output_layer(self, feats: Tensor, lens: Optional[Tensor] = None) -> Tensor:
+        return decode_ops.linear(feats, self.embed_tokens, lens=lens)        # --share-decoder-input-output-embed (weight [V, d], no bias)
 
-    def extract_links(self, feats: Tensor, prev_output_tokens: Tensor, dist_bias: Optional[Tensor] = None) -> Tensor:
+    def extract_links(self, feats: Tensor, prev_output_tokens: Tensor, dist_bias: Optional[Tensor] = None, lens: Optional[Tensor] = None) -> Tensor:
         """Compact transition log-probs [B, L, TR] fp32 (s2t_conformer_dag.py:171-212, banded branch :191-202).  `dist_bias` [>= TR]
         (optional, not in the reference) is added to the content score of distance d before the window soft-max."""
         a = self.a
         B, L, d = feats.shape
         h, ck = a.decoder_attention_heads, d // a.decoder_attention_heads
         fp = torch.cat([feats, self.link_positional(self.positions(prev_output_tokens))], dim=-1)
-        q = decode_ops.linear(fp, self.query_linear).view(B, L, h, ck).float()
-        k = decode_ops.linear(fp, self.key_linear).view(B, L, h, ck).float()
+        q = decode_ops.linear(fp, self.query_linear, lens=lens).view(B, L, h, ck).float()
+        k = decode_ops.linear(fp, self.key_linear, lens=lens).view(B, L, h, ck).float()
         log_gates = F.log_softmax(decode_ops.linear(fp, self.gate_linear), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
         # the fused kernels keep one tile's scores in LDS: XL_IT = 4 rows x (ck + TR rounded up to 32 + 2) x 8 heads floats <= 150 KB
@@ -433,9 +444,10 @@ class S2TConformerDAGModel(nn.Module):
         return self.encoder(src_tokens, src_lengths)
 
     def decode_graph(self, prev_output_tokens, enc):
-        feats = self.decoder.extract_features(prev_output_tokens, enc)
-        logits = self.decoder.output_layer(feats)
-        return logits, self.decoder.extract_links(feats, prev_output_tokens), feats
+        lens = self.decoder.ragged_lengths(prev_output_tokens)       # eval-mode GPU inference: padded graph positions are not computed
+        feats = self.decoder.extract_features(prev_output_tokens, enc, lens=lens)
+        logits = self.decoder.output_layer(feats, lens)
+        return logits, self.decoder.extract_links(feats, prev_output_tokens, lens=lens), feats
 
     def initialize_output_tokens_by_tokens(self, src_tokens: Tensor, src_lengths: Tensor) -> Tensor:
         """The criteria's entry point (nat_dag_loss.py:191): graph skeleton <bos> <unk>... <eos> of length scale * src_len."""

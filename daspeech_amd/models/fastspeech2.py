@@ -56,16 +56,16 @@ class _SelfAttention(nn.Module):
         self.p_attn = dropout
         self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(dim, dim) for _ in range(4))
 
-    def forward(self, x: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+    def forward(self, x: Tensor, padding_mask: Optional[Tensor], lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
         B, N, C = x.shape
         h = self.heads
         from ..decode_ops import linear as L_                 # fp32-accurate split GEMM in eval-mode fp32 inference, torch otherwise
         if not self.training:
             from ..decode_ops import attention, linear_fused   # eval: one stacked q|k|v projection + the fp32-accurate matrix-core attention
-            qf, kf, vf = linear_fused(x, (self.q_proj, self.k_proj, self.v_proj))
-            o = attention(qf, kf, vf, padding_mask, h)
+            qf, kf, vf = linear_fused(x, (self.q_proj, self.k_proj, self.v_proj), lens=lens, slack=slack)
+            o = attention(qf, kf, vf, padding_mask, h, q_lens=lens, q_slack=slack)
             if o is not None:
-                return L_(o, self.out_proj)
+                return L_(o, self.out_proj, lens=lens, slack=slack)
             q, k, v = (t.reshape(B, N, h, C // h).transpose(1, 2) for t in (qf, kf, vf))
         else:
             q = L_(x, self.q_proj).view(B, N, h, C // h).transpose(1, 2)
@@ -86,7 +86,7 @@ class _ConvFFN(nn.Module):
         self.ffn = nn.Sequential(nn.Conv1d(dim, hidden, kernel, padding=pad), nn.ReLU(), nn.Conv1d(hidden, dim, kernel, padding=pad))
         self.layer_norm = nn.LayerNorm(dim)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
         from .. import decode_ops as _dops
         if (_dops.SPLIT_GEMM and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
                 and not torch.is_autocast_enabled() and self.ffn[0].weight.dtype == torch.float32 and x.is_contiguous()):
@@ -100,7 +100,8 @@ class _ConvFFN(nn.Module):
                 self._split = (SplitConv1d(c1.weight, c1.bias), SplitConv1d(c2.weight, c2.bias)) if ok else None
                 self._split_key = key
             if self._split is not None:
-                return _dops.layer_norm(self._split[1](self._split[0](x, relu=True), residual=x), self.layer_norm)
+                return _dops.layer_norm(self._split[1](self._split[0](x, relu=True, lens=lens, slack=slack), residual=x, lens=lens, slack=slack),
+                                        self.layer_norm)
         return self.layer_norm(_drop(self.ffn(x.transpose(1, 2)).transpose(1, 2), self.p, self.training) + x)
 
 
@@ -111,10 +112,12 @@ class FFTLayer(nn.Module):
         self.layer_norm = nn.LayerNorm(dim)
         self.ffn = _ConvFFN(dim, hidden, kernel, dropout)
 
-    def forward(self, x: Tensor, padding_mask: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, padding_mask: Optional[Tensor] = None, lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
+        """lens [B] int32 + slack (eval-mode inference on the GPU only): rows from lens[b] + slack on are padding that no valid frame of
+        the model's output depends on; the matrix-core kernels skip their tiles and return zeros there."""
         from ..decode_ops import layer_norm as _ln
-        x = _ln(self.self_attn(x, padding_mask) + x, self.layer_norm)
-        return self.ffn(x)
+        x = _ln(self.self_attn(x, padding_mask, lens, slack) + x, self.layer_norm)
+        return self.ffn(x, lens, slack)
 
 
 class VariancePredictor(nn.Module):
@@ -252,6 +255,7 @@ class FastSpeech2NoEmb(nn.Module):
         super().__init__()
         a = SimpleNamespace(**{**DEFAULT_TTS_ARGS, **kw})
         self.args = a
+        self.ragged = True                          # eval-mode GPU inference skips the tiles of padding frames no valid frame depends on
         self.pos_emb_alpha = nn.Parameter(torch.ones(1))
         self.dec_pos_emb_alpha = nn.Parameter(torch.ones(1))
         self.register_buffer("pos_table", sinusoidal_table(a.max_positions + 2, a.embed_dim), persistent=False)
@@ -283,8 +287,18 @@ class FastSpeech2NoEmb(nn.Module):
         F_ = x.shape[1]
         dec_mask = torch.arange(F_, device=x.device).unsqueeze(0) >= out_lens.unsqueeze(1)
         x = x + self.dec_pos_emb_alpha * self._pos(dec_mask)
-        for layer in self.decoder_fft_layers:
-            x = layer(x, dec_mask)
+        # Ragged batch: the reference computes every padded frame (fastspeech2.py:86-98 masks attention keys only, the two K=9 convolutions
+        # of an FFT layer read 8 frames past an utterance's end), so a valid frame depends on padding frames up to 8 per remaining layer
+        # (+ the postnet's 5 x 2).  Frames beyond that bound influence nothing valid: their tiles are skipped (zeros).  Valid frames keep
+        # exactly the bits of the dense computation.
+        lens = None
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda and self.ragged:
+            lens = out_lens.to(torch.int32).contiguous()
+        nl = len(self.decoder_fft_layers)
+        reach = (self.args.fft_kernel_size - 1) // 2 * 2                                   # frames one layer's two convolutions reach
+        post = 0 if self.postnet is None else sum((c.kernel_size[0] - 1) // 2 for c in self.postnet.modules() if isinstance(c, nn.Conv1d))
+        for i, layer in enumerate(self.decoder_fft_layers):
+            x = layer(x, dec_mask, lens, reach * (nl - i) + post)
         from ..decode_ops import linear as _lin
         mel = _lin(x.contiguous(), self.out_proj)
         mel_post = mel + self.postnet(mel) if self.postnet is not None else None                             # :171-173

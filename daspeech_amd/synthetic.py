@@ -52,12 +52,13 @@ class NATSpeechToTextTask(NATSpeechToSpeechTask):
 def _synthetic_decode_graph(self, prev_output_tokens, enc):
     """decode_graph of the calibrated benchmark models: every layer of the product path runs (decoder, output GEMM, links head);
     then vertex j is made to prefer token 4 + (j mod cycle) and the transition logits get a distance prior."""
-    feats = self.decoder.extract_features(prev_output_tokens, enc)
-    logits = self.decoder.output_layer(feats)
+    lens = self.decoder.ragged_lengths(prev_output_tokens)          # as S2TConformerDAGModel.decode_graph
+    feats = self.decoder.extract_features(prev_output_tokens, enc, lens=lens)
+    logits = self.decoder.output_layer(feats, lens)
     L, V = logits.shape[1], logits.shape[2]
     tok = 4 + torch.arange(L, device=logits.device) % min(self.synthetic_token_cycle, V - 4)
     logits = 0.0 * logits + 20.0 * torch.nn.functional.one_hot(tok, V).to(logits).unsqueeze(0)     # GEMM still runs; values replaced
-    return logits, self.decoder.extract_links(feats, prev_output_tokens, dist_bias=self.synthetic_link_bias), feats
+    return logits, self.decoder.extract_links(feats, prev_output_tokens, dist_bias=self.synthetic_link_bias, lens=lens), feats
 
 
 @torch.no_grad()

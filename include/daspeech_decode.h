@@ -118,6 +118,15 @@ int dsp_conv1d_split_residual(const float* x, long ldx, const void* w_hi, const 
                               dsp_stream_t stream);
 
 
+/* the same for a ragged batch: lens [B] (device, int32) are the samples' valid lengths; a time tile that starts at or after
+ * lens[b] + slack is padding no valid output depends on (slack = the frames of padding later convolutions still reach into: 0 for
+ * position-wise layers, (K-1)/2 per convolution that follows) — it is not computed and its output rows are written as ZEROS (finite, so
+ * that masked attention keys and later position-wise layers stay finite).  Rows below that bound get exactly the bits of
+ * dsp_conv1d_split_residual.  res may be NULL with alpha = 1 (plain layer); lens may be NULL (dense batch). */
+int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr,
+                            float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
+                            const int* lens, int slack, dsp_stream_t stream);
+
 /* LayerNorm over the last dimension (torch.nn.LayerNorm semantics: biased variance, eps inside the square root), one wave per row:
  * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */
 int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, float* y, long rows, int C, dsp_stream_t stream);
@@ -137,9 +146,11 @@ int dsp_relpos_attention(const float* q, const float* k, const float* v, long ld
  *   out[b,i,h,:] = sum_j softmax_j( scale * q[b,i,h,:] . k[b,j,h,:] ; keys with key_pad_mask[b,j] != 0 -> -inf ) v[b,j,h,:]
  * q [B,N,H,dk], k / v [B,M,H,dk] fp32 as row-strided views (ldq / ldk / ldv floats between consecutive positions, >= H*dk, %4 == 0;
  * samples N*ldq / M*ldk / M*ldv apart: the slices of a fused q|k|v projection are served without a copy), key_pad_mask [B,M] bytes or
- * NULL, out [B,N,H*dk] contiguous.  dk = 64 or 128.  A sample whose keys are all masked gets NaN rows, as torch's soft-max does. */
+ * NULL, out [B,N,H*dk] contiguous.  dk = 64 or 128.  A sample whose keys are all masked gets NaN rows, as torch's soft-max does.
+ * q_lens [B] (device int32) or NULL: queries at or after q_lens[b] + q_slack are padding no valid output depends on; their 32-query
+ * groups are not computed and their output rows are written as zeros (see dsp_conv1d_split_ragged). */
 int dsp_attention_split(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const unsigned char* key_pad_mask,
-                        float* out, int B, int N, int M, int H, int DK, float scale, dsp_stream_t stream);
+                        float* out, int B, int N, int M, int H, int DK, float scale, const int* q_lens, int q_slack, dsp_stream_t stream);
 
 
 #ifdef __cplusplus

@@ -88,7 +88,7 @@ def test_attention_split_rejects_unsupported_head_width():
     from daspeech_amd import _lib
     lib = _lib.load()
     x = torch.zeros(1, 4, 96, device="cuda:0")
-    rc = lib.dsp_attention_split(_lib.ptr(x), 96, _lib.ptr(x), 96, _lib.ptr(x), 96, None, _lib.ptr(x), 1, 4, 4, 1, 96, 0.1, None)
+    rc = lib.dsp_attention_split(_lib.ptr(x), 96, _lib.ptr(x), 96, _lib.ptr(x), 96, None, _lib.ptr(x), 1, 4, 4, 1, 96, 0.1, None, 0, None)
     assert rc != 0 and b"head width" in lib.dsp_last_error()
 
 
@@ -120,3 +120,33 @@ def test_relpos_attention_split_matches_fp64(B, T, H, lens):
     ref = torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1), vd).reshape(B, T, C)
     err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 3e-6, err
+
+
+def test_ragged_arguments_skip_padding_tiles_and_keep_valid_rows_bit_identical():
+    """lens / q_lens (include/daspeech_decode.h: dsp_conv1d_split_ragged, dsp_attention_split): rows below lens[b] + slack carry exactly
+    the bits of the dense call, skipped tiles come back as zeros."""
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, T, C, H = 4, 330, 256, 4
+    lens_l = [330, 201, 64, 7]
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=dev)
+    pad = _lengths_mask(lens_l, T, dev)
+    assert torch.equal(decode_ops.valid_lengths(pad), lens)
+    x = torch.randn(B, T, C, device=dev)
+    lin = torch.nn.Linear(C, 3 * C).to(dev).eval()
+    conv = torch.nn.Conv1d(C, 1024, 9, padding=4).to(dev).eval()
+    sc = decode_ops.SplitConv1d(conv.weight, conv.bias)
+    with torch.no_grad():
+        for slack in (0, 8, 40):
+            dense, rag = decode_ops.linear(x, lin), decode_ops.linear(x, lin, lens=lens, slack=slack)
+            dc, rc = sc(x, relu=True), sc(x, relu=True, lens=lens, slack=slack)
+            q, k, v = dense[..., :C], dense[..., C:2 * C], dense[..., 2 * C:]
+            da, ra = decode_ops.attention(q, k, v, pad, H), decode_ops.attention(q, k, v, pad, H, q_lens=lens, q_slack=slack)
+            for d, r, tile in ((dense, rag, 128), (dc, rc, 128), (da, ra, 32)):
+                for b, n in enumerate(lens_l):
+                    lim = min(T, n + slack)
+                    assert torch.equal(d[b, :lim], r[b, :lim])
+                    first_skipped = (lim + tile - 1) // tile * tile                 # the first tile that starts at or after the bound
+                    assert (r[b, first_skipped:] == 0).all()
+        assert (rag[3, 128:] == 0).all() and (ra[3, 64:] == 0).all()                # something was skipped at all

@@ -14,10 +14,17 @@ dev = torch.device("cuda"); torch.manual_seed(1234)
 model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev).eval()
 gen = S2SNATGenerator(None, torch.zeros(80, device=dev), torch.ones(80, device=dev))
 batches = [make_s2st_batch(32, dev, seed=i) for i in range(2)]
+if os.environ.get("RAGGED", "1") == "0":                       # compute every padded row (the r04k behaviour)
+    model.decoder.ragged = model.tts.ragged = False
 with torch.no_grad():
     for i in range(3): gen._acoustic(model, batches[i % 2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(N): gen._acoustic(model, batches[i % 2])
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+with torch.no_grad():
+    ac = gen._acoustic(model, batches[0])
+    gl = batches[0]["net_input"]["src_lengths"] // 2
+    print(f"graph lengths: mean {gl.float().mean().item():.0f} of max {gl.max().item()}; mel frames: mean {ac['out_lens'].float().mean().item():.0f} of max "
+          f"{ac['out_lens'].max().item()}")
 print(f"acoustic stage, B=32: host issue {(t1 - t0) / N * 1e3:.2f} ms/batch, wall {(t2 - t0) / N * 1e3:.2f} ms/batch ({N} batches + 3 warm-up)")
