@@ -590,6 +590,48 @@ def linear_fused(x: Tensor, lins, lens: Optional[Tensor] = None, slack: int = 0)
     return tuple(linear(x, l, lens=lens, slack=slack) for l in lins)
 
 
+def _packed(lin) -> Optional["SplitConv1d"]:
+    """the SplitConv1d (packed hi / lo weights) split_linear caches on an nn.Linear, built on first use"""
+    wt = lin.weight
+    bias = getattr(lin, "bias", None)
+    key = (wt.data_ptr(), wt._version, None if bias is None else bias._version)
+    cache = getattr(lin, "_dsp_split", None)
+    if cache is None or cache[0] != key:
+        cache = (key, SplitConv1d(wt if wt.dim() == 3 else wt.unsqueeze(-1), bias))
+        lin._dsp_split = cache
+    return cache[1]
+
+
+def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: str, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Optional[Tensor]:
+    """[residual +] alpha * lin2(act(lin1(ln(x)))) in one matrix-core launch at fp32 accuracy (dsp_ffn_split: the hidden activations stay in
+    LDS, LayerNorm runs while the tile is staged), or None when the shape / mode is not served: eval-mode fp32 inference on the GPU,
+    256 channels in and out, hidden width a multiple of 512."""
+    if (not SPLIT_GEMM or torch.is_grad_enabled() or lin1.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or x.dim() != 3
+            or not x.is_contiguous() or lin1.weight.dtype != torch.float32 or lin1.weight.dim() != 2 or lin2.weight.dim() != 2):
+        return None
+    B, T, C = x.shape
+    H = lin1.weight.shape[0]
+    if C != 256 or tuple(lin1.weight.shape) != (H, C) or tuple(lin2.weight.shape) != (C, H) or H % 512 or B * T < 128:
+        return None
+    if ln is not None and (len(ln.normalized_shape) != 1 or ln.weight is None or ln.bias is None or ln.weight.dtype != torch.float32):
+        return None
+    lib = _lib.load()
+    p1, p2 = _packed(lin1), _packed(lin2)
+    r = None
+    if residual is not None:
+        r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
+        assert tuple(r.shape) == (B, T, C)
+    with torch.cuda.device(x.device):
+        nws = lib.dsp_ffn_split_workspace_bytes(B, T, C, H)
+        ws = torch.empty((nws // 4,), dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        _lib.check(lib.dsp_ffn_split(_lib.ptr(x), x.stride(1), _lib.ptr(None if ln is None else ln.weight), _lib.ptr(None if ln is None else ln.bias),
+                                     float(ln.eps) if ln is not None else 0.0, _lib.ptr(p1.hi), _lib.ptr(p1.lo), _lib.ptr(p1.bias), _lib.ptr(p2.hi),
+                                     _lib.ptr(p2.lo), _lib.ptr(p2.bias), _lib.ptr(r), C, float(alpha), _lib.ptr(out), C, _lib.ptr(ws), nws, B, T, C, H,
+                                     SplitConv1d.ACT[act], _lib.current_stream_handle()), "dsp_ffn_split")
+    return out
+
+
 def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
     """ln(x): the one-wave-per-row HIP kernel (dsp_layer_norm) in eval-mode fp32 inference on the GPU, torch otherwise."""
     C = x.shape[-1]

@@ -175,6 +175,9 @@ class ConformerLayer(nn.Module):
     @staticmethod
     def _ffn(m, x):
         """x + 0.5 * w_2(silu(w_1(layer_norm(x))))  — the macaron half-step, residual included."""
+        y = decode_ops.ffn_fused(x, m["layer_norm"], m["w_1"], m["w_2"], "silu", residual=x, alpha=0.5)      # one launch, hidden activations in LDS
+        if y is not None:
+            return y
         L_ = decode_ops.linear                 # fp32-accurate split GEMMs (bias, SiLU, scale and residual in their epilogues) in eval-mode
         return L_(L_(decode_ops.layer_norm(x, m["layer_norm"]), m["w_1"], act="silu"), m["w_2"], residual=x, alpha=0.5)      # fp32 inference, torch otherwise
 

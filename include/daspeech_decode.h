@@ -127,6 +127,17 @@ int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const vo
                             float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
                             const int* lens, int slack, dsp_stream_t stream);
 
+/* The Conformer's feed-forward module in one matrix-core launch (+ a fixed-order reduction of the hidden-channel groups), fp32 accuracy:
+ *   out = res + alpha * (W2 . act(W1 . LN(x) + b1) + b2)          (fairseq conformer_layer.py:140-146 called as x + 0.5 * ffn(x), :254-281)
+ * x [B,T,C] (row stride ldx), ln_w / ln_b [C] or both NULL (no LayerNorm), W1 [H,C] and W2 [C,H] as packed by dsp_conv1d_split_pack
+ * (one tap; W2 in 512-channel input slices as dsp_conv1d_split takes them), b1 [H], b2 [C] or NULL, res [B,T,C] (row stride ldr) or
+ * NULL, out [B,T,C] (row stride ldo; may be res).  act as dsp_conv1d_split's relu argument (0 none, 1 ReLU, 2 SiLU, 3 GELU).
+ * C = 256, H a multiple of 512.  workspace: dsp_ffn_split_workspace_bytes(B, T, C, H) bytes of device memory (partial sums). */
+size_t dsp_ffn_split_workspace_bytes(int B, int T, int C, int H);
+int dsp_ffn_split(const float* x, long ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* w1_hi, const void* w1_lo, const float* b1,
+                  const void* w2_hi, const void* w2_lo, const float* b2, const float* res, long ldr, float alpha, float* out, long ldo,
+                  void* workspace, size_t workspace_bytes, int B, int T, int C, int H, int act, dsp_stream_t stream);
+
 /* LayerNorm over the last dimension (torch.nn.LayerNorm semantics: biased variance, eps inside the square root), one wave per row:
  * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */
 int dsp_layer_norm(const float* x, const float* w, const float* b, float eps, float* y, long rows, int C, dsp_stream_t stream);
