@@ -13,6 +13,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/daspeech_hifigan.h"
 
 namespace dsp {
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
     const int co_base = wm * (MI * 16);
     const int nsteps = p.ntaps * NC;
     const size_t wn_elems = (size_t)nsteps * (C / 16) * 512;       // halves in the hi (and in the lo) part of a packed weight buffer
-    auto conv = [&](const _Float16* W, const char* thi, const char* tlo, int row0, int rstep) {
+    // NJ: 16-column tiles this wave computes (c2 needs NT of the NTI columns: with one wave column the last tile is skipped — a quarter
+    // of c2's MFMAs at C = 256, an eighth at C = 128)
+    auto conv = [&](auto njc, const _Float16* W, const char* thi, const char* tlo, int row0, int rstep) {
+        constexpr int NJ = decltype(njc)::value;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
         auto do_step = [&](int step, const h8 (&ah)[MI], const h8 (&al)[MI]) {
             const int k = step / NC, c = step - k * NC;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int row = (wn * NI + j) * 16 + lr + row0 + k * rstep;
                 const size_t o = ((size_t)row * CH + hgs_swz<C>(row, c * 4 + lk)) * 16;
                 const h8 bh = *reinterpret_cast<const h8*>(thi + o);
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
     };
 
     // ---- c1 over the NTI intermediate columns -> mid = split(lrelu(acc + b1)), zero outside [0, Tb) ----
-    conv(p.w1, xhi, xlo, 0, p.dil);
+    conv(std::integral_constant<int, NI>{}, p.w1, xhi, xlo, 0, p.dil);
     __syncthreads();                                  // every wave is done reading the x tile: its space becomes the intermediate
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
     __syncthreads();                                  // intermediate complete
 
     // ---- c2 over the NT output columns ----
-    conv(p.w2, mhi, mlo, 8 - h2, 1);
+    conv(std::integral_constant<int, (WN == 1 ? NT / 16 : NI)>{}, p.w2, mhi, mlo, 8 - h2, 1);
     __syncthreads();                                  // every wave is done reading the intermediate: its space becomes the output tile
     float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -542,7 +546,8 @@ extern "C" int dsp_hifigan_conv_chain_f32(const dsp_hg_layer* layers, int n_laye
             int rc;
             // (tile sweep of r03, ms per 32 x 329-frame call and stage — C=256: NT 32 / 48 / 64 = 5.30 / 4.69 / 5.04; C=128 as 8x1 waves: NT 64 / 80 / 96 /
             //  112 = 9.34 / 8.82 / 8.93 / 8.71, as 4x2 waves at 132 VGPRs and one workgroup per CU 9.8; C=64: <240,2,4> 4.40, <240,4,2> 4.63,
-            //  <176,4,2> 4.87, <112,4,2> 5.38; C=32: <496,1,8> 2.88, <496,2,4> 3.02, <240,2,4> 3.04, <240,1,8> 3.43)
+            //  <176,4,2> 4.87, <112,4,2> 5.38; C=32: <496,1,8> 2.88, <496,2,4> 3.02, <240,2,4> 3.04, <240,1,8> 3.43;
+            //  r04: C=128 as 4x2 waves under the 128-VGPR bound, two workgroups per CU: 24.9 vs 21.2 ms per call — profiles/r04_vocoder_ablation.txt)
             switch (l.CI) {
                 case 256: rc = hgs_unit_launch<256, 48, 8, 1>(u, as_stream(stream)); break;      // (32-column tiles for the wide-halo units, to fit two per CU: slower, 21.9 vs 21.2 ms per call)
                 case 128: {

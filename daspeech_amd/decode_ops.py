@@ -452,7 +452,7 @@ class SplitConv1d:
         Cout, Cin, K = weight.shape
         self.Cout, self.Cin, self.K = Cout, Cin, K
         self.bias = None if bias is None else bias.detach().float().contiguous()
-        step = Cin if Cin <= 512 else 512          # (256-channel slices with 128-row tiles were slower: 125 vs 95 us for 2048 -> 256)
+        step = Cin if Cin <= 512 else 512          # (256-channel slices with 128-row tiles: 125 vs 95 us for 2048 -> 256; r04 for the 512-wide decoder GEMMs: 3 - 10 % faster, not taken)
         assert Cin % step == 0 and step in (128, 256, 512) and Cout % 4 == 0 and K % 2 == 1, (Cin, Cout, K)
         self.step, self.nslices = step, Cin // step
         with torch.cuda.device(weight.device):
