@@ -106,8 +106,22 @@ class Conv1dSubsampler(nn.Module):
         return x.transpose(1, 2), self.out_lengths(lens)
 
 
+_POS_TABLES: Dict[tuple, Tensor] = {}           # (T, dim, device, dtype) -> table; the table is a constant of its key (read-only)
+
+
 def rel_positional_encoding(T: int, dim: int, device, dtype) -> Tensor:
     """[1, 2T-1, dim] sinusoid over relative positions T-1 .. -(T-1) (modules/positional_encoding.py RelPositionalEncoding)."""
+    key = (T, dim, str(device), dtype)
+    hit = _POS_TABLES.get(key)
+    if hit is not None:
+        return hit
+    if len(_POS_TABLES) >= 64:
+        _POS_TABLES.clear()
+    _POS_TABLES[key] = table = _rel_positional_encoding(T, dim, device, dtype)
+    return table
+
+
+def _rel_positional_encoding(T: int, dim: int, device, dtype) -> Tensor:
     pos = torch.arange(T - 1, -T, -1.0, device=device).unsqueeze(1)
     div = torch.exp(torch.arange(0, dim, 2, device=device).float() * -(math.log(10000.0) / dim))
     pe = torch.zeros(2 * T - 1, dim, device=device)
@@ -133,12 +147,27 @@ class RelPosSelfAttention(nn.Module):
         x = F.pad(x, (1, 0)).view(B, h, P + 1, T)[:, :, 1:].reshape(B, h, T, P)
         return x[..., : P // 2 + 1]
 
+    def _projected_positions(self, pos: Tensor) -> Tensor:
+        """linear_pos(pos) in eval-mode inference: a constant of (the position table, the weight) — kept per table instead of being
+        recomputed by every batch (12 small GEMMs per encoder pass)."""
+        w = self.linear_pos.weight
+        if torch.is_grad_enabled() or self.training:
+            return decode_ops.linear(pos, self.linear_pos)
+        key = (pos.data_ptr(), tuple(pos.shape), w.data_ptr(), w._version)
+        cache = self.__dict__.setdefault("_pos_proj", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 64:
+                cache.clear()
+            cache[key] = hit = (decode_ops.linear(pos, self.linear_pos), pos)         # the table is kept alive with its projection
+        return hit[0]
+
     def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor], residual: Optional[Tensor] = None) -> Tensor:
         B, T, C = x.shape
         L_ = decode_ops.linear
         if not self.training and self.dk == 64:
             qf, kf, vf = decode_ops.linear_fused(x, (self.linear_q, self.linear_k, self.linear_v))
-            o = decode_ops.relpos_attention(qf, kf, vf, L_(pos, self.linear_pos), self.pos_bias_u, self.pos_bias_v, pad_mask, self.h)
+            o = decode_ops.relpos_attention(qf, kf, vf, self._projected_positions(pos), self.pos_bias_u, self.pos_bias_v, pad_mask, self.h)
             if o is not None:                                         # one fused HIP kernel for scores, shift, soft-max and the value product
                 return L_(o, self.linear_out, residual=residual)
             qf, kf, vf = qf.contiguous(), kf.contiguous(), vf.contiguous()

@@ -65,3 +65,13 @@ cd $GRAFT_REPO_ROOT
 { python bench.py --workload train --steps 10 --warmup 4 2>/dev/null | tail -1; python bench.py --workload s2tt --steps 10 --warmup 4 2>/dev/null | tail -1; } > $OUT/bench_train_s2tt.txt
 bash tools/train_step_prof.sh 10 > $OUT/train_step_kernels.txt 2>&1
 bash tools/acoustic_stage_prof.sh > $OUT/acoustic_stage_kernels.txt 2>&1
+ROWS=40 NAMEW=110 bash tools/acoustic_stage_prof.sh > $OUT/acoustic_stage_kernels.txt 2>&1
+ROWS=40 bash tools/acoustic_trace.sh > $OUT/acoustic_stage_by_grid.txt 2>&1
+bash tools/attention_prof.sh > $OUT/attention_kernels.txt 2>&1
+cd /tmp
+ACCMD="python $GRAFT_REPO_ROOT/tools/acoustic_stage_prof.py 5"
+{
+echo "# rocprofv3 --pmc over: $ACCMD  (matrix-core kernels of the acoustic stage; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES))"
+pmc "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "conv1d_split_kernel|ffn_split|attention_split" $ACCMD
+pmc "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "conv1d_split_kernel|ffn_split|attention_split" $ACCMD
+} > $OUT/pmc_acoustic.txt 2>&1
