@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_links.py", ["40", "2"]),                  # fused extract_links vs the numpy oracle
     ("fuzz_layers.py", ["30", "6"]),                 # split-precision conv / GEMM tiles, layer norm, depthwise conv + BN + SiLU
     ("fuzz_tts_glue.py", ["40", "4"]),               # length regulator, durations, bucketize + embed, posterior / expected features
+    ("fuzz_attention.py", ["30", "1"]),              # matrix-core attention / relative-position attention / feed-forward module / ragged tiles
 ])
 def test_randomised_sweep(tool, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
