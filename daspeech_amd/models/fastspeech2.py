@@ -56,7 +56,9 @@ class _SelfAttention(nn.Module):
         self.p_attn = dropout
         self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(dim, dim) for _ in range(4))
 
-    def forward(self, x: Tensor, padding_mask: Optional[Tensor], lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
+    def forward(self, x: Tensor, padding_mask: Optional[Tensor], lens: Optional[Tensor] = None, slack: int = 0,
+                residual: Optional[Tensor] = None) -> Tensor:
+        """[residual +] out_proj(attention(x)) — the residual rides in the projection's epilogue on the split-GEMM path"""
         B, N, C = x.shape
         h = self.heads
         from ..decode_ops import linear as L_                 # fp32-accurate split GEMM in eval-mode fp32 inference, torch otherwise
@@ -65,7 +67,7 @@ class _SelfAttention(nn.Module):
             qf, kf, vf = linear_fused(x, (self.q_proj, self.k_proj, self.v_proj), lens=lens, slack=slack)
             o = attention(qf, kf, vf, padding_mask, h, q_lens=lens, q_slack=slack)
             if o is not None:
-                return L_(o, self.out_proj, lens=lens, slack=slack)
+                return L_(o, self.out_proj, residual=residual, lens=lens, slack=slack)
             q, k, v = (t.reshape(B, N, h, C // h).transpose(1, 2) for t in (qf, kf, vf))
         else:
             q = L_(x, self.q_proj).view(B, N, h, C // h).transpose(1, 2)
@@ -75,7 +77,7 @@ class _SelfAttention(nn.Module):
         if padding_mask is not None:
             mask = torch.zeros(B, 1, 1, N, dtype=x.dtype, device=x.device).masked_fill(padding_mask.view(B, 1, 1, N), float("-inf"))
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.p_attn if self.training else 0.0)
-        return L_(o.transpose(1, 2).reshape(B, N, C), self.out_proj)
+        return L_(o.transpose(1, 2).reshape(B, N, C), self.out_proj, residual=residual)
 
 
 class _ConvFFN(nn.Module):
@@ -116,7 +118,7 @@ class FFTLayer(nn.Module):
         """lens [B] int32 + slack (eval-mode inference on the GPU only): rows from lens[b] + slack on are padding that no valid frame of
         the model's output depends on; the matrix-core kernels skip their tiles and return zeros there."""
         from ..decode_ops import layer_norm as _ln
-        x = _ln(self.self_attn(x, padding_mask, lens, slack) + x, self.layer_norm)
+        x = _ln(self.self_attn(x, padding_mask, lens, slack, residual=x), self.layer_norm)
         return self.ffn(x, lens, slack)
 
 
