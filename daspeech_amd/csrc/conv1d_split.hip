@@ -24,6 +24,7 @@ struct CsParams {
     int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
     int nslices; long wslice;      // the input is nslices x CI channels wide; slice s uses weights + s * wslice (halves)
     const float* res; long ldr; float alpha;      // out = res + alpha * act(bias + conv)   (res may be NULL: out = alpha * act(...))
+    int kparts, tap_groups; float* part;          // split-K: kparts = nslices * tap_groups workgroups per output tile, raw partial sums to part [kparts][B][T][M]
     const int* lens; int slack;                   // ragged batch: rows >= lens[b] + slack of sample b are padding nobody reads — their
 };                                                // tiles are not computed, the output rows are written as zeros
 
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int lr = lane & 15, lk = lane >> 4;
-    const int b = blockIdx.z, t0 = blockIdx.x * NT, m0 = blockIdx.y * MT;
+    const int kp = p.kparts > 1 ? (int)(blockIdx.y % p.kparts) : 0;
+    const int b = blockIdx.z, t0 = blockIdx.x * NT, m0 = (p.kparts > 1 ? (int)(blockIdx.y / p.kparts) : (int)blockIdx.y) * MT;
     if (p.lens && t0 >= p.lens[b] + p.slack) {          // a tile of padding rows (block-uniform): zeros, so that they stay finite
         if (p.accumulate) return;
         const int cw = min(MT, p.M - m0) >> 2;          // float4 columns of this tile
@@ -79,13 +81,21 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     const int co_base = m0 + wm * (MI * 16);
     const int tl_base = wn * (NI * 16);
     const int Mt = (p.M + 15) >> 4;
-    const int nsteps = p.ntaps * NC;
+    // split-K: this workgroup owns ONE input slice and one group of taps (short sequences: a 1024 -> 256, K = 9 layer on 61 positions
+    // is 64 workgroups of 288 K-steps otherwise); the partial sums meet in cs_reduce_kernel
+    int sl_lo = 0, sl_hi = p.nslices, k_lo = 0, k_hi = p.ntaps;
+    if (p.kparts > 1) {
+        const int tpg = (p.ntaps + p.tap_groups - 1) / p.tap_groups;
+        sl_lo = kp / p.tap_groups; sl_hi = sl_lo + 1;
+        k_lo = (kp % p.tap_groups) * tpg; k_hi = min(p.ntaps, k_lo + tpg);
+    }
+    const int sb = k_lo * NC, nsteps = (k_hi - k_lo) * NC;
     // input slices of CI channels one after the other through the same LDS tiles; the accumulators stay in registers
-    for (int sl = 0; sl < p.nslices; ++sl) {
+    for (int sl = sl_lo; sl < sl_hi; ++sl) {
     const float* Xs = X + (size_t)sl * CI;
     const _Float16* WH = p.wh + (size_t)sl * p.wslice;
     const _Float16* WL = p.wl + (size_t)sl * p.wslice;
-    if (sl) __syncthreads();                              // every wave is done with the previous slice's tiles
+    if (sl > sl_lo) __syncthreads();                      // every wave is done with the previous slice's tiles
     // ---- stage: rows t0-P .. t0+NT-1+P, zero outside [0,T); split into hi / lo*2^11.  All of a lane's row chunks (R*CH/512 <= 10) are
     //      requested together, UNCONDITIONALLY from a clamped row: predicated loads wait for one another (r01h s_memtime accounting: 10 k
     //      cycles of staging per slice, eight dependent round trips, against 17 k cycles of MFMA loop) ----
@@ -154,23 +164,39 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     };
     // 3-deep register ring of weight fragments: a request is two steps (>= 48 MFMAs per wave) ahead of its use
     cs_h8 ah0[MI], al0[MI], ah1[MI], al1[MI], ah2[MI], al2[MI];
-    load_a(0, ah0, al0);
-    if (nsteps > 1) load_a(1, ah1, al1);
+    if (nsteps > 0) load_a(sb, ah0, al0);
+    if (nsteps > 1) load_a(sb + 1, ah1, al1);
     for (int step = 0; step < nsteps; step += 3) {
-        if (step + 2 < nsteps) load_a(step + 2, ah2, al2);
-        do_step(step, ah0, al0);
+        if (step + 2 < nsteps) load_a(sb + step + 2, ah2, al2);
+        do_step(sb + step, ah0, al0);
         if (step + 1 < nsteps) {
-            if (step + 3 < nsteps) load_a(step + 3, ah0, al0);
-            do_step(step + 1, ah1, al1);
+            if (step + 3 < nsteps) load_a(sb + step + 3, ah0, al0);
+            do_step(sb + step + 1, ah1, al1);
         }
         if (step + 2 < nsteps) {
-            if (step + 4 < nsteps) load_a(step + 4, ah1, al1);
-            do_step(step + 2, ah2, al2);
+            if (step + 4 < nsteps) load_a(sb + step + 4, ah1, al1);
+            do_step(sb + step + 2, ah2, al2);
         }
     }
 
     }
 
+    if (p.kparts > 1) {                                   // raw partial sums; bias, activation, residual: cs_reduce_kernel
+        float* P = p.part + ((size_t)kp * p.B + b) * p.T * p.M;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int co = co_base + i * 16 + lk * 4;
+            if (co >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int t = t0 + tl_base + j * 16 + lr;
+                if (t >= p.T) continue;
+                *reinterpret_cast<float4*>(P + (size_t)t * p.M + co) = make_float4(acc0[i][j][0] + acc1[i][j][0] * (1.f / 2048.f), acc0[i][j][1] + acc1[i][j][1] * (1.f / 2048.f),
+                                                                                 acc0[i][j][2] + acc1[i][j][2] * (1.f / 2048.f), acc0[i][j][3] + acc1[i][j][3] * (1.f / 2048.f));
+            }
+        }
+        return;
+    }
     // ---- epilogue: D fragment = 4 consecutive output channels of one frame per lane -> one 16-byte fp32 store ----
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -234,6 +260,32 @@ __global__ void conv1d_split_pack_kernel(const float* __restrict__ w, _Float16* 
     }
 }
 
+// out = res + alpha * act(bias + part[0] + part[1] + ...): the K-parts in a fixed order
+__global__ __launch_bounds__(256) void cs_reduce_kernel(const float* __restrict__ part, int KP, long n, const float* __restrict__ bias, int M, int act,
+                                                        const float* __restrict__ res, long ldr, float alpha, float* __restrict__ out, long ldo)
+{
+    const long n4 = n >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long idx = e << 2, row = idx / M; const int c = (int)(idx - row * M);
+        float4 s4 = *reinterpret_cast<const float4*>(part + idx);
+        for (int k = 1; k < KP; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * n + idx);
+            s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w;
+        }
+        float v[4] = {s4.x, s4.y, s4.z, s4.w};
+        if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (act == 1) v[i] = fmaxf(v[i], 0.f);
+            else if (act == 2) v[i] = v[i] / (1.f + __expf(-v[i]));
+            else if (act == 3) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
+        }
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = *reinterpret_cast<const float4*>(res + row * ldr + c);
+        *reinterpret_cast<float4*>(out + row * ldo + c) = make_float4(r.x + alpha * v[0], r.y + alpha * v[1], r.z + alpha * v[2], r.w + alpha * v[3]);
+    }
+}
+
 template <int CI, int MT, int NT, int WM, int WN>
 static int cs_launch(const CsParams& p, hipStream_t st)
 {
@@ -241,7 +293,7 @@ static int cs_launch(const CsParams& p, hipStream_t st)
     if (lds > 160 * 1024) { set_error("conv1d_split: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = conv1d_split_kernel<CI, MT, NT, WM, WN>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, (p.M + MT - 1) / MT, p.B), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, ((p.M + MT - 1) / MT) * (p.kparts > 1 ? p.kparts : 1), p.B), dim3(512), lds, st, p);
     return check_launch("conv1d_split");
 }
 
@@ -266,7 +318,7 @@ extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void*
 
 static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
                   int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, const float* res, long ldr, float alpha,
-                  dsp_stream_t stream, const int* lens = nullptr, int slack = 0)
+                  dsp_stream_t stream, const int* lens = nullptr, int slack = 0, int tap_groups = 0, float* part = nullptr)
 {
     if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || nslices < 1 || ldx < (long)CI * nslices || ldo < M ||
         (ldx & 3) || (ldo & 3)) {
@@ -279,18 +331,20 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
     p.nslices = nslices; p.wslice = dsp_conv1d_split_packed_elems(ntaps, M, CI);
     p.res = res; p.ldr = ldr; p.alpha = alpha; p.lens = lens; p.slack = slack;
+    p.kparts = tap_groups > 0 ? nslices * tap_groups : 1; p.tap_groups = tap_groups > 0 ? tap_groups : 1; p.part = part;
+    const long kmul = p.kparts;                              // workgroups per output tile
     if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     switch (CI) {
         case 256: {
             // 128-row tiles (8 time sub-tiles per wave, one workgroup per CU) when they fill the chip, 64-row tiles (two per CU) for the
             // narrow layers: 256 -> 256 projections on 12.6 k rows are 99 workgroups at 128 rows
-            const long wgs128 = (long)((T + 127) / 128) * ((M + 255) / 256) * B;
+            const long wgs128 = (long)((T + 127) / 128) * ((M + 255) / 256) * B * kmul;
             if (wgs128 >= 256) return cs_launch<256, 256, 128, 8, 1>(p, st);
             // under-filled launches (the Conformer's 256 -> 256 projections on 4.4 k positions: 69 workgroups of 256 output channels) take
             // 128-channel output tiles: twice the workgroups at 124 VGPRs, two per CU (the 256-channel tile needs 188: one per CU).
             // Acoustic stage 14.60 -> 14.25 ms; applied to every 64-row launch: 14.47 (the input tile is staged twice)
-            const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B;
+            const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B * kmul;
             if (wgs64 < 150) return cs_launch<256, 128, 64, 8, 1>(p, st);
             return cs_launch<256, 256, 64, 8, 1>(p, st);
         }
@@ -300,7 +354,7 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
             // launches that would leave CUs idle with 64-frame tiles (the Conformer's 2048 -> 256 on 4.4 k positions: 69 workgroups)
             // take 32-frame tiles, two workgroups per CU: 52.7 -> 36.7 us; where the 64-frame tiles fill the chip they are 10-20 % faster
             // (at 192 workgroups the 64-frame tiles still win: 34.3 vs 38.9 us for 1024 -> 256 on 10.6 k positions; 128-channel tiles: no gain)
-            const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B;
+            const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B * kmul;
             if (ntaps <= 9 && wgs64 < 128) return cs_launch<512, 256, 32, 8, 1>(p, st);
             return cs_launch<512, 256, 64, 8, 1>(p, st);
         }
@@ -329,4 +383,29 @@ extern "C" int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_h
 {
     if (lens && slack < 0) { set_error("conv1d_split_ragged: negative slack"); return DSP_EINVAL; }
     return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, CI, nslices, M, ntaps, relu, 0, res, ldr, alpha, stream, lens, slack);
+}
+
+extern "C" size_t dsp_conv1d_split_ksplit_workspace_bytes(int B, int T, int M, int nslices, int tap_groups)
+{
+    if (B < 1 || T < 1 || M < 4 || nslices < 1 || tap_groups < 1) return 0;
+    return (size_t)nslices * tap_groups * B * T * M * sizeof(float);
+}
+
+extern "C" int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr,
+                                       float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int act,
+                                       int tap_groups, void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    if (tap_groups < 1 || tap_groups > ntaps || nslices * tap_groups < 2 || nslices * tap_groups > 64) {
+        set_error("conv1d_split_ksplit: tap_groups=%d with %d slices and %d taps", tap_groups, nslices, ntaps); return DSP_EINVAL; }
+    const size_t need = dsp_conv1d_split_ksplit_workspace_bytes(B, T, M, nslices, tap_groups);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) { set_error("conv1d_split_ksplit: workspace of %zu bytes, %zu needed (16-byte aligned)", workspace_bytes, need); return DSP_EINVAL; }
+    if (act < 0 || act > 3 || (M & 3)) { set_error("conv1d_split_ksplit: bad activation / width"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    int rc = cs_run(x, ldx, w_hi, w_lo, nullptr, out, ldo, B, T, CI, nslices, M, ntaps, 0, 0, nullptr, 0, 1.f, stream, nullptr, 0, tap_groups, (float*)workspace);
+    if (rc != DSP_OK) return rc;
+    if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split_ksplit: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
+    const long n = (long)B * T * M;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(cs_reduce_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)workspace, nslices * tap_groups, n, bias, M, act, res, ldr, alpha, out, ldo);
+    return check_launch("conv1d_split_ksplit(reduce)");
 }

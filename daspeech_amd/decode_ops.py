@@ -465,6 +465,21 @@ class SplitConv1d:
                                                      ctypes.c_void_p(self.lo.data_ptr() + 2 * sl * n), K, Cout, step, st), "dsp_conv1d_split_pack")
 
     ACT = {None: 0, "relu": 1, "silu": 2, "gelu": 3}
+    KSPLIT = True              # short sequences: split deep reductions over workgroups (set False to time / compare the single-launch form)
+
+    def _tap_groups(self, B: int, T: int) -> int:
+        """tap groups for the split-K form, 0 = one launch: only when the layer would occupy under half of the 256 CUs with a reduction
+        of >= 4 slice-taps per workgroup (the FastSpeech2 encoder's second FFT convolution: 1024 -> 256, K = 9 over ~60 positions)"""
+        if not SplitConv1d.KSPLIT or self.Cout % 4:
+            return 0
+        wgs = B * ((T + 63) // 64) * ((self.Cout + 255) // 256)
+        if wgs >= 128 or self.nslices * self.K < 4:
+            return 0
+        tg = 1
+        while tg < self.K and wgs * self.nslices * tg < 256 and tg < 3:
+            tg += 1
+        return tg if self.nslices * tg >= 2 else 0
+
 
     def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0,
                  lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
@@ -478,7 +493,19 @@ class SplitConv1d:
         with torch.cuda.device(x.device):
             st = _lib.current_stream_handle()
             out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
-            if lens is not None:
+            tg = self._tap_groups(B, T) if lens is None else 0
+            if tg:
+                # short sequence: split the reduction over slices x tap groups so that the launch fills the chip (dsp_conv1d_split_ksplit)
+                r = None
+                if residual is not None:
+                    r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
+                    assert tuple(r.shape) == (B, T, self.Cout)
+                nws = lib.dsp_conv1d_split_ksplit_workspace_bytes(B, T, self.Cout, self.nslices, tg)
+                ws = torch.empty((nws // 4,), dtype=torch.float32, device=x.device)
+                _lib.check(lib.dsp_conv1d_split_ksplit(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(r), self.Cout,
+                                                       float(alpha), _lib.ptr(out), self.Cout, B, T, self.step, self.nslices, self.Cout, self.K, code, tg,
+                                                       _lib.ptr(ws), nws, st), "dsp_conv1d_split_ksplit")
+            elif lens is not None:
                 r = None
                 if residual is not None:
                     r = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()

@@ -127,6 +127,16 @@ int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const vo
                             float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
                             const int* lens, int slack, dsp_stream_t stream);
 
+/* the same layer for SHORT sequences (few time tiles: the FastSpeech2 encoder's K = 9 convolutions over ~60 phoneme positions leave
+ * three quarters of the CUs idle and run a 288-step reduction per workgroup): the K dimension is split over nslices * tap_groups
+ * workgroups per output tile (one 512-channel input slice and ceil(ntaps / tap_groups) taps each), raw partial sums go to `workspace`
+ * (dsp_conv1d_split_ksplit_workspace_bytes) and a second launch adds them in a fixed order with bias, activation and residual:
+ *   out = res + alpha * act(bias + sum over parts).   Not bit-identical to dsp_conv1d_split (different association of the K sum). */
+size_t dsp_conv1d_split_ksplit_workspace_bytes(int B, int T, int M, int nslices, int tap_groups);
+int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr, float alpha,
+                            float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int act, int tap_groups,
+                            void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
 /* The Conformer's feed-forward module in one matrix-core launch (+ a fixed-order reduction of the hidden-channel groups), fp32 accuracy:
  *   out = res + alpha * (W2 . act(W1 . LN(x) + b1) + b2)          (fairseq conformer_layer.py:140-146 called as x + 0.5 * ffn(x), :254-281)
  * x [B,T,C] (row stride ldx), ln_w / ln_b [C] or both NULL (no LayerNorm), W1 [H,C] and W2 [C,H] as packed by dsp_conv1d_split_pack

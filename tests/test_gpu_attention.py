@@ -122,10 +122,11 @@ def test_relpos_attention_split_matches_fp64(B, T, H, lens):
     assert err < 3e-6, err
 
 
-def test_ragged_arguments_skip_padding_tiles_and_keep_valid_rows_bit_identical():
+def test_ragged_arguments_skip_padding_tiles_and_keep_valid_rows_bit_identical(monkeypatch):
     """lens / q_lens (include/daspeech_decode.h: dsp_conv1d_split_ragged, dsp_attention_split): rows below lens[b] + slack carry exactly
     the bits of the dense call, skipped tiles come back as zeros."""
     from daspeech_amd import decode_ops
+    monkeypatch.setattr(decode_ops.SplitConv1d, "KSPLIT", False)      # the dense call must take the same single-launch form as the ragged one
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
     B, T, C, H = 4, 330, 256, 4
@@ -150,3 +151,24 @@ def test_ragged_arguments_skip_padding_tiles_and_keep_valid_rows_bit_identical()
                     first_skipped = (lim + tile - 1) // tile * tile                 # the first tile that starts at or after the bound
                     assert (r[b, first_skipped:] == 0).all()
         assert (rag[3, 128:] == 0).all() and (ra[3, 64:] == 0).all()                # something was skipped at all
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,K", [(32, 61, 1024, 256, 9), (3, 40, 2048, 512, 1), (8, 17, 512, 256, 9), (2, 130, 1024, 128, 3)])
+def test_split_k_form_of_short_sequence_layers_matches_fp64(B, T, Cin, Cout, K, monkeypatch):
+    """dsp_conv1d_split_ksplit (slices x tap groups over workgroups + fixed-order reduction) against fp64 and the single-launch form."""
+    from daspeech_amd import decode_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(K + T)
+    conv = torch.nn.Conv1d(Cin, Cout, K, padding=(K - 1) // 2).to(dev)
+    sc = decode_ops.SplitConv1d(conv.weight, conv.bias)
+    assert sc._tap_groups(B, T) > 0
+    x, res = torch.randn(B, T, Cin, device=dev), torch.randn(B, T, Cout, device=dev)
+    with torch.no_grad():
+        got = sc(x, act="relu", residual=res, alpha=0.5)
+        monkeypatch.setattr(decode_ops.SplitConv1d, "KSPLIT", False)
+        one = sc(x, act="relu", residual=res, alpha=0.5)
+        ref = res.double() + 0.5 * torch.relu(torch.nn.functional.conv1d(x.double().transpose(1, 2), conv.weight.double(), conv.bias.double(),
+                                                                          padding=(K - 1) // 2).transpose(1, 2))
+    scale = ref.abs().max().item()
+    e_k, e_1 = (got.double() - ref).abs().max().item() / scale, (one.double() - ref).abs().max().item() / scale
+    assert e_k < 3e-6 and e_k < 3 * max(e_1, 3e-7), (e_k, e_1)

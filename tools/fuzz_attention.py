@@ -101,7 +101,9 @@ for case in range(n):
         x = rn(B, T, Cin); lens = torch.randint(0, T + 1, (B,), generator=g).to(torch.int32).to(dev); slack = [0, 4, 32][ri(0, 3)]
         res = rn(B, T, Cout) if ri(0, 2) else None
         with torch.no_grad():
+            SplitConv1d.KSPLIT = False                        # the dense call in the single-launch form, like the ragged one
             dense, rag = sc(x, act="relu", residual=res), sc(x, act="relu", residual=res, lens=lens, slack=slack)
+            SplitConv1d.KSPLIT = True
         for b in range(B):
             lim = min(T, int(lens[b]) + slack)
             assert torch.equal(dense[b, :lim], rag[b, :lim]), "valid rows differ"
