@@ -67,7 +67,7 @@ SIGNATURES = {
                                      _c_p, _c_int, _c_p]),
     "dsp_conv1d_split_ksplit_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dsp_conv1d_split_ksplit": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_int,
-                                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+                                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p, _c_int, _c_p]),
     "dsp_ffn_split_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dsp_ffn_split": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, ctypes.c_float, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float,
                                _c_p, ctypes.c_long, _c_p, _c_sz, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),

@@ -61,9 +61,11 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
         if (p.accumulate) return;
         const int cw = min(MT, p.M - m0) >> 2;          // float4 columns of this tile
         const int rows = min(NT, p.T - t0);
+        float* dst = p.kparts > 1 ? p.part + ((size_t)kp * p.B + b) * p.T * p.M : p.out + (size_t)b * p.T * p.ldo;     // split-K: the partial sums are zero
+        const size_t ld = p.kparts > 1 ? (size_t)p.M : (size_t)p.ldo;
         for (int e = tid; e < rows * cw; e += 512) {
             const int r = e / cw, c4 = e - r * cw;
-            *reinterpret_cast<float4*>(p.out + ((size_t)b * p.T + t0 + r) * p.ldo + m0 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dst + (size_t)(t0 + r) * ld + m0 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
@@ -393,7 +395,7 @@ extern "C" size_t dsp_conv1d_split_ksplit_workspace_bytes(int B, int T, int M, i
 
 extern "C" int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr,
                                        float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int act,
-                                       int tap_groups, void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+                                       int tap_groups, void* workspace, size_t workspace_bytes, const int* lens, int slack, dsp_stream_t stream)
 {
     if (tap_groups < 1 || tap_groups > ntaps || nslices * tap_groups < 2 || nslices * tap_groups > 64) {
         set_error("conv1d_split_ksplit: tap_groups=%d with %d slices and %d taps", tap_groups, nslices, ntaps); return DSP_EINVAL; }
@@ -401,7 +403,8 @@ extern "C" int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_h
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) { set_error("conv1d_split_ksplit: workspace of %zu bytes, %zu needed (16-byte aligned)", workspace_bytes, need); return DSP_EINVAL; }
     if (act < 0 || act > 3 || (M & 3)) { set_error("conv1d_split_ksplit: bad activation / width"); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
-    int rc = cs_run(x, ldx, w_hi, w_lo, nullptr, out, ldo, B, T, CI, nslices, M, ntaps, 0, 0, nullptr, 0, 1.f, stream, nullptr, 0, tap_groups, (float*)workspace);
+    if (lens && slack < 0) { set_error("conv1d_split_ksplit: negative slack"); return DSP_EINVAL; }
+    int rc = cs_run(x, ldx, w_hi, w_lo, nullptr, out, ldo, B, T, CI, nslices, M, ntaps, 0, 0, nullptr, 0, 1.f, stream, lens, slack, tap_groups, (float*)workspace);
     if (rc != DSP_OK) return rc;
     if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split_ksplit: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     const long n = (long)B * T * M;

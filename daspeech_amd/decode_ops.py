@@ -484,7 +484,8 @@ class SplitConv1d:
     def __call__(self, x: Tensor, relu: bool = False, act: Optional[str] = None, residual: Optional[Tensor] = None, alpha: float = 1.0,
                  lens: Optional[Tensor] = None, slack: int = 0) -> Tensor:
         """act(conv(x) + bias), or residual + alpha * that when a residual [B,T,Cout] is given.  lens [B] int32 (ragged batch): time tiles
-        starting at or after lens[b] + slack are padding and come back as zeros without being computed (dsp_conv1d_split_ragged)."""
+        starting at or after lens[b] + slack are padding and are not computed: they come back as zeros (dsp_conv1d_split_ragged) or, in
+        the split-K form of short sequences, as residual + alpha * act(bias) — finite either way."""
         _gpu("SplitConv1d", x)
         code = 1 if relu else self.ACT[act]
         assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == self.Cin and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
@@ -493,7 +494,9 @@ class SplitConv1d:
         with torch.cuda.device(x.device):
             st = _lib.current_stream_handle()
             out = torch.empty((B, T, self.Cout), dtype=torch.float32, device=x.device)
-            tg = self._tap_groups(B, T) if lens is None else 0
+            tg = self._tap_groups(B, T)
+            if lens is not None:
+                assert lens.dtype == torch.int32 and lens.is_cuda and lens.is_contiguous() and lens.numel() == B
             if tg:
                 # short sequence: split the reduction over slices x tap groups so that the launch fills the chip (dsp_conv1d_split_ksplit)
                 r = None
@@ -504,7 +507,7 @@ class SplitConv1d:
                 ws = torch.empty((nws // 4,), dtype=torch.float32, device=x.device)
                 _lib.check(lib.dsp_conv1d_split_ksplit(_lib.ptr(x), x.stride(1), _lib.ptr(self.hi), _lib.ptr(self.lo), _lib.ptr(self.bias), _lib.ptr(r), self.Cout,
                                                        float(alpha), _lib.ptr(out), self.Cout, B, T, self.step, self.nslices, self.Cout, self.K, code, tg,
-                                                       _lib.ptr(ws), nws, st), "dsp_conv1d_split_ksplit")
+                                                       _lib.ptr(ws), nws, _lib.ptr(lens), int(slack), st), "dsp_conv1d_split_ksplit")
             elif lens is not None:
                 r = None
                 if residual is not None:

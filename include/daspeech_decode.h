@@ -131,11 +131,13 @@ int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const vo
  * three quarters of the CUs idle and run a 288-step reduction per workgroup): the K dimension is split over nslices * tap_groups
  * workgroups per output tile (one 512-channel input slice and ceil(ntaps / tap_groups) taps each), raw partial sums go to `workspace`
  * (dsp_conv1d_split_ksplit_workspace_bytes) and a second launch adds them in a fixed order with bias, activation and residual:
- *   out = res + alpha * act(bias + sum over parts).   Not bit-identical to dsp_conv1d_split (different association of the K sum). */
+ *   out = res + alpha * act(bias + sum over parts).   Not bit-identical to dsp_conv1d_split (different association of the K sum).
+ * lens / slack as dsp_conv1d_split_ragged (NULL: dense); skipped tiles contribute zero partial sums, so their rows come back as
+ * res + alpha * act(bias) — finite padding. */
 size_t dsp_conv1d_split_ksplit_workspace_bytes(int B, int T, int M, int nslices, int tap_groups);
 int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, const float* res, long ldr, float alpha,
                             float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int act, int tap_groups,
-                            void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+                            void* workspace, size_t workspace_bytes, const int* lens, int slack, dsp_stream_t stream);
 
 /* The Conformer's feed-forward module in one matrix-core launch (+ a fixed-order reduction of the hidden-channel groups), fp32 accuracy:
  *   out = res + alpha * (W2 . act(W1 . LN(x) + b1) + b2)          (fairseq conformer_layer.py:140-146 called as x + 0.5 * ffn(x), :254-281)

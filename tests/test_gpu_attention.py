@@ -172,3 +172,25 @@ def test_split_k_form_of_short_sequence_layers_matches_fp64(B, T, Cin, Cout, K, 
     scale = ref.abs().max().item()
     e_k, e_1 = (got.double() - ref).abs().max().item() / scale, (one.double() - ref).abs().max().item() / scale
     assert e_k < 3e-6 and e_k < 3 * max(e_1, 3e-7), (e_k, e_1)
+
+
+def test_ragged_acoustic_stage_equals_the_dense_one_on_every_valid_frame():
+    """The whole acoustic stage (Conformer -> NAT decoder -> graph decode -> FastSpeech2) with the tile-skipping switches on and off:
+    identical tokens, identical mel bits on every valid frame (padding rows only feed padding)."""
+    from daspeech_amd.generator import S2SNATGenerator
+    from daspeech_amd.models.daspeech import S2SConformerDAGFastSpeech2Model
+    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev).eval()
+    gen = S2SNATGenerator(None, torch.zeros(80, device=dev), torch.ones(80, device=dev))
+    batch = make_s2st_batch(6, dev, seed=3, min_frames=120, max_frames=700)
+    with torch.no_grad():
+        model.decoder.ragged = model.tts.ragged = True
+        a = gen._acoustic(model, batch)
+        model.decoder.ragged = model.tts.ragged = False
+        b = gen._acoustic(model, batch)
+    assert torch.equal(a["tokens"], b["tokens"]) and torch.equal(a["out_lens"], b["out_lens"])
+    assert int(a["out_lens"].min()) < int(a["out_lens"].max())                 # the batch IS ragged
+    for i, n in enumerate(a["out_lens"].tolist()):
+        assert torch.equal(a["mel"][i, :n], b["mel"][i, :n]), i
