@@ -14,7 +14,7 @@ dev = torch.device("cuda"); torch.manual_seed(1234)
 model = calibrate_synthetic_weights(S2SConformerDAGFastSpeech2Model()).to(dev).eval()
 gen = S2SNATGenerator(None, torch.zeros(80, device=dev), torch.ones(80, device=dev))
 batches = [make_s2st_batch(32, dev, seed=i) for i in range(2)]
-if os.environ.get("RAGGED", "1") == "0":                       # compute every padded row (the r04k behaviour)
+if os.environ.get("RAGGED", "1") == "0":                       # compute every padded row
     model.decoder.ragged = model.tts.ragged = False
 with torch.no_grad():
     for i in range(3): gen._acoustic(model, batches[i % 2])
