@@ -70,7 +70,9 @@ SIGNATURES = {
                                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p, _c_int, _c_p]),
     "dsp_ffn_split_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dsp_ffn_split": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, ctypes.c_float, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float,
-                               _c_p, ctypes.c_long, _c_p, _c_sz, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+                               _c_p, ctypes.c_long, _c_p, _c_sz, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, ctypes.c_float, _c_p, _c_p]),
+    "dsp_linear_ln_split": (_c_int, [_c_p, ctypes.c_long, _c_p, _c_p, ctypes.c_float, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, ctypes.c_float, _c_p, ctypes.c_long,
+                                     _c_int, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p]),
     "dsp_layer_norm": (_c_int, [_c_p, _c_p, _c_p, ctypes.c_float, _c_p, ctypes.c_long, _c_int, _c_p]),
     "dsp_dwconv_bn_silu": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_float, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_hifigan_conv": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int),

@@ -24,6 +24,7 @@ struct CsParams {
     int relu, accumulate;          // relu: activation after the bias — 0 none, 1 ReLU, 2 SiLU, 3 GELU(erf)
     int nslices; long wslice;      // the input is nslices x CI channels wide; slice s uses weights + s * wslice (halves)
     const float* res; long ldr; float alpha;      // out = res + alpha * act(bias + conv)   (res may be NULL: out = alpha * act(...))
+    const float* ln_w; const float* ln_b; float ln_eps;   // LayerNorm of the input rows while they are staged (256-channel one-tap layers: the row sits in half a wave)
     int kparts, tap_groups; float* part;          // split-K: kparts = nslices * tap_groups workgroups per output tile, raw partial sums to part [kparts][B][T][M]
     const int* lens; int slack;                   // ragged batch: rows >= lens[b] + slack of sample b are padding nobody reads — their
 };                                                // tiles are not computed, the output rows are written as zeros
@@ -122,7 +123,28 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
                 const int e = e0 + u * 512;
                 if (e < n) {
                     const int row = e / CH, ch = e - row * CH;
-                    const float f[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vc[u].x, vc[u].y, vc[u].z, vc[u].w};
+                    float f[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vc[u].x, vc[u].y, vc[u].z, vc[u].w};
+                    if constexpr (CI == 256 && NT == 64 && MT == 256) {
+                        if (p.ln_w) {                        // one tap, one slice (host-checked): every lane is here; the row's 32 chunks are 32 consecutive lanes
+                            float s1 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) s1 += f[i];
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+                            const float mean = s1 * (1.f / CI);
+                            float q = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; q += d * d; }
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                            const float rstd = rsqrtf(q * (1.f / CI) + p.ln_eps);
+                            const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + ch * 8), w1 = *reinterpret_cast<const float4*>(p.ln_w + ch * 8 + 4);
+                            const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + ch * 8), b1 = *reinterpret_cast<const float4*>(p.ln_b + ch * 8 + 4);
+                            const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * w8[i] + b8[i];
+                        }
+                    }
                     cs_h8 vh, vl;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -320,7 +342,8 @@ extern "C" int dsp_conv1d_split_pack(const float* w_tap_major, void* w_hi, void*
 
 static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, const float* bias, float* out, long ldo,
                   int B, int T, int CI, int nslices, int M, int ntaps, int relu, int accumulate, const float* res, long ldr, float alpha,
-                  dsp_stream_t stream, const int* lens = nullptr, int slack = 0, int tap_groups = 0, float* part = nullptr)
+                  dsp_stream_t stream, const int* lens = nullptr, int slack = 0, int tap_groups = 0, float* part = nullptr,
+                  const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f)
 {
     if (B < 0 || T < 1 || M < 4 || (M & 3) || ntaps < 1 || !(ntaps & 1) || ntaps > 31 || nslices < 1 || ldx < (long)CI * nslices || ldo < M ||
         (ldx & 3) || (ldo & 3)) {
@@ -333,10 +356,14 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
     p.B = B; p.T = T; p.M = M; p.ntaps = ntaps; p.ldx = ldx; p.ldo = ldo; p.relu = relu; p.accumulate = accumulate;
     p.nslices = nslices; p.wslice = dsp_conv1d_split_packed_elems(ntaps, M, CI);
     p.res = res; p.ldr = ldr; p.alpha = alpha; p.lens = lens; p.slack = slack;
+    p.ln_w = ln_w; p.ln_b = ln_b; p.ln_eps = ln_eps;
+    if (ln_w && (!ln_b || CI != 256 || nslices != 1 || ntaps != 1 || tap_groups > 0 || (((uintptr_t)ln_w | (uintptr_t)ln_b) & 15))) {
+        set_error("conv1d_split: the staged LayerNorm needs a one-tap layer over exactly 256 input channels"); return DSP_EINVAL; }
     p.kparts = tap_groups > 0 ? nslices * tap_groups : 1; p.tap_groups = tap_groups > 0 ? tap_groups : 1; p.part = part;
     const long kmul = p.kparts;                              // workgroups per output tile
     if (res && (((uintptr_t)res & 15) || ldr < M || (ldr & 3))) { set_error("conv1d_split: residual must be 16-byte aligned with row stride >= M"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    if (ln_w) return cs_launch<256, 256, 64, 8, 1>(p, st);      // the instance that carries the staged LayerNorm
     switch (CI) {
         case 256: {
             // 128-row tiles (8 time sub-tiles per wave, one workgroup per CU) when they fill the chip, 64-row tiles (two per CU) for the
@@ -411,4 +438,13 @@ extern "C" int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_h
     int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(cs_reduce_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)workspace, nslices * tap_groups, n, bias, M, act, res, ldr, alpha, out, ldo);
     return check_launch("conv1d_split_ksplit(reduce)");
+}
+
+extern "C" int dsp_linear_ln_split(const float* x, long ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* w_hi, const void* w_lo,
+                                   const float* bias, const float* res, long ldr, float alpha, float* out, long ldo, int B, int T, int M, int act,
+                                   const int* lens, int slack, dsp_stream_t stream)
+{
+    if (!ln_w || !ln_b) { set_error("linear_ln_split: LayerNorm weight and bias are required"); return DSP_EINVAL; }
+    if (lens && slack < 0) { set_error("linear_ln_split: negative slack"); return DSP_EINVAL; }
+    return cs_run(x, ldx, w_hi, w_lo, bias, out, ldo, B, T, 256, 1, M, 1, act, 0, res, ldr, alpha, stream, lens, slack, 0, nullptr, ln_w, ln_b, ln_eps);
 }

@@ -243,6 +243,35 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(const float* __restrict
     }
 }
 
+// the same with LayerNorm(out) as a second (or the only) result: one wave per row of 256 channels
+__global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(const float* __restrict__ part, int G, long rows, const float* __restrict__ b2,
+                                                            const float* __restrict__ res, long ldr, float alpha, float* __restrict__ out, long ldo,
+                                                            const float* __restrict__ lw, const float* __restrict__ lb, float eps, float* __restrict__ out_ln)
+{
+    constexpr int C = 256;
+    const int lane = threadIdx.x & 63;
+    const long n = rows * C;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const long idx = row * C + lane * 4;
+        float4 s = *reinterpret_cast<const float4*>(part + idx);
+        for (int k = 1; k < G; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * n + idx);
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        if (b2) { const float4 bb = *reinterpret_cast<const float4*>(b2 + lane * 4); s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = *reinterpret_cast<const float4*>(res + row * ldr + lane * 4);
+        const float4 v = make_float4(r.x + alpha * s.x, r.y + alpha * s.y, r.z + alpha * s.z, r.w + alpha * s.w);
+        if (out) *reinterpret_cast<float4*>(out + row * ldo + lane * 4) = v;
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / C) + eps);
+        const float4 w4 = *reinterpret_cast<const float4*>(lw + lane * 4), b4 = *reinterpret_cast<const float4*>(lb + lane * 4);
+        *reinterpret_cast<float4*>(out_ln + row * C + lane * 4) = make_float4(dx * rstd * w4.x + b4.x, dy * rstd * w4.y + b4.y, dz * rstd * w4.z + b4.z,
+                                                                               dw * rstd * w4.w + b4.w);
+    }
+}
+
 static int ff_groups(int B, int T, int H)
 {
     const long tiles = (long)((T + 63) / 64) * B;
@@ -264,12 +293,15 @@ extern "C" size_t dsp_ffn_split_workspace_bytes(int B, int T, int C, int H)
 extern "C" int dsp_ffn_split(const float* x, long ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* w1_hi, const void* w1_lo,
                              const float* b1, const void* w2_hi, const void* w2_lo, const float* b2, const float* res, long ldr, float alpha,
                              float* out, long ldo, void* workspace, size_t workspace_bytes, int B, int T, int C, int H, int act,
-                             dsp_stream_t stream)
+                             const float* post_ln_w, const float* post_ln_b, float post_ln_eps, float* out_ln, dsp_stream_t stream)
 {
     if (B < 0 || T < 1 || C != 256 || H < 512 || (H & 511) || act < 0 || act > 3 || ldx < C || ldo < C || (ldx & 3) || (ldo & 3)) {
         set_error("ffn_split: bad sizes B=%d T=%d C=%d H=%d (C = 256, H a multiple of 512)", B, T, C, H); return DSP_EINVAL; }
     if (B == 0) return DSP_OK;
-    if (!x || !w1_hi || !w1_lo || !w2_hi || !w2_lo || !out || !workspace) { set_error("ffn_split: null pointer"); return DSP_EINVAL; }
+    const bool post = post_ln_w != nullptr;
+    if (post != (post_ln_b != nullptr) || post != (out_ln != nullptr) || (post && ((((uintptr_t)post_ln_w) | ((uintptr_t)post_ln_b) | ((uintptr_t)out_ln)) & 15))) {
+        set_error("ffn_split: the post-LayerNorm needs weight, bias and an output, 16-byte aligned"); return DSP_EINVAL; }
+    if (!x || !w1_hi || !w1_lo || !w2_hi || !w2_lo || (!out && !post) || !workspace) { set_error("ffn_split: null pointer"); return DSP_EINVAL; }
     if ((ln_w == nullptr) != (ln_b == nullptr)) { set_error("ffn_split: LayerNorm needs weight and bias"); return DSP_EINVAL; }
     if (((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)workspace) | ((uintptr_t)res) | ((uintptr_t)ln_w) | ((uintptr_t)ln_b) | ((uintptr_t)b1) |
           ((uintptr_t)b2)) & 15) || (res && (ldr < C || (ldr & 3)))) {
@@ -289,6 +321,13 @@ extern "C" int dsp_ffn_split(const float* x, long ldx, const float* ln_w, const 
     int rc = check_launch("ffn_split");
     if (rc != DSP_OK) return rc;
     const long n = (long)B * T * C;
+    if (post) {
+        const long rows = (long)B * T;
+        int grid = (int)((rows + 3) / 4); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(ffn_reduce_ln_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, p.G, rows, b2, res, ldr, alpha, out, ldo, post_ln_w,
+                           post_ln_b, post_ln_eps, out_ln);
+        return check_launch("ffn_reduce_ln");
+    }
     int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(ffn_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, p.G, n, b2, C, res, ldr, alpha, out, ldo);
     return check_launch("ffn_reduce");

@@ -632,10 +632,12 @@ def _packed(lin) -> Optional["SplitConv1d"]:
     return cache[1]
 
 
-def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: str, residual: Optional[Tensor] = None, alpha: float = 1.0) -> Optional[Tensor]:
+def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: str, residual: Optional[Tensor] = None, alpha: float = 1.0,
+              post_ln: Optional["torch.nn.LayerNorm"] = None, need_out: bool = True):
     """[residual +] alpha * lin2(act(lin1(ln(x)))) in one matrix-core launch at fp32 accuracy (dsp_ffn_split: the hidden activations stay in
     LDS, LayerNorm runs while the tile is staged), or None when the shape / mode is not served: eval-mode fp32 inference on the GPU,
-    256 channels in and out, hidden width a multiple of 512."""
+    256 channels in and out, hidden width a multiple of 512.  With post_ln the reduction also applies that LayerNorm to its result (the
+    next block of a pre-norm layer starts with one) and the call returns (out, post_ln(out)); need_out=False: (None, post_ln(out))."""
     if (not SPLIT_GEMM or torch.is_grad_enabled() or lin1.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or x.dim() != 3
             or not x.is_contiguous() or lin1.weight.dtype != torch.float32 or lin1.weight.dim() != 2 or lin2.weight.dim() != 2):
         return None
@@ -643,8 +645,9 @@ def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: st
     H = lin1.weight.shape[0]
     if C != 256 or tuple(lin1.weight.shape) != (H, C) or tuple(lin2.weight.shape) != (C, H) or H % 512 or B * T < 128:
         return None
-    if ln is not None and (len(ln.normalized_shape) != 1 or ln.weight is None or ln.bias is None or ln.weight.dtype != torch.float32):
-        return None
+    for n_ in (ln, post_ln):
+        if n_ is not None and (len(n_.normalized_shape) != 1 or n_.weight is None or n_.bias is None or n_.weight.dtype != torch.float32):
+            return None
     lib = _lib.load()
     p1, p2 = _packed(lin1), _packed(lin2)
     r = None
@@ -654,12 +657,53 @@ def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: st
     with torch.cuda.device(x.device):
         nws = lib.dsp_ffn_split_workspace_bytes(B, T, C, H)
         ws = torch.empty((nws // 4,), dtype=torch.float32, device=x.device)
-        out = torch.empty_like(x)
+        out = torch.empty_like(x) if (need_out or post_ln is None) else None
+        out_ln = None if post_ln is None else torch.empty_like(x)
         _lib.check(lib.dsp_ffn_split(_lib.ptr(x), x.stride(1), _lib.ptr(None if ln is None else ln.weight), _lib.ptr(None if ln is None else ln.bias),
                                      float(ln.eps) if ln is not None else 0.0, _lib.ptr(p1.hi), _lib.ptr(p1.lo), _lib.ptr(p1.bias), _lib.ptr(p2.hi),
                                      _lib.ptr(p2.lo), _lib.ptr(p2.bias), _lib.ptr(r), C, float(alpha), _lib.ptr(out), C, _lib.ptr(ws), nws, B, T, C, H,
-                                     SplitConv1d.ACT[act], _lib.current_stream_handle()), "dsp_ffn_split")
-    return out
+                                     SplitConv1d.ACT[act], _lib.ptr(None if post_ln is None else post_ln.weight),
+                                     _lib.ptr(None if post_ln is None else post_ln.bias), float(post_ln.eps) if post_ln is not None else 0.0,
+                                     _lib.ptr(out_ln), _lib.current_stream_handle()), "dsp_ffn_split")
+    return out if post_ln is None else (out, out_ln)
+
+
+def linear_ln(x: Tensor, ln: "torch.nn.LayerNorm", lins, act: Optional[str] = None, lens: Optional[Tensor] = None, slack: int = 0) -> tuple:
+    """(lin(ln(x)) for lin in lins): for 256-channel inputs in eval-mode fp32 inference on the GPU ONE split GEMM over the stacked weights with
+    the LayerNorm applied while the row tile is staged (dsp_linear_ln_split) — no LayerNorm launch, no normalised copy of x; otherwise
+    layer_norm followed by linear_fused."""
+    first = lins[0]
+    if (SPLIT_GEMM and not first.training and not ln.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and not torch.is_autocast_enabled() and x.dim() == 3 and x.is_contiguous() and x.shape[2] == 256 and x.shape[0] * x.shape[1] >= 128
+            and len(ln.normalized_shape) == 1 and ln.weight is not None and ln.bias is not None and ln.weight.dtype == torch.float32
+            and all(l.weight.dim() in (2, 3) and l.weight.shape[1] == 256 and l.weight.dtype == torch.float32 and (l.weight.dim() == 2 or l.weight.shape[2] == 1)
+                    for l in lins)):
+        if len(lins) == 1:
+            pk = _packed(first)
+        else:
+            key = tuple((l.weight.data_ptr(), l.weight._version, None if l.bias is None else l.bias._version) for l in lins)
+            cache = getattr(first, "_dsp_cat", None)
+            if cache is None or cache[0] != key:
+                cache = (key, _CatLinear(lins))
+                first._dsp_cat = cache
+            pk = _packed(cache[1])
+        if pk.Cout % 4 == 0 and pk.Cout >= 128:
+            B, T, _ = x.shape
+            lib = _lib.load()
+            with torch.cuda.device(x.device):
+                y = torch.empty((B, T, pk.Cout), dtype=torch.float32, device=x.device)
+                _lib.check(lib.dsp_linear_ln_split(_lib.ptr(x), x.stride(1), _lib.ptr(ln.weight), _lib.ptr(ln.bias), float(ln.eps), _lib.ptr(pk.hi), _lib.ptr(pk.lo),
+                                                   _lib.ptr(pk.bias), None, 0, 1.0, _lib.ptr(y), pk.Cout, B, T, pk.Cout, SplitConv1d.ACT[act], _lib.ptr(lens),
+                                                   int(slack), _lib.current_stream_handle()), "dsp_linear_ln_split")
+            outs, o = [], 0
+            for l in lins:
+                outs.append(y[..., o:o + l.weight.shape[0]]); o += l.weight.shape[0]
+            return tuple(outs)
+    xn = layer_norm(x, ln)
+    if len(lins) == 1:
+        return (linear(xn, first, act=act, lens=lens, slack=slack),)
+    assert act is None
+    return linear_fused(xn, lins, lens=lens, slack=slack)
 
 
 def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:

@@ -162,11 +162,17 @@ class RelPosSelfAttention(nn.Module):
             cache[key] = hit = (decode_ops.linear(pos, self.linear_pos), pos)         # the table is kept alive with its projection
         return hit[0]
 
-    def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor], residual: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, pos: Tensor, pad_mask: Optional[Tensor], residual: Optional[Tensor] = None, ln: Optional[nn.LayerNorm] = None) -> Tensor:
+        """ln (eval-mode fast path only): the block's pre-LayerNorm, applied inside the stacked q|k|v projection instead of by the caller"""
         B, T, C = x.shape
         L_ = decode_ops.linear
+        if ln is not None and (self.training or self.dk != 64):
+            x, ln = decode_ops.layer_norm(x, ln), None
         if not self.training and self.dk == 64:
-            qf, kf, vf = decode_ops.linear_fused(x, (self.linear_q, self.linear_k, self.linear_v))
+            if ln is not None:
+                qf, kf, vf = decode_ops.linear_ln(x, ln, (self.linear_q, self.linear_k, self.linear_v))
+            else:
+                qf, kf, vf = decode_ops.linear_fused(x, (self.linear_q, self.linear_k, self.linear_v))
             o = decode_ops.relpos_attention(qf, kf, vf, self._projected_positions(pos), self.pos_bias_u, self.pos_bias_v, pad_mask, self.h)
             if o is not None:                                         # one fused HIP kernel for scores, shift, soft-max and the value product
                 return L_(o, self.linear_out, residual=residual)
@@ -227,15 +233,22 @@ class ConformerLayer(nn.Module):
             x = x + _drop(F.linear(y.transpose(1, 2), c["pointwise_conv2"].weight.squeeze(-1)), p, tr)  # :100
             x = ffn(self.ffn2, x)
             return self.final_layer_norm(x)
+        # pre-norm blocks with their LayerNorms folded into the kernels around them (eval): ffn1 (LayerNorm while staging) -> attention (its
+        # LayerNorm inside the stacked q|k|v projection) -> convolution module (its LayerNorm inside pointwise_conv1) -> ffn2, whose
+        # reduction also applies final_layer_norm
         x = self._ffn(self.ffn1, x)
-        x = self.self_attn(decode_ops.layer_norm(x, self.self_attn_layer_norm), pos, pad_mask, residual=x)
-        y = F.glu(decode_ops.linear(decode_ops.layer_norm(x, c["layer_norm"]), c["pointwise_conv1"]), dim=-1)
+        x = self.self_attn(x, pos, pad_mask, residual=x, ln=self.self_attn_layer_norm)
+        y = F.glu(decode_ops.linear_ln(x, c["layer_norm"], (c["pointwise_conv1"],))[0], dim=-1)
         dw = c["depthwise_conv"]
         if y.is_cuda and y.shape[-1] % 4 == 0 and dw.kernel_size[0] in (3, 7, 15, 31) and dw.bias is None:
             y = decode_ops.dwconv_bn_silu(y, dw.weight, c["batch_norm"])       # one HIP pass on [B,T,C], no transposes
         else:
             y = F.silu(c["batch_norm"](dw(y.transpose(1, 2)))).transpose(1, 2)
         x = decode_ops.linear(y.contiguous(), c["pointwise_conv2"], residual=x)
+        m = self.ffn2
+        fused = decode_ops.ffn_fused(x, m["layer_norm"], m["w_1"], m["w_2"], "silu", residual=x, alpha=0.5, post_ln=self.final_layer_norm, need_out=False)
+        if fused is not None:
+            return fused[1]
         x = self._ffn(self.ffn2, x)
         return decode_ops.layer_norm(x, self.final_layer_norm)
 

@@ -127,6 +127,15 @@ int dsp_conv1d_split_ragged(const float* x, long ldx, const void* w_hi, const vo
                             float alpha, float* out, long ldo, int B, int T, int CI, int nslices, int M, int ntaps, int relu,
                             const int* lens, int slack, dsp_stream_t stream);
 
+/* act(W . LayerNorm(x) + b) [as residual / alpha of dsp_conv1d_split_residual] for a Linear layer over exactly 256 input channels: the
+ * LayerNorm (torch semantics, weight and bias [256]) is applied while the row tile is staged — a row's 256 channels sit in half a wave —
+ * so pre-norm blocks (the Conformer's self-attention and convolution modules: LayerNorm -> linear_q|k|v, LayerNorm -> pointwise_conv1,
+ * conformer_layer.py:254-281) need no LayerNorm launch and no normalised copy of x in HBM.  w_hi / w_lo as dsp_conv1d_split_pack packs a
+ * one-tap layer; lens / slack as dsp_conv1d_split_ragged (NULL: dense). */
+int dsp_linear_ln_split(const float* x, long ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* w_hi, const void* w_lo,
+                        const float* bias, const float* res, long ldr, float alpha, float* out, long ldo, int B, int T, int M, int act,
+                        const int* lens, int slack, dsp_stream_t stream);
+
 /* the same layer for SHORT sequences (few time tiles: the FastSpeech2 encoder's K = 9 convolutions over ~60 phoneme positions leave
  * three quarters of the CUs idle and run a 288-step reduction per workgroup): the K dimension is split over nslices * tap_groups
  * workgroups per output tile (one 512-channel input slice and ceil(ntaps / tap_groups) taps each), raw partial sums go to `workspace`
@@ -144,11 +153,14 @@ int dsp_conv1d_split_ksplit(const float* x, long ldx, const void* w_hi, const vo
  * x [B,T,C] (row stride ldx), ln_w / ln_b [C] or both NULL (no LayerNorm), W1 [H,C] and W2 [C,H] as packed by dsp_conv1d_split_pack
  * (one tap; W2 in 512-channel input slices as dsp_conv1d_split takes them), b1 [H], b2 [C] or NULL, res [B,T,C] (row stride ldr) or
  * NULL, out [B,T,C] (row stride ldo; may be res).  act as dsp_conv1d_split's relu argument (0 none, 1 ReLU, 2 SiLU, 3 GELU).
- * C = 256, H a multiple of 512.  workspace: dsp_ffn_split_workspace_bytes(B, T, C, H) bytes of device memory (partial sums). */
+ * C = 256, H a multiple of 512.  workspace: dsp_ffn_split_workspace_bytes(B, T, C, H) bytes of device memory (partial sums).
+ * post_ln_w / post_ln_b (both or neither) + out_ln [B,T,C] contiguous: the reduction also writes LayerNorm(out) there (the block that
+ * follows in a pre-norm layer starts with one); out itself may then be NULL when only the normalised rows are needed. */
 size_t dsp_ffn_split_workspace_bytes(int B, int T, int C, int H);
 int dsp_ffn_split(const float* x, long ldx, const float* ln_w, const float* ln_b, float ln_eps, const void* w1_hi, const void* w1_lo, const float* b1,
                   const void* w2_hi, const void* w2_lo, const float* b2, const float* res, long ldr, float alpha, float* out, long ldo,
-                  void* workspace, size_t workspace_bytes, int B, int T, int C, int H, int act, dsp_stream_t stream);
+                  void* workspace, size_t workspace_bytes, int B, int T, int C, int H, int act, const float* post_ln_w, const float* post_ln_b,
+                  float post_ln_eps, float* out_ln, dsp_stream_t stream);
 
 /* LayerNorm over the last dimension (torch.nn.LayerNorm semantics: biased variance, eps inside the square root), one wave per row:
  * x, y [rows, C] fp32 contiguous (y may be x), w / b [C] or NULL, C % 4 == 0, C <= 2048, all pointers 16-byte aligned. */
