@@ -137,6 +137,7 @@ class RelPosSelfAttention(nn.Module):
         self.p_attn = dropout                       # on the attention probabilities (espnet_multihead_attention.py:40,82)
         self.linear_q, self.linear_k, self.linear_v, self.linear_out = (nn.Linear(dim, dim) for _ in range(4))
         self.linear_pos = nn.Linear(dim, dim, bias=False)
+        self.cache_position_projection = False
         self.pos_bias_u = nn.Parameter(torch.zeros(heads, self.dk))
         self.pos_bias_v = nn.Parameter(torch.zeros(heads, self.dk))
         nn.init.xavier_uniform_(self.pos_bias_u); nn.init.xavier_uniform_(self.pos_bias_v)
@@ -148,10 +149,11 @@ class RelPosSelfAttention(nn.Module):
         return x[..., : P // 2 + 1]
 
     def _projected_positions(self, pos: Tensor) -> Tensor:
-        """linear_pos(pos) in eval-mode inference: a constant of (the position table, the weight) — kept per table instead of being
-        recomputed by every batch (12 small GEMMs per encoder pass)."""
+        """linear_pos(pos).  With `cache_position_projection = True` (a serving option, OFF by default and in bench.py: the reference computes
+        it in every forward, fairseq espnet_multihead_attention.py:217-218) eval-mode inference keeps the projection per (position table,
+        weight version) instead of recomputing it for every batch (12 small GEMMs per encoder pass)."""
         w = self.linear_pos.weight
-        if torch.is_grad_enabled() or self.training:
+        if torch.is_grad_enabled() or self.training or not self.cache_position_projection:
             return decode_ops.linear(pos, self.linear_pos)
         key = (pos.data_ptr(), tuple(pos.shape), w.data_ptr(), w._version)
         cache = self.__dict__.setdefault("_pos_proj", {})

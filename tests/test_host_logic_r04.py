@@ -36,6 +36,9 @@ def test_position_tables_are_cached_constants():
     assert rel_positional_encoding(18, 64, torch.device("cpu"), torch.float32).shape == (1, 35, 64)
     att = RelPosSelfAttention(128, 2).eval()
     with torch.no_grad():
+        t9 = rel_positional_encoding(9, 128, torch.device("cpu"), torch.float32)
+        assert att._projected_positions(t9) is not att._projected_positions(t9)           # off by default: computed per forward, as the reference does
+        att.cache_position_projection = True
         p1, p2 = att._projected_positions(rel_positional_encoding(9, 128, torch.device("cpu"), torch.float32)), \
             att._projected_positions(rel_positional_encoding(9, 128, torch.device("cpu"), torch.float32))
         assert p1 is p2
