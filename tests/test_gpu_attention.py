@@ -95,7 +95,7 @@ def test_attention_split_rejects_unsupported_head_width():
 @pytest.mark.parametrize("B,T,H,lens", [(3, 77, 4, [77, 40, 5]), (2, 200, 4, [200, 131]), (1, 5, 2, None), (2, 256, 1, [256, 255]),
                                         (2, 300, 4, [300, 170]), (1, 513, 2, None), (32, 177, 4, None)])
 def test_relpos_attention_split_matches_fp64(B, T, H, lens):
-    """dsp_relpos_attention_split against an fp64 restatement of espnet's RelPositionMultiHeadedAttention core
+    """dsp_relpos_attention (the matrix-core kernel) against an fp64 restatement of espnet's RelPositionMultiHeadedAttention core
     (fairseq/modules/espnet_multihead_attention.py:172-254: matrix_ac + rel_shift(matrix_bd), masked soft-max, value product)."""
     from daspeech_amd import decode_ops
     dev = torch.device("cuda:0")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Split-precision Conv1d / Linear kernels per layer shape of the acoustic model: whole-slice kernel (conv1d_split.hip) vs K-streaming kernel
-(conv1d_stream.hip), us per call and TFLOP/s of convolution (matrix cores issue 3x that).  GPU box."""
+"""Split-precision Conv1d / Linear kernel (conv1d_split.hip) per layer shape of the acoustic model: us per call and TFLOP/s of convolution
+(the matrix cores issue 3x that).  (r04's K-streaming experiment kernel this tool compared against lives only at commit 072a6ad:
+profiles/r04_conv_stream_experiment.txt.)  GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
