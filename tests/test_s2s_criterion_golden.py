@@ -173,7 +173,11 @@ def _run_case(m, g, pre, opts, case, seed, tol=1.0):
     for key in keys:
         ref = g[f"{pre}/grad:{key}"]
         got = grads[key].detach().float().cpu().numpy().reshape(-1)[: ref.size].reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 3e-4 * tol * np.abs(ref).max() + 1e-7 * tol * total, (key, np.abs(got - ref).max(), np.abs(ref).max())
+        # a global scalar (tts.pos_emb_alpha, dec_pos_emb_alpha) is one cancelling sum over every position and channel of a gradient that
+        # reached it through atomic scatter-adds (the length regulator's gather backward): run to run it moves by ~1e-3 of itself on the
+        # GPU (seen: 1.3231 vs 1.3244 in one of three identical runs), so scalars get ten times the tensors' tolerance
+        w = 10.0 if ref.size <= 4 else 1.0
+        assert np.abs(got - ref).max() <= 3e-4 * tol * w * np.abs(ref).max() + 1e-7 * tol * total, (key, np.abs(got - ref).max(), np.abs(ref).max())
     return grads
 
 
