@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 METRIC = "utterances/sec end-to-end S2ST (fbank→waveform) + dag_loss fwd+bwd ms/batch"
 
 
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="headline", choices=["headline", "dag", "s2tt", "s2st", "train"],
+    ap.add_argument("--workload", default="headline", choices=["headline", "dag", "s2tt", "s2st", "train", "plumbing"],
                     help="headline (default) = C4 S2ST utt/s + C2 DAG ops with the DP roofline + C1 vs the CPU baseline, one JSON line; "
                          "dag / s2st / s2tt / train = that part alone")
     ap.add_argument("--tr", type=int, default=32, help="C2 transition window (32 = banded fast path, 4095 = README's --max-transition-length 99999)")
@@ -73,6 +74,8 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
     ap.add_argument("--no-peaked", action="store_true")
     ap.add_argument("--no-c1", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline: skip the C3 (s2tt, B=64) and C5 (train, B=32, fp16 model) legs")
+    ap.add_argument("--extra-steps", type=int, default=6, help="headline: timed steps of the C3 / C5 legs")
     ap.add_argument("--torch-links", action="store_true", help="train: the torch [B,L,L,h] formulation of extract_links instead of the fused band kernels")
     args = ap.parse_args()
     if args.batch is None:
@@ -115,34 +118,51 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # DSP_BENCH_BACKEND=gloo: the rehearsal mode of the multi-rank plumbing (tests/): ranks may share a device, collectives on host
+        # tensors.  The default, and the only mode a measurement may use, is "nccl" (= RCCL), one rank per GPU.
+        self.backend = os.environ.get("DSP_BENCH_BACKEND", "nccl")
+        self.plumbing = args.workload == "plumbing"
         if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+            if not self.plumbing:
+                raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+            self.backend = "gloo"
         if args.gpus != self.world:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch one rank per GPU")
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev:
+            if self.backend == "nccl" and self.local_rank >= ndev:
+                raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {ndev} GPUs are visible")
+            torch.cuda.set_device(self.local_rank % ndev)
+            self.dev = torch.device("cuda", self.local_rank % ndev)
+        else:
+            self.dev = torch.device("cpu")
+        self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")       # where collective payloads live
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=self.dev)
-            self.world = dist.get_world_size()            # n_gpus of the line comes from RCCL's world, not from the flag
-            assert self.world == args.gpus, f"RCCL world size {self.world} != --gpus {args.gpus}"
-            # one collective before anything is timed: every rank really is in the RCCL communicator, on its own device
-            probe = torch.tensor([1.0, float(torch.cuda.current_device())], device=self.dev)
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend="gloo")
+            self.world = dist.get_world_size()            # n_gpus of the line comes from the communicator's world, not from the flag
+            assert self.world == args.gpus, f"world size {self.world} != --gpus {args.gpus}"
+            # one collective before anything is timed: every rank really is in the communicator, on its own device
+            probe = torch.tensor([1.0, float(torch.cuda.current_device() if ndev else self.rank)], device=self.cdev)
             dist.all_reduce(probe)
             assert int(probe[0].item()) == self.world, f"all-reduce over {self.world} ranks summed to {probe[0].item()}"
-            if torch.cuda.device_count() >= self.world:
+            if self.backend == "nccl" or not ndev:
                 assert int(probe[1].item()) == self.world * (self.world - 1) // 2, "ranks share a device"
-            print(f"[bench] rank {self.rank}/{self.world} on cuda:{self.local_rank} ({torch.cuda.get_device_name(self.dev)}), RCCL all-reduce ok",
-                  file=sys.stderr, flush=True)
+            name = torch.cuda.get_device_name(self.dev) if ndev else "cpu"
+            print(f"[bench] rank {self.rank}/{self.world} on {self.dev} ({name}), {self.backend} all-reduce ok", file=sys.stderr, flush=True)
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if self.dev.type == "cuda":
+            self.torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
         if self.world > 1:
-            t = self.torch.tensor([seconds], device=self.dev, dtype=self.torch.float64)
+            t = self.torch.tensor([seconds], device=self.cdev, dtype=self.torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             return float(t.item())
         return seconds
@@ -414,7 +434,17 @@ def build_model_step(ctx, args, workload):
     model.args.decode_strategy = args.decode_strategy
     if getattr(args, "torch_links", False):
         model.decoder.fused_links = False
-    batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
+    if world > 1:
+        # ONE global pool of world * B utterances per step (same seed on every rank), split by balanced_shards on src_frames: the per-rank
+        # sum of T*L*TR (and of frames) differs by < 1 % instead of the 10-50 % of an arbitrary split — the max-over-ranks timing pays for it
+        from daspeech_amd.distributed import balanced_shards, shard_sample
+        batches = []
+        for i in range(2):
+            pool = make_s2st_batch(B * world, "cpu", seed=9000 + i)
+            shards = balanced_shards(pool["net_input"]["src_lengths"], world)
+            batches.append(shard_sample(pool, shards[rank], dev))
+    else:
+        batches = [make_s2st_batch(B, dev, seed=100 * rank + i) for i in range(2)]
     amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
     state = {"frames": 0, "model": model, "batches": batches, "B": B}
     prec = "fp32" if args.amp == "none" else f"{args.amp} autocast dense layers / fp32 graph + TTS glue ops"
@@ -558,6 +588,24 @@ def main():
     from daspeech_amd import _lib
     _lib.load()                                       # fails loudly if the HIP extension is missing
     world, rank = ctx.world, ctx.rank
+    if ctx.plumbing:
+        # launcher / rendezvous / barrier / max-over-ranks / sharding rehearsal: K trivial "steps" (a sleep proportional to this rank's
+        # shard cost), no kernels — value is NOT a measurement and the line says so
+        from daspeech_amd.distributed import balanced_shards, shard_spread
+        g = ctx.torch.Generator().manual_seed(17)
+        frames = ctx.torch.randint(300, 801, (32 * world,), generator=g)
+        shards = balanced_shards(frames, world)
+        mine = float(frames[ctx.torch.tensor(shards[rank])].sum())
+        el, _ = ctx.timed(lambda i: time.sleep(mine * 1e-8), args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "none", "data": "none", "config": {"workload": "plumbing rehearsal: no kernels, NOT a measurement",
+                                                                           "backend": ctx.backend, "shard_spread": shard_spread(frames, shards)},
+                              "roofline": None, "cpu_baseline": None}))
+        if world > 1:
+            ctx.dist.destroy_process_group()
+        return
     base = {"metric": METRIC, "unit": "utt/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "data": "synthetic"}
     par = f"dp{world} (independent utterances per rank, no data-path collective)"
@@ -593,6 +641,13 @@ def main():
                 tr_full = {"workload": f"C2 with the README's dense window: B={args.dag_batch}, graph_len={args.graph_len}, tgt_len={args.tgt_len}, TR={args.graph_len - 1}",
                            "dag_fwd_ms": pf["dag_fwd"], "dag_bwd_ms": pf["dag_bwd"], "best_alignment_ms": pf["best_alignment"],
                            "dag_loss_fwd_bwd_ms": pf["dag_fwd"] + pf["dag_bwd"], "phases_ms": pf, **inf}
+                # dense window: every DP row is a triangular [1 x L].[L x L] product in both directions -> 2 dirs * B * T * L^2/2 * 2 FLOP on the
+                # fp32 matrix cores (v_mfma_f32_16x16x4_f32, 157 TFLOP/s dense peak); the alignment is the same count of (max, +) pairs on the VALU
+                Lf, fl = float(args.graph_len), 2.0 * args.dag_batch * args.tgt_len * float(args.graph_len) ** 2
+                tr_full["roofline"] = {"bound": "mfma", "kernel": "dag_dense_mfma forward (alpha||beta)", "flop": fl, "achieved": fl / (pf["dag_fwd"] * 1e-3) / 1e12,
+                                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (pf["dag_fwd"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+                tr_full["alignment_roofline"] = {"bound": "valu", "kernel": "dag_dense_max (max-plus products) + block back-trace", "pair_ops": fl / 4.0,
+                                                 "achieved_Gpairs_per_s": fl / 4.0 / (pf["best_alignment"] * 1e-3) / 1e9}
             except Exception as e:      # noqa: a leg of its own, the headline does not depend on it
                 tr_full = {"error": repr(e)[:200]}
         result = {**base, "value": s2st["value"], "steps": s2st["steps"], "warmup": s2st["warmup"], "ms_per_step": s2st["ms_per_step"],
@@ -612,6 +667,18 @@ def main():
                                            "vocoder_roofline": fast.get("roofline")}
         if tr_full is not None:
             result["dag_tr%d" % (args.graph_len - 1)] = tr_full
+        # C3 and C5 in the same driver-timed line (short legs; `--workload s2tt|train` run them alone at the contract's K)
+        if not args.no_extra_legs:
+            for key, wl, nb in (("c3_s2tt", "s2tt", 64), ("c5_train", "train", 32)):
+                try:
+                    ax = copy.copy(args); ax.batch = nb
+                    rr = run_model(ctx, ax, wl, args.extra_steps, 2)
+                    result[key] = {"workload": rr["workload"], "value": rr["value"], "unit": "utt/s", "ms_per_step": rr["ms_per_step"],
+                                   "steps": rr["steps"], "warmup": rr["warmup"], "batch_per_gpu": rr["batch_per_gpu"],
+                                   "dtype": "f32" if wl == "s2tt" else "fp16",
+                                   **({k: rr[k] for k in ("peak_memory_GB", "loss_scale", "last_grad_norm") if k in rr})}
+                except Exception as e:      # noqa: legs of their own
+                    result[key] = {"error": repr(e)[:300]}
         if not args.no_c1:
             result["c1"] = c1_report(ctx, args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("headline", "dag"):

@@ -43,3 +43,72 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int =
             n += g.numel()
         if bucket:
             reduce_bucket(bucket)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Length-balanced sharding of utterances over ranks ("balance by src_frames — sort + round-robin").
+# Every kernel of this path treats utterances independently, so ranks own disjoint utterances; what has to be balanced is the
+# COST: the DAG DP is T·L·TR cells per utterance (L ∝ src_frames, T ∝ src_frames / 13, TR fixed or ∝ L) and the acoustic /
+# vocoder stages are linear in the frame count — all monotone in src_frames, which is why the reference's batcher sorts by it
+# (fairseq/fairseq/data/data_utils.py batch_by_size on num_tokens = frames) before legacy DDP hands whole batches to ranks.
+# ----------------------------------------------------------------------------------------------------------------------------
+def dag_cost(src_frames, upsample_ratio: float = 0.5, frames_per_target: float = 13.0, trans_len: int = None):
+    """T·L·TR of one utterance as the DAG DP sees it: L = ratio·frames (`--src-upsample-ratio`), T = frames / 13 + 2 (CVSS-C
+    statistics, README.md:165-167), TR = min(trans_len, L - 1) (None: the README's dense window L - 1)."""
+    f = torch.as_tensor(src_frames, dtype=torch.float64)
+    L = (f * upsample_ratio).floor().clamp(min=2)
+    T = (f / frames_per_target).round().clamp(min=1) + 2
+    TR = L - 1 if trans_len is None else torch.minimum(L - 1, torch.full_like(L, float(trans_len)))
+    return T * L * TR
+
+
+def balanced_shards(src_frames, world_size: int, cost=None):
+    """Index lists, one per rank: utterances sorted by descending cost and dealt out in boustrophedon order (0..W-1, W-1..0, ...),
+    the "sort + round-robin" split of SURVEY §8e with the serpentine turn that keeps rank 0 from always taking the longest of
+    every round.  Deterministic (ties by index), every utterance appears exactly once, shard sizes differ by at most one.
+    `cost`: per-utterance cost (default: dag_cost(src_frames) with the dense window)."""
+    f = torch.as_tensor(src_frames)
+    n = int(f.numel())
+    c = dag_cost(f) if cost is None else torch.as_tensor(cost, dtype=torch.float64)
+    assert c.numel() == n and world_size >= 1
+    order = sorted(range(n), key=lambda i: (-float(c[i]), i))
+    shards = [[] for _ in range(world_size)]
+    for k, i in enumerate(order):
+        rnd, pos = divmod(k, world_size)
+        shards[pos if rnd % 2 == 0 else world_size - 1 - pos].append(i)
+    return shards
+
+
+def shard_spread(src_frames, shards, cost=None):
+    """(max - min) / mean of the per-rank cost sums — what the max-over-ranks timing of a data-parallel step pays for."""
+    f = torch.as_tensor(src_frames)
+    c = dag_cost(f) if cost is None else torch.as_tensor(cost, dtype=torch.float64)
+    sums = torch.tensor([float(c[torch.as_tensor(s, dtype=torch.long)].sum()) if len(s) else 0.0 for s in shards], dtype=torch.float64)
+    return float((sums.max() - sums.min()) / sums.mean())
+
+
+def shard_sample(sample: dict, idx, device=None):
+    """Rows `idx` of a batch dict as make_s2st_batch / the reference's collater build it (nested dicts of [B, ...] tensors), trimmed to
+    the shard's own longest utterance on the padded axes the length fields name."""
+    idx = torch.as_tensor(idx, dtype=torch.long)
+
+    def take(x):
+        if isinstance(x, dict):
+            return {k: take(v) for k, v in x.items()}
+        if torch.is_tensor(x) and x.dim() >= 1:
+            y = x.index_select(0, idx.to(x.device))
+            return y.to(device) if device is not None else y
+        return x
+    out = take(sample)
+    ni = out.get("net_input", {})
+    if "src_tokens" in ni and "src_lengths" in ni and ni["src_lengths"].numel():
+        ni["src_tokens"] = ni["src_tokens"][:, : int(ni["src_lengths"].max())].contiguous()
+    if "target_text" in out and "target_text_lengths" in out and out["target_text_lengths"].numel():
+        Tm = int(out["target_text_lengths"].max())
+        out["target_text"] = out["target_text"][:, :Tm].contiguous()
+        for k in ("durations", "pitches", "energies"):
+            if k in out:
+                out[k] = out[k][:, : Tm - 1].contiguous()
+    if "target_audio" in out and "target_audio_lengths" in out and out["target_audio_lengths"].numel():
+        out["target_audio"] = out["target_audio"][:, : int(out["target_audio_lengths"].max())].contiguous()
+    return out

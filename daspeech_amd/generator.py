@@ -152,6 +152,20 @@ class S2SNATGenerator:
         torch.cuda.current_stream().wait_event(vev)
         return res
 
+    def generate_sharded(self, model, sample: Dict, rank: int = None, world_size: int = None, generate_waveform: bool = True):
+        """Data-parallel inference over one pool of utterances: every rank takes its length-balanced shard (distributed.balanced_shards on
+        src_lengths — SURVEY §8e), generates it, and returns (indices into the pool, results) — no collective: utterances are independent."""
+        import torch.distributed as dist
+        from .distributed import balanced_shards, shard_sample
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        idx = balanced_shards(sample["net_input"]["src_lengths"].cpu(), world_size)[rank]
+        if not idx:
+            return [], []
+        return idx, self.generate(model, shard_sample(sample, idx), generate_waveform)
+
     def generate_batches(self, model, samples):
         """for results in generator.generate_batches(model, batch_iterable): ...  — same results as calling generate() per batch."""
         for sample in samples:

@@ -45,3 +45,46 @@ def test_bench_cli_accepts_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.strip().split("\n") if l.startswith("{")]
+    assert lines, stdout
+    return json.loads(lines[-1])
+
+
+def test_bench_self_spawn_world2_gloo_rehearsal():
+    """`bench.py --gpus 2` started WITHOUT a launcher re-executes itself under torch.distributed.run (127.0.0.1 rendezvous), builds the
+    process group, runs the probe all-reduce, the barriers and the max-over-ranks reduction, shards a pool by length and prints ONE line
+    from rank 0.  No kernels (`--workload plumbing`): this is the launcher path the driver's 2/4/8-GPU runs take, rehearsed on CPU."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["DSP_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "plumbing"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json_line(out.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["shard_spread"] <= 0.05
+    assert out.stderr.count("all-reduce ok") == 2
+    assert len([l for l in out.stdout.split("\n") if l.startswith("{")]) == 1          # rank 0 only
+
+
+def test_bench_under_a_launcher_world2_gloo_rehearsal():
+    """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 (RANK / WORLD_SIZE from the env)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["DSP_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "plumbing"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert _json_line(out.stdout)["n_gpus"] == 2
+    # a world that does not match --gpus is refused, not silently re-labelled
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "plumbing"], capture_output=True, text=True,
+                         timeout=300, env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

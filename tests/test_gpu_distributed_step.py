@@ -104,3 +104,28 @@ def test_two_ranks_one_gpu_gloo_training_step_gradients():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
 def test_two_ranks_nccl_training_step_gradients():
     _run("nccl", one_gpu=False)
+
+
+def test_bench_dag_workload_two_ranks_through_its_own_launcher():
+    """`python bench.py --gpus 2 --workload dag` from a plain shell: the self-spawn path (torch.distributed.run, 127.0.0.1 rendezvous), two
+    ranks running the REAL DAG ops with their own inputs, barrier + max-over-ranks timing, one JSON line from rank 0 whose utt/s counts
+    both ranks.  Backend gloo with both ranks on this box's one GPU (DSP_BENCH_BACKEND — rehearsal mode; RCCL needs one GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["DSP_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "dag", "--steps", "2", "--warmup", "1",
+                          "--dag-batch", "4", "--graph-len", "1024", "--tgt-len", "128", "--vocab", "1024", "--no-cpu-baseline", "--no-peaked",
+                          "--no-c1"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dag"]["finite_losses"] == 4 and d["dag"]["launch_status"] == 0
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job: both ranks' utterances
+    assert d["roofline"]["frac"] > 0
