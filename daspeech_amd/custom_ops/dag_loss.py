@@ -28,6 +28,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from .. import _lib
+from . import dag_double
 
 __all__ = ["dag_loss", "dag_loss_with_alpha_beta", "dag_best_alignment", "dag_logsoftmax_gather_inplace",
            "torch_dag_loss", "torch_dag_best_alignment", "torch_dag_logsoftmax_gather_inplace", "logsumexp_keepdim"]
@@ -66,10 +67,10 @@ def _check_dp_args(name, match_all, links, output_length, target_length):
 def _f32c(t: Tensor) -> Tensor:
     """fp32 working copy (a no-op for the fp32 contiguous tensors the criteria pass).  fp16 / bf16 inputs are WIDENED — the DP runs in
     fp32 where the reference's half instantiation accumulates in half (dag_loss.cu:160), results go back in the caller's dtype.  float64
-    is refused: the reference dispatches a double instantiation, these kernels have none, and narrowing silently would hand back fp32
-    accuracy in a double tensor (use torch_dag_loss / torch_dag_best_alignment for double)."""
+    never gets here: dag_loss / dag_loss_with_alpha_beta / dag_best_alignment route it to dag_double.py (narrowing silently would hand
+    back fp32 accuracy in a double tensor)."""
     if t.dtype == torch.float64:
-        raise RuntimeError("the HIP DAG ops compute in float32: float64 inputs are not supported (cast to float32, or use the torch_* variants)")
+        raise RuntimeError("internal: float64 reached the fp32 HIP launch path (dag_double.py serves double inputs)")
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -178,8 +179,26 @@ class DagLossWithAlphaBetaFunc(Function):
         return gm, gl, None, None
 
 
-dag_loss = DagLossFunc.apply
-dag_loss_with_alpha_beta = DagLossWithAlphaBetaFunc.apply
+def _any_double(*ts) -> bool:
+    return any(t.dtype == torch.float64 for t in ts)
+
+
+def dag_loss(match_all, links, output_length, target_length):
+    """`DagLossFunc.apply` (dag_loss.py:188) — float64 inputs take the double-precision band DP of dag_double.py (the reference
+    dispatches a double instantiation, dag_loss.cu:160; the HIP kernels compute in fp32)."""
+    if _any_double(match_all, links):
+        _require_gpu("dag_loss", match_all, links, output_length, target_length)
+        _check_dp_args("dag_loss", match_all, links, output_length, target_length)
+        return dag_double.dag_loss(match_all.double(), links.double(), output_length, target_length)
+    return DagLossFunc.apply(match_all, links, output_length, target_length)
+
+
+def dag_loss_with_alpha_beta(match_all, links, output_length, target_length):
+    if _any_double(match_all, links):
+        _require_gpu("dag_loss", match_all, links, output_length, target_length)
+        _check_dp_args("dag_loss", match_all, links, output_length, target_length)
+        return dag_double.dag_loss_with_alpha_beta(match_all.double(), links.double(), output_length, target_length)
+    return DagLossWithAlphaBetaFunc.apply(match_all, links, output_length, target_length)
 
 
 class DagBestAlignmentFunc(Function):
@@ -214,7 +233,12 @@ class DagBestAlignmentFunc(Function):
         assert False, "no backward function for best alignment"
 
 
-dag_best_alignment = DagBestAlignmentFunc.apply
+def dag_best_alignment(match_all, links, output_length, target_length):
+    if _any_double(match_all, links):
+        _require_gpu("dag_best_alignment", match_all, links, output_length, target_length)
+        _check_dp_args("dag_best_alignment", match_all, links, output_length, target_length)
+        return dag_double.dag_best_alignment(match_all.double(), links.double(), output_length, target_length)
+    return DagBestAlignmentFunc.apply(match_all, links, output_length, target_length)
 
 
 def _elem_strides(t: Tensor):

@@ -639,14 +639,16 @@ def ffn_fused(x: Tensor, ln: Optional["torch.nn.LayerNorm"], lin1, lin2, act: st
     256 channels in and out, hidden width a multiple of 512.  With post_ln the reduction also applies that LayerNorm to its result (the
     next block of a pre-norm layer starts with one) and the call returns (out, post_ln(out)); need_out=False: (None, post_ln(out))."""
     if (not SPLIT_GEMM or torch.is_grad_enabled() or lin1.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled() or x.dim() != 3
-            or not x.is_contiguous() or lin1.weight.dtype != torch.float32 or lin1.weight.dim() != 2 or lin2.weight.dim() != 2):
-        return None
+            or not x.is_contiguous() or lin1.weight.dtype != torch.float32 or lin1.weight.dim() != 2 or lin2.weight.dim() != 2
+            or lin2.weight.dtype != torch.float32 or x.data_ptr() % 16):
+        return None                                   # (null biases are handled by the kernels: `if (p.b1)`, `if (p.b2)`)
     B, T, C = x.shape
     H = lin1.weight.shape[0]
     if C != 256 or tuple(lin1.weight.shape) != (H, C) or tuple(lin2.weight.shape) != (C, H) or H % 512 or B * T < 128:
         return None
     for n_ in (ln, post_ln):
-        if n_ is not None and (len(n_.normalized_shape) != 1 or n_.weight is None or n_.bias is None or n_.weight.dtype != torch.float32):
+        if n_ is not None and (tuple(n_.normalized_shape) != (C,) or n_.weight is None or n_.bias is None or n_.weight.dtype != torch.float32
+                               or n_.weight.data_ptr() % 16 or n_.bias.data_ptr() % 16):
             return None
     lib = _lib.load()
     p1, p2 = _packed(lin1), _packed(lin2)
@@ -675,7 +677,7 @@ def linear_ln(x: Tensor, ln: "torch.nn.LayerNorm", lins, act: Optional[str] = No
     first = lins[0]
     if (SPLIT_GEMM and not first.training and not ln.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
             and not torch.is_autocast_enabled() and x.dim() == 3 and x.is_contiguous() and x.shape[2] == 256 and x.shape[0] * x.shape[1] >= 128
-            and len(ln.normalized_shape) == 1 and ln.weight is not None and ln.bias is not None and ln.weight.dtype == torch.float32
+            and tuple(ln.normalized_shape) == (256,) and ln.weight is not None and ln.bias is not None and ln.weight.dtype == torch.float32
             and all(l.weight.dim() in (2, 3) and l.weight.shape[1] == 256 and l.weight.dtype == torch.float32 and (l.weight.dim() == 2 or l.weight.shape[2] == 1)
                     for l in lins)):
         if len(lins) == 1:
@@ -710,7 +712,7 @@ def layer_norm(x: Tensor, ln: "torch.nn.LayerNorm") -> Tensor:
     """ln(x): the one-wave-per-row HIP kernel (dsp_layer_norm) in eval-mode fp32 inference on the GPU, torch otherwise."""
     C = x.shape[-1]
     if (SPLIT_GEMM and not ln.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
-            and x.is_contiguous() and len(ln.normalized_shape) == 1 and C % 4 == 0 and C <= 2048 and (ln.weight is None or ln.weight.dtype == torch.float32)):
+            and x.is_contiguous() and tuple(ln.normalized_shape) == (C,) and C % 4 == 0 and C <= 2048 and (ln.weight is None or ln.weight.dtype == torch.float32)):
         lib = _lib.load()
         with torch.cuda.device(x.device):
             y = torch.empty_like(x)
@@ -730,11 +732,13 @@ def relpos_attention(q: Tensor, k: Tensor, v: Tensor, p: Tensor, bias_u: Tensor,
             or any(t.stride(2) != 1 or t.stride(1) != ld or t.stride(0) != T * ld or t.data_ptr() % 16 or t.shape != q.shape for t in (q, k, v)) or ld % 4):
         return None
     pp = p.reshape(-1, C).contiguous()
-    if pp.shape[0] != 2 * T - 1:
+    if pp.shape[0] != 2 * T - 1 or pp.dtype != torch.float32 or tuple(bias_u.shape) != (heads, 64) or tuple(bias_v.shape) != (heads, 64):
         return None
     lib = _lib.load()
     pm = _mask_bytes(pad_mask)
     bu, bv = bias_u.detach().float().contiguous(), bias_v.detach().float().contiguous()      # named: must outlive the launch
+    # the kernel reads all three with 16-byte loads: a view at an odd storage offset gets an aligned copy instead of a C-side error
+    pp, bu, bv = (t if t.data_ptr() % 16 == 0 else t.clone() for t in (pp, bu, bv))
     with torch.cuda.device(q.device):
         out = torch.empty((B, T, C), dtype=torch.float32, device=q.device)
         _lib.check(lib.dsp_relpos_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), ld, _lib.ptr(pp), _lib.ptr(bu), _lib.ptr(bv), _lib.ptr(pm),

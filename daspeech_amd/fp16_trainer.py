@@ -76,7 +76,8 @@ class FP16FlatOptimizer:
         if self.clip_norm and nv > self.clip_norm:
             g.mul_(self.clip_norm / (nv + 1e-6))
         self.opt.step()
-        torch._foreach_copy_([p.data for p in self.params], self._mviews)                    # :146-170
+        with torch.no_grad():                                                                # :146-170 — into the parameters THEMSELVES, so that
+            torch._foreach_copy_(self.params, self._mviews)                                  # p._version advances (weight caches key on it)
         self.scaler.update()
         return True
 

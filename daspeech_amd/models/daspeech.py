@@ -115,9 +115,15 @@ def rel_positional_encoding(T: int, dim: int, device, dtype) -> Tensor:
     hit = _POS_TABLES.get(key)
     if hit is not None:
         return hit
-    if len(_POS_TABLES) >= 64:
-        _POS_TABLES.clear()
-    _POS_TABLES[key] = table = _rel_positional_encoding(T, dim, device, dtype)
+    per_dev = [k for k in _POS_TABLES if k[2] == key[2]]
+    if len(per_dev) >= 64:                                  # bounded per device: drop that device's oldest entries only
+        for k in per_dev[:32]:
+            del _POS_TABLES[k]
+    # built outside inference mode and without a graph: a table first requested under torch.inference_mode() would otherwise be an
+    # inference tensor and break a later training forward of the same length.  Shared by every model of the process: READ-ONLY.
+    with torch.inference_mode(False), torch.no_grad():
+        table = _rel_positional_encoding(T, dim, device, dtype)
+    _POS_TABLES[key] = table
     return table
 
 
@@ -422,15 +428,25 @@ class DAGDecoder(nn.Module):
 def _same_draws(seed: int, device, active: bool):
     """The reference runs both decoder passes of the GLAT forward under `torch_seed(rand_seed)` (s2t_conformer_dag.py:39-50,214-215): the
     same dropout masks in the glancing pass and in the training pass, the surrounding random stream untouched."""
-    if not active or device.type != "cuda":
+    if not active:
         yield
         return
-    state = torch.cuda.get_rng_state(device)
-    torch.cuda.manual_seed(seed)
-    try:
-        yield
-    finally:
-        torch.cuda.set_rng_state(state, device)
+    if device.type == "cuda":
+        # the generator of the MODEL's device (not the current one): state saved, seeded and restored on that device
+        state = torch.cuda.get_rng_state(device)
+        with torch.cuda.device(device):
+            torch.cuda.manual_seed(seed)
+        try:
+            yield
+        finally:
+            torch.cuda.set_rng_state(state, device)
+    else:
+        state = torch.random.get_rng_state()
+        torch.random.manual_seed(seed)
+        try:
+            yield
+        finally:
+            torch.random.set_rng_state(state)
 
 
 # ------------------------------------------------------------------------------------------------ models
