@@ -39,7 +39,9 @@ struct DXParams {
 // chunks of DX_MT x 16 rows.  32-row chunks (DX_MT = 2: a weight read serves 8 rows of a thread, the per-block overhead is paid half
 // as often) measured WORSE here except at the largest shape — C1 2.12 -> 2.32 ms, B=32 T=100 L=400 0.41 -> 0.45, C2 at TR=4095
 // 22.8 -> 22.1 — unlike the matrix-core kernel: the (+, max) product is VALU work proportional to the rows either way.
-constexpr int DX_BW = 64, DX_MT = 1, DX_TM = 16 * DX_MT, DX_WP = 68;      // weight tile [n = column][k = source], row pitch 68 floats: a thread reads its column's next four k as ONE ds_read_b128
+// r05: the 16-row kernel of r04 moves the whole transition matrix T/16 times — 68.7 GB per launch at C2 / TR = 4095, 5.5 TB/s over its 12.5 ms: it had
+// become HBM-bound.  DX_MT is a template parameter now; 32-row chunks halve that traffic (see launch_dag_dense_max for who gets which).
+constexpr int DX_BW = 64, DX_WP = 68;      // weight tile [n = column][k = source], row pitch 68 floats: a thread reads its column's next four k as ONE ds_read_b128
                                                                           // (16-lane groups land on 16 different 16-byte slots: 272-byte stride); [k][n] with pitch 65 took four ds_read_b32 per four k
 constexpr u32 DX_SPIN_LIMIT = 1u << 24;
 
@@ -61,8 +63,10 @@ __device__ __forceinline__ float dx_wave_max(float v) {
 __device__ __forceinline__ float dx_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dx_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <int DX_MT>
 __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
 {
+    constexpr int DX_TM = 16 * DX_MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_ticket;
     float* At = smem;                                  // [2][TM][64]   source rows (previous DP row of block V), row-major
@@ -123,7 +127,6 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
     for (int i = 0; i < 16; ++i) offW[i] = (unsigned)((16 * mg + i) * (TR - 1) + ub + min(n, L - 1 - ub) - 1);          // links[vb + k][ub + n - vb - k - 1]
     // (columns past the graph — the ragged last block — take the last real column's weights: in-bounds, and a column of the product
     //  depends on that column of the weights alone; rows without a source step likewise take the nearest real step's: dag_dp_dense_mfma.hip)
-    static_assert(DX_MT == 1, "the clamped row offsets below assume one row tile per chunk");
     for (int c = 0; c < nchunks; ++c) {
         const int tt0 = c * DX_TM;
         float acc[DX_MT][4];
@@ -156,7 +159,10 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
         }
         constexpr bool chunk_full = true;
         auto src_step = [&](int m) -> int { return min(max(tt0 + m - 1, 0), Tb - 1); };
-        const unsigned offS = (unsigned)(src_step(tid & (DX_TM - 1)) * NJ), offA = (unsigned)(src_step(tid >> 4) * L + 4 * (tid & 15));
+        const unsigned offS = (unsigned)(src_step(tid & (DX_TM - 1)) * NJ);
+        unsigned offA[DX_MT];                                  // (clamped per row tile: a row past T_b - 1 takes the last real step's operands)
+#pragma unroll
+        for (int mt = 0; mt < DX_MT; ++mt) offA[mt] = (unsigned)(src_step(16 * mt + (tid >> 4)) * L + 4 * (tid & 15));
         auto row_ok = [&](int m) -> bool { const int tt = tt0 + m; return tt >= 1 && tt < Tb; };
         if (U > 0) {
             const u32 want = p.tag_base + (u32)c + 1u;
@@ -207,7 +213,7 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
 #pragma unroll
                     for (int mt = 0; mt < DX_MT; ++mt)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dx_ld(Ov + offA + (unsigned)(16 * mt * L) + e);
+                        for (int e = 0; e < 4; ++e) st_a[s][mt][e] = dx_ld(Ov + offA[mt] + e);
                     return;
                 }
                 {
@@ -344,8 +350,8 @@ __device__ __forceinline__ void dag_dense_max_body(const DXParams& p)
 // Two builds of the same body: 256 VGPRs (31 spilled) so that two workgroups share a CU — the faster one when there are more workgroups
 // than CUs (C2 at TR = 4095: 22.8 -> 18.2 ms) — and the unconstrained one for launches that put at most one workgroup on a CU anyway
 // (C1: 2.18 vs 2.25 ms).
-__global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p) { dag_dense_max_body(p); }
-__global__ __launch_bounds__(256, 2) void dag_dense_max_kernel_occ2(DXParams p) { dag_dense_max_body(p); }
+template <int DX_MT> __global__ __launch_bounds__(256) void dag_dense_max_kernel(DXParams p) { dag_dense_max_body<DX_MT>(p); }
+template <int DX_MT> __global__ __launch_bounds__(256, 2) void dag_dense_max_kernel_occ2(DXParams p) { dag_dense_max_body<DX_MT>(p); }
 
 // K7: path[b][pos] = t along the chain of arg-max predecessors from (T_b-1, L_b-1), with the block trace of the max-DP (r03): the arg-max predecessor of cell (t, pos) lies in block V = btrace[t][pos], so a hop
 // evaluates 64 candidates — one wave, one gather of 64 transition weights — instead of every predecessor.  The rows the hops will
@@ -440,6 +446,9 @@ __global__ __launch_bounds__(256) void dag_dense_backtrace_blk_kernel(const floa
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
+static thread_local int g_dx_mt = 0;                   // diagnostic switch (dsp_dag_set_option "dx_mt"): 0 = auto, 1 / 2 = 16- / 32-row chunks
+void set_dx_mt(int v) { g_dx_mt = (v == 1 || v == 2) ? v : 0; }
+
 bool dense_max_supported(int L, int TR) { return TR > 64 && L >= 128 && (size_t)L * 4 <= 150 * 1024 && (long)L * TR < (1L << 31); }
 
 int launch_dag_dense_max(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
@@ -458,11 +467,17 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float*>(reinterpret_cast<char*>(area) + prog_bytes);
     p.btrace = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(area) + prog_bytes + s_bytes);
-    const size_t lds = (size_t)(2 * DX_TM * 64 + 2 * 64 * DX_WP + 2 * DX_TM + DX_TM * 64 + 64 + DX_TM * 64 + 4 + DX_TM * 64) * 4 + 64;
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    auto k = (B * NJ > ncu) ? dag_dense_max_kernel_occ2 : dag_dense_max_kernel;
+    // chunk height (r05 sweep, ms at 16 / 32 rows — C2 at TR = 4095: 13.5 / 12.4; B=8 L=4096 T=512: 5.95 / 6.17; C1: 1.61 / 1.81; B=16 L=1024 T=150:
+    // 0.70 / 0.79; B=32 L=400 T=100: 0.33 / 0.38; paths bit-identical): 32 rows only pay when the launch holds many rounds of workgroups — then
+    // half the passes over the transition matrix (68.7 -> 34.4 GB at C2) outweigh the longer (chunk, block) wavefront; dx_mt pins it
+    const bool big = B * NJ > ncu;
+    const int mt = g_dx_mt ? g_dx_mt : (B * NJ >= 6 * ncu) ? 2 : 1;
+    const int TM = 16 * mt;
+    const size_t lds = (size_t)(2 * TM * 64 + 2 * 64 * DX_WP + 2 * TM + TM * 64 + 64 + TM * 64 + 4 + TM * 64) * 4 + 64;
+    auto k = mt == 2 ? (big ? dag_dense_max_kernel_occ2<2> : dag_dense_max_kernel<2>) : (big ? dag_dense_max_kernel_occ2<1> : dag_dense_max_kernel<1>);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");

@@ -110,13 +110,16 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
     float* Xd = Sb + 2 * TM;                                   // [8] (of 2 TM)    diagonal block: exponent of each 8-column group of the previous row
     float* SCb = Xd + 2 * TM;                                  // [2][TM]          log2 of the factor a row's sums take before this block (0: none)
     float* SCf = SCb + 2 * TM;                                 // [2] (of 4)       1 if any row of the block rescales, else 0
-    float* Poff = SCf + 4;                                     // [TM][64]         off-diagonal sums of the tile
-    float* Roff = Poff + TM * 64;                              // [TM]             their reference exponents
+    // (r05) the tile's off-diagonal sums and the chunk's emissions are only alive between the products and the end of the diagonal phase,
+    // when nobody touches the A buffers: they live IN them (2 TM x 68 floats >= 2 x TM x 64), which is what lets a 64-row chunk keep two
+    // workgroups on a CU (72 KB instead of 105)
+    float* Poff = At;                                          // [TM][64]         off-diagonal sums of the tile            (aliases At)
+    float* Roff = SCf + 4;                                     // [TM]             their reference exponents
     float* FLo = Roff + TM;                                    // [TM]             first live column (global u) among the source blocks
     float* Vd = FLo + TM;                                      // [64]             diagonal block: previous row, 2^(a2 - X[group of 8])
     int* RDY = reinterpret_cast<int*>(Vd + 64);                // [4]              [0] broadcast slot of the readiness poll, [1] "the launch gave up"
     float* A2d = Vd + 68;                                      // [64]             diagonal block: previous row, exact log2 values
-    float* Md = A2d + 64;                                      // [TM][64]         diagonal block: the chunk's emissions
+    float* Md = At + TM * 64;                                  // [TM][64]         diagonal block: the chunk's emissions   (aliases At)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tl = tid, wg = wave;
     const int T = p.T, L = p.L, TR = p.TR, NJ = p.NJ;
@@ -265,7 +268,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
         // the first and a ragged last chunk took the predicated path (the training shapes, T <= 100: half of their chunks).
         constexpr bool chunk_full = true;
         auto src_step = [&](int m) -> int { return min(max(tt0 + m - 1, 0), Tb - 1); };
-        const unsigned offS0 = 8u * (unsigned)(src_step(tid & (TM - 1)) * NJ);              // (bytes, as offE)
+        const unsigned offS0 = 8u * (unsigned)(src_step(tid % TM) * NJ);              // (bytes, as offE)
         unsigned offS1[MT], offA[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -375,7 +378,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
                     return;
                 }
                 {
-                    const int m = tl & (TM - 1);
+                    const int m = tl % TM;
                     const unsigned si = row_ok(m) ? (unsigned)((tt0 + m - 1) * NJ + V) : 0u;
                     st_s[s] = dm_ld(&S[si].x); st_f[s] = dm_ld(&S[si].y);
                 }
@@ -397,7 +400,7 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             };
             auto stage_live = [&](auto SC) -> bool {                     // lanes 0..15 of every wave hold the 16 rows: same vote in all waves
                 constexpr int s = decltype(SC)::value;
-                return __any(row_ok(tl & (TM - 1)) && st_s[s] != DM_SENT);
+                return __any(row_ok(tl % TM) && st_s[s] != DM_SENT);
             };
             // convert a register stage into LDS buffer nb: exponents, A = 2^(a2 - s), E = 2^(weight)
             auto commit = [&](auto SC, int V, int nb) {
@@ -632,7 +635,9 @@ __device__ __forceinline__ void dense_mfma_body(const DMParams& p, char* smem_ra
             if (have) mfma_issue(cur);
         }
         stamp(pf_gemm);
-        // ---- hand the tile's off-diagonal sums and the chunk's emissions to the diagonal wave
+        // ---- hand the tile's off-diagonal sums and the chunk's emissions to the diagonal wave (through the A buffers: every wave's last
+        // fragment reads of them must be done first)
+        __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -915,7 +920,7 @@ template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
 {
     constexpr int TM = DM_TM * MT;
-    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + TM * 64) * 4 + 64;
+    const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
     auto k = dag_dense_mfma_kernel<D, MT>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
@@ -966,9 +971,18 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     // every shape of the r02 sweep on the pipelined kernel (C1 1.53 / 1.53 ms, B=16 T=150 L=1024 0.79 / 0.71, C2 at TR = 4095 38.6 / 31.2
     // for 16- / 32-row chunks; the pre-pipeline kernel had it the other way round: its blocks cost a memory round trip each)
     const int mt = g_dm_mt ? g_dm_mt : 2;
+    if (mt == 14) return then_standby(launch_dm<1, 4>(p, nwg, st));    // (64-row chunks, one workgroup per CU: comparison build)
+    if (mt == 3 || mt == 4) {                            // 48- / 64-row chunks, two workgroups per CU: 2/3 / half the passes over the transition matrix
+        const int TM = DM_TM * mt;
+        const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
+        auto k = mt == 3 ? dag_dense_mfma_kernel_occ2<1, 3> : dag_dense_mfma_kernel_occ2<1, 4>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
+        return then_standby(check_launch("dag_loss_fwd(dense mfma)"));
+    }
     if (mt >= 2 && g_dm_depth != 9) {                    // default: 32-row chunks, one stage, two workgroups per CU
         constexpr int TM = DM_TM * 2;
-        const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + TM * 64 + 2 * TM + 68 + 64 + TM * 64) * 4 + 64;
+        const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
         auto k = dag_dense_mfma_kernel_occ2<1, 2>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
