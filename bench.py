@@ -650,6 +650,15 @@ def main():
                                                  "achieved_Gpairs_per_s": fl / 4.0 / (pf["best_alignment"] * 1e-3) / 1e9}
             except Exception as e:      # noqa: a leg of its own, the headline does not depend on it
                 tr_full = {"error": repr(e)[:200]}
+        # 32 < TR <= 64 is served by the older banded kernels (dag_dp_banded / strip2): one number for that window too
+        tr64 = None
+        try:
+            p64, _, i64 = run_dag_ops(ctx, args.dag_batch, args.graph_len, args.tgt_len, args.vocab, 64, 3, 1, 55 + rank)
+            b64 = 2.0 * (2 * args.dag_batch * args.tgt_len * args.graph_len * 4.0 + args.dag_batch * args.graph_len * 64 * 4.0)
+            tr64 = {"workload": f"C2 with TR=64 (the banded kernels between the TR<=32 strips and the dense-window matrix-core DP)", "phases_ms": p64,
+                    "dag_loss_fwd_bwd_ms": p64["dag_fwd"] + p64["dag_bwd"], "dag_fwd_frac_of_hbm_peak": b64 / (p64["dag_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, **i64}
+        except Exception as e:      # noqa
+            tr64 = {"error": repr(e)[:200]}
         result = {**base, "value": s2st["value"], "steps": s2st["steps"], "warmup": s2st["warmup"], "ms_per_step": s2st["ms_per_step"],
                   "dtype": "f32" if args.amp == "none" else args.amp,
                   "dag_loss_fwd_bwd_ms_per_batch": dag["dag_loss_fwd_bwd_ms"],
@@ -667,6 +676,7 @@ def main():
                                            "vocoder_roofline": fast.get("roofline")}
         if tr_full is not None:
             result["dag_tr%d" % (args.graph_len - 1)] = tr_full
+        result["dag_tr64"] = tr64
         # C3 and C5 in the same driver-timed line (short legs; `--workload s2tt|train` run them alone at the contract's K)
         if not args.no_extra_legs:
             for key, wl, nb in (("c3_s2tt", "s2tt", 64), ("c5_train", "train", 32)):

@@ -264,6 +264,283 @@ __global__ __launch_bounds__(256) void extract_links_bwd_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// r05 — windows whose score image does not fit LDS (TR above ~1100 at 8 heads x 64: the README's --max-transition-length 99999 on graphs
+// longer than ~1100 vertices, up to BASELINE's L = 4096).  Same arithmetic, but the partner range is walked in TILES of TW slots:
+//   forward:   pass 1 streams every successor once and keeps an online (max, sum) per (vertex, head) — the soft-max state; pass 2
+//              recomputes the scores tile by tile into a [IT][TW][H] image and emits the tile's links (the dot products run twice,
+//              nothing of size TR is ever held on chip);
+//   backward:  (dq, dgate) pass 1 accumulates SA = sum_d A the same streaming way, pass 2 builds ds per tile and contracts it with the
+//              tile's partner rows into accumulators that live across the tiles; (dk) needs no pre-pass (its soft-max rows are the
+//              partners, whose state the first launch left in `stats` / `dgate`).
+// With TW >= the partner range these kernels compute exactly what the one-image kernels above compute (tests force small tiles on small
+// graphs and compare the two, and both with torch autograd).
+template <int CK4>
+__device__ __forceinline__ float xl_dot(const float* __restrict__ qrow, const float4 (&kv)[CK4])
+{
+    const float4* qr = reinterpret_cast<const float4*>(qrow);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CK4; ++c) {
+        const float4 qv = qr[c];
+        a0 = fmaf(qv.x, kv[c].x, a0); a1 = fmaf(qv.y, kv[c].y, a1); a2 = fmaf(qv.z, kv[c].z, a2); a3 = fmaf(qv.w, kv[c].w, a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <int CK4>
+__global__ __launch_bounds__(256) void extract_links_tiled_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ log_gates,
+    const int64_t* __restrict__ out_len, const float* __restrict__ dist_bias, float* __restrict__ links,
+    float* __restrict__ stats, int B, int L, int TR, float scale, int TW)
+{
+    extern __shared__ __attribute__((aligned(16))) float xl_smem[];
+    constexpr int CK = CK4 * 4;
+    float* qs = xl_smem;                       // [IT][H][CK]
+    float* sc = qs + XL_IT * XL_H * CK;        // [IT][TW][H]   scores of the current tile, slot = successor - tile start
+    float* red = sc + (size_t)XL_IT * TW * XL_H;    // [IT][H][2]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, d0 = tid & 31, h = tid >> 5;
+    const int Lb = (int)out_len[b];
+    const size_t rowstride = (size_t)XL_H * CK;
+    const int i0 = blockIdx.x * XL_IT;
+    const int nit = min(XL_IT, L - i0);
+    for (int e = tid; e < nit * XL_H * CK; e += 256) qs[e] = q[((size_t)b * L + i0) * rowstride + e];
+    __syncthreads();
+    const int jend = min(min(L, Lb), i0 + nit + TR);
+    // score of (owner ii, successor j) — the SAME expression in both passes, so pass 2 reproduces pass 1's values bit for bit
+    auto score = [&](int ii, int j, const float4 (&kv)[CK4], float& sv) -> bool {
+        const int d = j - (i0 + ii) - 1;
+        const float dot = xl_dot<CK4>(qs + (ii * XL_H + h) * CK, kv);
+        if (!(ii < nit && d >= 0 && d < TR)) return false;
+        sv = dot * scale;
+        if (dist_bias) sv += dist_bias[d];
+        return true;
+    };
+    // ---- pass 1: online soft-max state per (owner, head) over all successors
+    float m[XL_IT], sm[XL_IT];
+#pragma unroll
+    for (int ii = 0; ii < XL_IT; ++ii) { m[ii] = NEG_INF; sm[ii] = 0.f; }
+    for (int jc = i0 + 1; jc < jend; jc += 32) {
+        const int j = jc + d0;
+        const bool live = j < jend;
+        float4 kv[CK4];
+        const float4* kr = reinterpret_cast<const float4*>(k + ((size_t)b * L + (live ? j : jc)) * rowstride + (size_t)h * CK);
+#pragma unroll
+        for (int c = 0; c < CK4; ++c) kv[c] = kr[c];
+#pragma unroll
+        for (int ii = 0; ii < XL_IT; ++ii) {
+            float sv;
+            if (score(ii, j, kv, sv) && live) {
+                if (sv > m[ii]) { sm[ii] = sm[ii] * __expf(m[ii] - sv) + 1.f; m[ii] = sv; }       // (m = -inf: exp(-inf) = 0)
+                else sm[ii] += __expf(sv - m[ii]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < XL_IT; ++ii) {
+        float M = m[ii];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 32));
+        float S = (m[ii] == NEG_INF) ? 0.f : sm[ii] * __expf(m[ii] - M);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) S += __shfl_xor(S, o, 32);
+        if (d0 == 0) {
+            const float ls = (M == NEG_INF) ? 0.f : __logf(S);
+            red[(ii * XL_H + h) * 2] = M; red[(ii * XL_H + h) * 2 + 1] = ls;
+            if (stats && ii < nit) { float* st = stats + (((size_t)b * L + i0 + ii) * XL_H + h) * 2; st[0] = M; st[1] = ls; }
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: tiles of successors
+    for (int jt = i0 + 1; jt < jend; jt += TW) {
+        const int jte = min(jt + TW, jend);
+        for (int e = tid; e < XL_IT * TW * XL_H; e += 256) sc[e] = NEG_INF;
+        __syncthreads();
+        for (int jc = jt; jc < jte; jc += 32) {
+            const int j = jc + d0;
+            const bool live = j < jte;
+            float4 kv[CK4];
+            const float4* kr = reinterpret_cast<const float4*>(k + ((size_t)b * L + (live ? j : jc)) * rowstride + (size_t)h * CK);
+#pragma unroll
+            for (int c = 0; c < CK4; ++c) kv[c] = kr[c];
+#pragma unroll
+            for (int ii = 0; ii < XL_IT; ++ii) {
+                float sv;
+                if (score(ii, j, kv, sv) && live) sc[((size_t)ii * TW + (j - jt)) * XL_H + h] = sv;
+            }
+        }
+        __syncthreads();
+        for (int ii = 0; ii < nit; ++ii) {
+            const int i = i0 + ii;
+            float gate[XL_H], mh[XL_H], lh[XL_H];
+#pragma unroll
+            for (int hh = 0; hh < XL_H; ++hh) {
+                gate[hh] = log_gates[((size_t)b * L + i) * XL_H + hh]; mh[hh] = red[(ii * XL_H + hh) * 2]; lh[hh] = red[(ii * XL_H + hh) * 2 + 1];
+            }
+            for (int js = tid; js < jte - jt; js += 256) {
+                const int d = jt + js - i - 1;
+                if (d < 0 || d >= TR) continue;
+                float v[XL_H], m2 = NEG_INF;
+#pragma unroll
+                for (int hh = 0; hh < XL_H; ++hh) {
+                    const float sx = sc[((size_t)ii * TW + js) * XL_H + hh];
+                    v[hh] = (sx == NEG_INF) ? NEG_INF : ((sx - mh[hh]) - lh[hh]) + gate[hh];
+                    m2 = fmaxf(m2, v[hh]);
+                }
+                float r = NEG_INF;
+                if (m2 != NEG_INF) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int hh = 0; hh < XL_H; ++hh) acc += __expf(v[hh] - m2);
+                    r = m2 + __logf(acc);
+                }
+                links[((size_t)b * L + i) * TR + d] = r;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- slots without a successor inside the graph
+    for (int ii = 0; ii < nit; ++ii) {
+        const int i = i0 + ii;
+        for (int d = max(0, jend - i - 1) + tid; d < TR; d += 256) links[((size_t)b * L + i) * TR + d] = NEG_INF;
+    }
+}
+
+template <int CK4, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void extract_links_bwd_tiled_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ log_gates,
+    const int64_t* __restrict__ out_len, const float* __restrict__ dist_bias, const float* __restrict__ links,
+    const float* __restrict__ G, const float* __restrict__ stats, float* __restrict__ dgate,
+    float* __restrict__ dout, int B, int L, int TR, float scale, int TW)
+{
+    extern __shared__ __attribute__((aligned(16))) float xl_smem[];
+    constexpr int CK = CK4 * 4;
+    float* own = xl_smem;                          // [IT][H][CK]
+    float* sc = own + XL_IT * XL_H * CK;           // [IT][TW][H]   ds of the current tile, slot = partner - tile start
+    float* red = sc + (size_t)XL_IT * TW * XL_H;   // [IT][H]       SA of the owner rows (first launch)
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, d0 = tid & 31, h = tid >> 5;
+    const int Lb = min((int)out_len[b], L);
+    const size_t rowstride = (size_t)XL_H * CK;
+    const int o0 = blockIdx.x * XL_IT;
+    const int nit = min(XL_IT, L - o0);
+    const float* OWN = TRANSPOSED ? k : q;
+    const float* PAR = TRANSPOSED ? q : k;
+    for (int e = tid; e < nit * XL_H * CK; e += 256) own[e] = OWN[((size_t)b * L + o0) * rowstride + e];
+    __syncthreads();
+    const int pbeg = TRANSPOSED ? max(0, o0 - TR) : (o0 + 1);
+    const int pend = TRANSPOSED ? min(o0 + nit - 1, Lb) : min(Lb, o0 + nit + TR);
+    // soft-max state of the owner rows (dq launch): per (owner, head), this thread's head
+    float o_mx[XL_IT], o_ls[XL_IT], o_g[XL_IT];
+    if (!TRANSPOSED) {
+#pragma unroll
+        for (int oo = 0; oo < XL_IT; ++oo) {
+            const size_t so = ((size_t)b * L + min(o0 + oo, L - 1)) * XL_H + h;
+            o_mx[oo] = stats[2 * so]; o_ls[oo] = stats[2 * so + 1]; o_g[oo] = log_gates[so];
+        }
+        // ---- pass 1: SA[owner][head] = sum_d A
+        float sa[XL_IT];
+#pragma unroll
+        for (int oo = 0; oo < XL_IT; ++oo) sa[oo] = 0.f;
+        for (int pc = pbeg; pc < pend; pc += 32) {
+            const int pp = pc + d0;
+            const bool live = pp < pend;
+            float4 pv[CK4];
+            const float4* pr = reinterpret_cast<const float4*>(PAR + ((size_t)b * L + (live ? pp : pc)) * rowstride + (size_t)h * CK);
+#pragma unroll
+            for (int c = 0; c < CK4; ++c) pv[c] = pr[c];
+#pragma unroll
+            for (int oo = 0; oo < XL_IT; ++oo) {
+                const int o = o0 + oo, d = pp - o - 1;
+                const float dot = xl_dot<CK4>(own + (oo * XL_H + h) * CK, pv);
+                if (live && oo < nit && d >= 0 && d < TR && o_mx[oo] != NEG_INF) {
+                    float sv = dot * scale;
+                    if (dist_bias) sv += dist_bias[d];
+                    const size_t lo = ((size_t)b * L + o) * TR + d;
+                    const float lk = links[lo];
+                    if (lk != NEG_INF) sa[oo] += G[lo] * __expf(((sv - o_mx[oo]) - o_ls[oo]) + o_g[oo] - lk);
+                }
+            }
+        }
+#pragma unroll
+        for (int oo = 0; oo < XL_IT; ++oo) {
+            float v = sa[oo];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 32);
+            if (d0 == 0) { red[oo * XL_H + h] = v; if (oo < nit) dgate[((size_t)b * L + o0 + oo) * XL_H + h] = v; }
+        }
+        __syncthreads();
+    }
+    const int c4 = tid & (CK4 - 1), hh = (tid / CK4) % XL_H, op = tid / (CK4 * XL_H);
+    constexpr int NOP = 256 / (CK4 * XL_H);
+    constexpr int OPG = XL_IT / NOP;
+    float4 acc[OPG];
+#pragma unroll
+    for (int x = 0; x < OPG; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pt = pbeg; pt < pend; pt += TW) {
+        const int pte = min(pt + TW, pend);
+        for (int e = tid; e < XL_IT * TW * XL_H; e += 256) sc[e] = 0.f;
+        __syncthreads();
+        for (int pc = pt; pc < pte; pc += 32) {
+            const int pp = pc + d0;
+            const bool live = pp < pte;
+            float4 pv[CK4];
+            const float4* pr = reinterpret_cast<const float4*>(PAR + ((size_t)b * L + (live ? pp : pc)) * rowstride + (size_t)h * CK);
+#pragma unroll
+            for (int c = 0; c < CK4; ++c) pv[c] = pr[c];
+            float st_mx = 0.f, st_ls = 0.f, st_g = 0.f, st_sa = 0.f;
+            if (TRANSPOSED && live) {
+                const size_t so = ((size_t)b * L + pp) * XL_H + h;
+                st_mx = stats[2 * so]; st_ls = stats[2 * so + 1]; st_g = log_gates[so]; st_sa = dgate[so];
+            }
+#pragma unroll
+            for (int oo = 0; oo < XL_IT; ++oo) {
+                const int o = o0 + oo;
+                const int d = TRANSPOSED ? (o - pp - 1) : (pp - o - 1);
+                const float dot = xl_dot<CK4>(own + (oo * XL_H + h) * CK, pv);
+                if (live && oo < nit && d >= 0 && d < TR && (!TRANSPOSED || o < Lb)) {
+                    float sv = dot * scale;
+                    if (dist_bias) sv += dist_bias[d];
+                    const float mxv = TRANSPOSED ? st_mx : o_mx[oo], lsv = TRANSPOSED ? st_ls : o_ls[oo], gv = TRANSPOSED ? st_g : o_g[oo];
+                    const float sav = TRANSPOSED ? st_sa : red[oo * XL_H + h];
+                    const size_t lo = TRANSPOSED ? (((size_t)b * L + pp) * TR + d) : (((size_t)b * L + o) * TR + d);
+                    float dsv = 0.f;
+                    if (mxv != NEG_INF) {
+                        const float lk = links[lo], ls = (sv - mxv) - lsv;
+                        const float A = (lk == NEG_INF) ? 0.f : G[lo] * __expf(ls + gv - lk);
+                        dsv = A - __expf(ls) * sav;
+                    }
+                    sc[((size_t)oo * TW + (pp - pt)) * XL_H + h] = dsv;
+                }
+            }
+        }
+        __syncthreads();
+        for (int pp = pt; pp < pte; ++pp) {
+            const float4 pv = *reinterpret_cast<const float4*>(PAR + ((size_t)b * L + pp) * rowstride + (size_t)hh * CK + c4 * 4);
+#pragma unroll
+            for (int x = 0; x < OPG; ++x) {
+                const int oo = op * OPG + x;
+                const int d = TRANSPOSED ? (o0 + oo - pp - 1) : (pp - o0 - oo - 1);
+                const float dsv = (d >= 0 && d < TR) ? sc[((size_t)oo * TW + (pp - pt)) * XL_H + hh] : 0.f;
+                acc[x].x = fmaf(dsv, pv.x, acc[x].x); acc[x].y = fmaf(dsv, pv.y, acc[x].y);
+                acc[x].z = fmaf(dsv, pv.z, acc[x].z); acc[x].w = fmaf(dsv, pv.w, acc[x].w);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < OPG; ++x) {
+        const int oo = op * OPG + x;
+        if (oo < nit)
+            *reinterpret_cast<float4*>(dout + ((size_t)b * L + o0 + oo) * rowstride + (size_t)hh * CK + c4 * 4) =
+                make_float4(acc[x].x * scale, acc[x].y * scale, acc[x].z * scale, acc[x].w * scale);
+    }
+}
+
+static int g_xl_tile = 0;          // dsp_dag_set_option("xl_tile", n): n > 0 forces the tiled kernels with TW = n (tests); 0 = only where the image does not fit
+void set_xl_tile(int v) { g_xl_tile = v > 0 ? ((v + 31) / 32) * 32 : 0; }
 }  // namespace dsp
 
 static int xl_check(const char* fn, const void* q, const void* k, const void* g, const void* ol, const void* links, int B, int L, int H, int CK, int TR, size_t* lds)
@@ -274,10 +551,17 @@ static int xl_check(const char* fn, const void* q, const void* k, const void* g,
     if (B > 0 && (!q || !k || !g || !ol || !links)) { set_error("%s: null pointer", fn); return DSP_EINVAL; }
     if ((((uintptr_t)q) | ((uintptr_t)k)) & 15) { set_error("%s: q / k must be 16-byte aligned", fn); return DSP_EINVAL; }
     *lds = ((size_t)XL_IT * XL_H * CK + (size_t)XL_IT * ((TR + 31) / 32) * 32 * XL_H + 2 * XL_IT * XL_H) * sizeof(float);
-    if (*lds > 150 * 1024) { set_error("%s: TR=%d too large for the score image", fn, TR); return DSP_EINVAL; }
     if (!(CK == 32 || CK == 64 || CK == 128)) { set_error("%s: head width %d (32, 64 or 128)", fn, CK); return DSP_EINVAL; }
     return DSP_OK;
 }
+
+// tile width of the tiled kernels for this call, 0 = the one-image kernels serve it
+static int xl_tile_width(size_t lds_one_image)
+{
+    if (dsp::g_xl_tile > 0) return dsp::g_xl_tile;
+    return lds_one_image > 150 * 1024 ? 512 : 0;              // 512 slots: a 64 KB image, two workgroups per CU
+}
+static size_t xl_tiled_lds(int CK, int TW) { return ((size_t)dsp::XL_IT * dsp::XL_H * CK + (size_t)dsp::XL_IT * TW * dsp::XL_H + 2 * dsp::XL_IT * dsp::XL_H) * sizeof(float); }
 
 extern "C" int dsp_extract_links_train(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
                                        const float* dist_bias, float* links, float* stats, int B, int L, int H, int CK, int TR, float scale,
@@ -289,6 +573,13 @@ extern "C" int dsp_extract_links_train(const float* q, const float* k, const flo
     if (rc) return rc;
     if (B == 0) return DSP_OK;
     if (!stats) { set_error("extract_links_train: null stats"); return DSP_EINVAL; }
+    if (const int TW = xl_tile_width(lds)) {
+        const size_t l2 = xl_tiled_lds(CK, TW);
+        auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
+        if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale, TW);
+        return check_launch("extract_links_train(tiled)");
+    }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
@@ -328,6 +619,24 @@ extern "C" int dsp_extract_links_bwd(const float* q, const float* k, const float
     if (!grad_links || !stats || !grad_q || !grad_k || !grad_log_gates) { set_error("extract_links_bwd: null pointer"); return DSP_EINVAL; }
     if ((((uintptr_t)grad_q) | ((uintptr_t)grad_k)) & 15) { set_error("extract_links_bwd: grad_q / grad_k must be 16-byte aligned"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    if (const int TW = xl_tile_width(lds)) {
+        const size_t l2 = xl_tiled_lds(CK, TW);
+        const dim3 grid((L + XL_IT - 1) / XL_IT, B);
+        auto go = [&](auto ka, auto kb) -> int {
+            if (l2 > 48 * 1024) {
+                (void)hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            }
+            hipLaunchKernelGGL(ka, grid, dim3(256), l2, st, q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_log_gates, grad_q, B, L, TR, scale, TW);
+            int r = check_launch("extract_links_bwd(tiled: dq, dgate)");
+            if (r) return r;
+            hipLaunchKernelGGL(kb, grid, dim3(256), l2, st, q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_log_gates, grad_k, B, L, TR, scale, TW);
+            return check_launch("extract_links_bwd(tiled: dk)");
+        };
+        if (CK == 64) return go(extract_links_bwd_tiled_kernel<16, false>, extract_links_bwd_tiled_kernel<16, true>);
+        if (CK == 32) return go(extract_links_bwd_tiled_kernel<8, false>, extract_links_bwd_tiled_kernel<8, true>);
+        return go(extract_links_bwd_tiled_kernel<32, false>, extract_links_bwd_tiled_kernel<32, true>);
+    }
     if (CK == 64) return xl_bwd_launch<16>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
     if (CK == 32) return xl_bwd_launch<8>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
     return xl_bwd_launch<32>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
@@ -344,8 +653,14 @@ extern "C" int dsp_extract_links(const float* q, const float* k, const float* lo
     if (!q || !k || !log_gates || !out_len || !links) { set_error("extract_links: null pointer"); return DSP_EINVAL; }
     if ((((uintptr_t)q) | ((uintptr_t)k)) & 15) { set_error("extract_links: q / k must be 16-byte aligned"); return DSP_EINVAL; }
     const size_t lds = ((size_t)XL_IT * XL_H * CK + (size_t)XL_IT * ((TR + 31) / 32) * 32 * XL_H + 2 * XL_IT * XL_H) * sizeof(float);
-    if (lds > 150 * 1024) { set_error("extract_links: TR=%d too large for the score image", TR); return DSP_EINVAL; }
     if (!(CK == 32 || CK == 64 || CK == 128)) { set_error("extract_links: head width %d (32, 64 or 128)", CK); return DSP_EINVAL; }
+    if (const int TW = xl_tile_width(lds)) {
+        const size_t l2 = xl_tiled_lds(CK, TW);
+        auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
+        if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale, TW);
+        return check_launch("extract_links(tiled)");
+    }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),

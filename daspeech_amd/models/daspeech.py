@@ -394,11 +394,10 @@ class DAGDecoder(nn.Module):
         k = decode_ops.linear(fp, self.key_linear, lens=lens).view(B, L, h, ck).float()
         log_gates = F.log_softmax(decode_ops.linear(fp, self.gate_linear), dim=-1, dtype=torch.float)                   # [B,L,h]
         TR = min(a.max_transition_length, L - 1)
-        # the fused kernels keep one tile's scores in LDS: XL_IT = 4 rows x (ck + TR rounded up to 32 + 2) x 8 heads floats <= 150 KB
-        # (csrc/extract_links.hip xl_check) — TR up to ~1100 at ck = 64, i.e. every graph the README's limits produce; wider windows take
-        # the torch band formulation below instead of raising
-        fits_lds = 4 * 8 * (ck + (TR + 31) // 32 * 32 + 2) * 4 <= 150 * 1024
-        if feats.is_cuda and h == 8 and ck in (32, 64, 128) and TR >= 1 and self.fused_links and fits_lds \
+        # the fused kernels keep one tile's scores in LDS: up to TR ~ 1100 (ck = 64) the whole window is ONE tile; wider windows — the README's
+        # --max-transition-length 99999 on graphs up to BASELINE's L = 4096 — are walked in 512-slot tiles (r05: extract_links_tiled_kernel,
+        # forward and backward), so every window stays on the HIP path
+        if feats.is_cuda and h == 8 and ck in (32, 64, 128) and TR >= 1 and self.fused_links \
                 and not (dist_bias is not None and dist_bias.requires_grad and torch.is_grad_enabled()):
             # the band only, fused (csrc/extract_links.hip) — no [B,L,L,h] content tensor, no gather; under autograd the backward
             # recomputes the scores tile by tile from q, k and [B,L,h] soft-max state (dsp_extract_links_bwd)

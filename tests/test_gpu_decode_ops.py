@@ -405,3 +405,96 @@ def test_fused_relpos_attention_matches_torch_formulation(shape):
         finally:
             decode_ops.set_split_gemm(old)
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+def _links_case(B, L, CK, TR, lens, seed):
+    torch.manual_seed(seed)
+    H = 8
+    olen = torch.tensor(lens, device="cuda")
+    q0 = torch.randn(B, L, H, CK, device="cuda") * 0.5; k0 = torch.randn(B, L, H, CK, device="cuda") * 0.5
+    g0 = torch.log_softmax(torch.randn(B, L, H, device="cuda"), -1)
+    w = torch.randn(B, L, TR, device="cuda")
+    bias = -0.02 * torch.arange(TR, device="cuda").float()
+    return olen, q0, k0, g0, w, bias
+
+
+def _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias):
+    from daspeech_amd import decode_ops
+    q, k, lg = q0.clone().requires_grad_(), k0.clone().requires_grad_(), g0.clone().requires_grad_()
+    links = decode_ops.extract_links_autograd(q, k, lg, olen, TR, bias)
+    fin = torch.isfinite(links)
+    (links.masked_fill(~fin, 0.0) * w).sum().backward()
+    with torch.no_grad():
+        inf_links = decode_ops.extract_links(q0, k0, g0, olen, TR, bias)
+    return links.detach(), q.grad, k.grad, lg.grad, inf_links
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,CK,TR,lens,tile", [(2, 150, 64, 149, [150, 97], 32), (2, 150, 64, 149, [150, 97], 64), (3, 200, 32, 70, [200, 131, 3], 96),
+                                                (2, 90, 128, 89, [90, 41], 32), (2, 300, 64, 299, [300, 1], 128)])
+def test_tiled_extract_links_equal_the_one_image_kernels(B, L, CK, TR, lens, tile):
+    """r05: dsp_extract_links / _train / _bwd with the window walked in tiles (forced through the xl_tile option on graphs the one-image kernels
+    serve too): links, soft-max state and all three gradients against the one-image kernels — same arithmetic, different summation order of
+    the soft-max denominators (online vs one pass): <= 2e-6 relative."""
+    from daspeech_amd import _lib
+    olen, q0, k0, g0, w, bias = _links_case(B, L, CK, TR, lens, 5)
+    try:
+        _lib.set_option("xl_tile", 0)
+        ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        _lib.set_option("xl_tile", tile)
+        got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+    finally:
+        _lib.set_option("xl_tile", 0)
+    for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
+        assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
+        f = torch.isfinite(b)
+        sc = max(1.0, float(b[f].abs().max()))
+        assert float((a[f] - b[f]).abs().max()) <= 4e-6 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
+
+
+@pytest.mark.gpu
+def test_extract_links_wide_window_stays_on_the_hip_path():
+    """A window the one-image kernels cannot hold (L = 1500, TR = 1499: a 768 KB score image) — r04 sent it to the torch band formulation.
+    Forward and backward through the model's own dispatch against that formulation; the tiled kernels must be the ones that ran."""
+    from daspeech_amd.models.daspeech import DAGDecoder, DEFAULT_ARGS, PAD, BOS, EOS, UNK
+    from types import SimpleNamespace
+    torch.manual_seed(4)
+    dev = torch.device("cuda")
+    a = SimpleNamespace(**{**DEFAULT_ARGS, "max_transition_length": 99999, "decoder_layers": 0, "max_target_positions": 2048})
+    dec = DAGDecoder(a).to(dev).train()
+    B, L = 2, 1500
+    lens = [1500, 1203]
+    prev = torch.full((B, L), PAD, dtype=torch.long, device=dev)
+    for b, n in enumerate(lens):
+        prev[b, :n] = UNK; prev[b, 0] = BOS; prev[b, n - 1] = EOS
+    feats0 = torch.randn(B, L, a.decoder_embed_dim, device=dev)
+    res = {}
+    wgt = None
+    import daspeech_amd.decode_ops as dops
+    calls = []
+    orig = dops.extract_links_autograd
+    dops.extract_links_autograd = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
+    try:
+        for fused in (True, False):
+            dec.fused_links = fused
+            dec.zero_grad(set_to_none=True)
+            feats = feats0.clone().requires_grad_()
+            links = dec.extract_links(feats, prev)
+            if wgt is None:
+                wgt = torch.randn_like(links) / L
+            fin = torch.isfinite(links)
+            ((links.masked_fill(~fin, 0.0) * wgt).sum()).backward()
+            res[fused] = (links.detach(), feats.grad.detach())
+            del links, feats
+            torch.cuda.empty_cache()
+    finally:
+        dops.extract_links_autograd = orig
+    assert calls == [1], "the fused path did not take this window"
+    (l1, g1), (l0, g0) = res[True], res[False]
+    assert l1.shape == (B, L, L - 1) and torch.equal(torch.isneginf(l1), torch.isneginf(l0))
+    f = torch.isfinite(l0)
+    torch.testing.assert_close(l1[f], l0[f], rtol=1e-5, atol=3e-5)
+    sc = max(1.0, float(g0.abs().max()))
+    assert float((g1 - g0).abs().max()) <= 2e-5 * sc + 2e-5, float((g1 - g0).abs().max())
+    rows = f.any(-1)
+    torch.testing.assert_close(torch.logsumexp(l1[rows], -1), torch.zeros_like(l1[rows][:, 0]), rtol=0, atol=5e-5)

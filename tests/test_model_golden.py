@@ -87,8 +87,16 @@ def test_s2st_end_to_end_vs_reference_generator():
         fin = torch.isfinite(ls_ref)
         torch.testing.assert_close(ls[fin], ls_ref[fin], rtol=2e-4, atol=5e-4)
         valid = prev.ne(m.pad).cpu()
-        agree = (logits.argmax(-1).cpu() == torch.from_numpy(g["vertex_argmax"]))[valid].float().mean()
-        assert agree > 0.995, float(agree)                                         # (near-ties may flip on another device; the path must not)
+        # every vertex's arg-max token is the reference's — except where the reference's token is a NEAR-TIE of this device's logits (its
+        # logit within 1e-3 of the maximum: twice the logits bound above); such vertices exist (random weights, 512-way soft-max) and may
+        # flip between devices, the decoded path below must not
+        ref_am = torch.from_numpy(g["vertex_argmax"])
+        lc = logits.float().cpu()
+        top = lc.max(-1).values
+        at_ref = lc.gather(-1, ref_am.unsqueeze(-1)).squeeze(-1)
+        differs = (lc.argmax(-1) != ref_am) & valid
+        assert bool(((top - at_ref)[differs] <= 1e-3).all()), float((top - at_ref)[differs].max())
+        assert int(differs.sum()) <= max(1, int(0.005 * int(valid.sum()))), int(differs.sum())
         gen = S2SNATGenerator(None, None, None)
         out = gen.generate(m, {"net_input": {"src_tokens": src, "src_lengths": lens}}, generate_waveform=False)
     ref_tok = g["tokens"]
@@ -100,8 +108,13 @@ def test_s2st_end_to_end_vs_reference_generator():
         mel_ref = g[f"mel{b}"]
         mel = o["feature"].float().cpu().numpy()
         assert mel.shape == mel_ref.shape, (b, mel.shape, mel_ref.shape)
-        scale = np.abs(mel_ref).max()
-        assert np.abs(mel - mel_ref).max() <= 1e-4 * scale + 1e-5, (b, np.abs(mel - mel_ref).max(), scale)
+        # north_star: <= 1e-4 relative on mel-spectrogram FRAMES — per frame, relative to that frame's own largest bin, plus an absolute
+        # floor of 2e-5 (the fp32 round-off of the out_proj GEMM's 256-term sums at the mel scale of ~1-10: a frame whose bins all sit near
+        # zero would otherwise be held to less than one ulp of the layers that produced it)
+        err_f = np.abs(mel - mel_ref).max(axis=1)
+        ref_f = np.abs(mel_ref).max(axis=1)
+        worst = int(np.argmax(err_f - 1e-4 * ref_f))
+        assert (err_f <= 1e-4 * ref_f + 2e-5).all(), (b, worst, float(err_f[worst]), float(ref_f[worst]))
 
 
 def _seeded_product_model(man, seed):
