@@ -585,6 +585,11 @@ def main():
     args = parse()
     maybe_spawn(args)
     ctx = Ctx(args)
+    # library selection switches for the stock-torch part of the training step (experiments; defaults are what the numbers are quoted with)
+    if os.environ.get("DSP_TRAIN_BLAS"):
+        ctx.torch.backends.cuda.preferred_blas_library(os.environ["DSP_TRAIN_BLAS"])          # "cublas" (= rocBLAS) | "cublaslt" (= hipBLASLt)
+    if os.environ.get("DSP_CUDNN_BENCHMARK"):
+        ctx.torch.backends.cudnn.benchmark = os.environ["DSP_CUDNN_BENCHMARK"] == "1"
     from daspeech_amd import _lib
     _lib.load()                                       # fails loudly if the HIP extension is missing
     world, rank = ctx.world, ctx.rank

@@ -256,9 +256,7 @@ struct HgsUnitParams {
     const int* lens; int len_mul;
 };
 
-// EXPERIMENT (r05, timing only — wrong results for EXP != 0): bit0 = Winograd F(2,3) cost emulation (4/3, 10/7, 16/11 x the K-steps over half the
-// column tiles), bit1 = one accumulator set for main + correction products, bit2 = no residual re-read from global memory
-template <int C, int NT, int WM, int WN, int EXP>
+template <int C, int NT, int WM, int WN>
 __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_resunit_f32_kernel(HgsUnitParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -282,21 +280,19 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
     hgs_stage_tile<C, 4>(xhi, xlo, X, Tb, t0 - 8 - h1, R1, p.slope, tid);
     __syncthreads();
 
-    f4 accm[MI][NI], accc[(EXP & 2) ? 1 : MI][(EXP & 2) ? 1 : NI];
+    f4 accm[MI][NI], accc[MI][NI];
     const int co_base = wm * (MI * 16);
     const int nsteps = p.ntaps * NC;
-    const int wsteps = (EXP & 1) ? (p.ntaps == 3 ? 4 : p.ntaps == 7 ? 10 : p.ntaps == 11 ? 16 : p.ntaps) * NC : nsteps;
     const size_t wn_elems = (size_t)nsteps * (C / 16) * 512;       // halves in the hi (and in the lo) part of a packed weight buffer
     // NJ: 16-column tiles this wave computes (c2 needs NT of the NTI columns: with one wave column the last tile is skipped — a quarter
     // of c2's MFMAs at C = 256, an eighth at C = 128)
     auto conv = [&](auto njc, const _Float16* W, const char* thi, const char* tlo, int row0, int rstep) {
-        constexpr int NJ = (EXP & 1) ? (decltype(njc)::value + 1) / 2 : decltype(njc)::value;
+        constexpr int NJ = decltype(njc)::value;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) { accm[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; if constexpr (!(EXP & 2)) accc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < NI; ++j) { accm[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; accc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
         auto load_a = [&](int step, h8 (&ah)[MI], h8 (&al)[MI]) {
-            if constexpr (EXP & 1) step = step % nsteps;
             const _Float16* Ws = W + (size_t)step * (C / 16) * 512 + lane * 8;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -305,8 +301,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
             }
         };
         auto do_step = [&](int step, const h8 (&ah)[MI], const h8 (&al)[MI]) {
-            int k = step / NC; const int c = step - k * NC;
-            if constexpr (EXP & 1) k = k % p.ntaps;
+            const int k = step / NC, c = step - k * NC;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int row = (wn * NI + j) * 16 + lr + row0 + k * rstep;
@@ -316,23 +311,18 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, accm[i][j], 0, 0, 0);
-                    if constexpr (EXP & 2) {
-                        accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, accm[i][j], 0, 0, 0);
-                        accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, accm[i][j], 0, 0, 0);
-                    } else {
-                        accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, accc[i][j], 0, 0, 0);
-                        accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, accc[i][j], 0, 0, 0);
-                    }
+                    accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, accc[i][j], 0, 0, 0);
+                    accc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, accc[i][j], 0, 0, 0);
                 }
             }
         };
         h8 a0h[MI], a0l[MI], a1h[MI], a1l[MI];
         load_a(0, a0h, a0l);
-        for (int step = 0; step < wsteps; step += 2) {
-            if (step + 1 < wsteps) load_a(step + 1, a1h, a1l);
+        for (int step = 0; step < nsteps; step += 2) {
+            if (step + 1 < nsteps) load_a(step + 1, a1h, a1l);
             do_step(step, a0h, a0l);
-            if (step + 1 < wsteps) {
-                if (step + 2 < wsteps) load_a(step + 2, a0h, a0l);
+            if (step + 1 < nsteps) {
+                if (step + 2 < nsteps) load_a(step + 2, a0h, a0l);
                 do_step(step + 1, a1h, a1l);
             }
         }
@@ -353,7 +343,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
             _Float16 hv[4], lv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = accm[i][j][e] + ((EXP & 2) ? 0.f : accc[(EXP & 2) ? 0 : i][(EXP & 2) ? 0 : j][e] * HGS_LO_INV) + bv[e];
+                float v = accm[i][j][e] + accc[i][j][e] * HGS_LO_INV + bv[e];
                 v = v > 0.f ? v : v * p.slope;
                 if (!(tm >= 0 && tm < Tb)) v = 0.f;
                 const _Float16 hh = (_Float16)v;
@@ -381,7 +371,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
                 const int tl = (wn * NI + j) * 16 + lr;
                 f4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = accm[i][j][e] + ((EXP & 2) ? 0.f : accc[(EXP & 2) ? 0 : i][(EXP & 2) ? 0 : j][e] * HGS_LO_INV) + bv[e];
+                for (int e = 0; e < 4; ++e) v[e] = accm[i][j][e] + accc[i][j][e] * HGS_LO_INV + bv[e];
                 *reinterpret_cast<f4*>(otile + (size_t)tl * OPITCH + ml) = v;
             }
         }
@@ -398,7 +388,7 @@ __global__ __launch_bounds__(512, ((C == 32 || C == 128) ? 4 : 2)) void hifigan_
             live[u] = e < NT * CPR && t0 + tl < p.T;
             const size_t o = ((size_t)b * p.T + t0 + tl) * C + ch * 4;
             r4[u] = (f4){0.f, 0.f, 0.f, 0.f}; a4[u] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (live[u] && !(EXP & 4)) r4[u] = *reinterpret_cast<const f4*>(p.x + o);              // the unit's residual is its own input
+            if (live[u]) r4[u] = *reinterpret_cast<const f4*>(p.x + o);              // the unit's residual is its own input
             if (live[u] && p.accumulate) a4[u] = *reinterpret_cast<const f4*>(p.out + o);
         }
 #pragma unroll
@@ -423,35 +413,17 @@ static size_t hgs_unit_lds(int C, int NT, int h1)
     return ((m > ot ? m : ot) + 255) / 256 * 256;
 }
 
-static int g_hgs_exp = 0;          // EXPERIMENT selector (dsp_hifigan_set_experiment): bits 0-2 = kernel variant, bit 8 = one workgroup per CU
-
-template <int C, int NT, int WM, int WN, int EXP>
-static int hgs_unit_launch_e(const HgsUnitParams& p, hipStream_t st)
+template <int C, int NT, int WM, int WN>
+static int hgs_unit_launch(const HgsUnitParams& p, hipStream_t st)
 {
     const int h1 = p.dil * (p.ntaps - 1) / 2;
-    size_t lds = hgs_unit_lds(C, NT, h1);
+    const size_t lds = hgs_unit_lds(C, NT, h1);
     if (lds > 160 * 1024) { set_error("hifigan_resunit_f32: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
-    if ((g_hgs_exp & 256) && lds < 100 * 1024) lds = 100 * 1024;
-    auto k = hifigan_resunit_f32_kernel<C, NT, WM, WN, EXP>;
+    auto k = hifigan_resunit_f32_kernel<C, NT, WM, WN>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, 1, p.B), dim3(512), lds, st, p);
     return check_launch("hifigan_resunit_f32");
 }
-
-template <int C, int NT, int WM, int WN>
-static int hgs_unit_launch(const HgsUnitParams& p, hipStream_t st)
-{
-    switch (g_hgs_exp & 7) {
-        case 1: return hgs_unit_launch_e<C, NT, WM, WN, 1>(p, st);
-        case 2: return hgs_unit_launch_e<C, NT, WM, WN, 2>(p, st);
-        case 3: return hgs_unit_launch_e<C, NT, WM, WN, 3>(p, st);
-        case 4: return hgs_unit_launch_e<C, NT, WM, WN, 4>(p, st);
-        case 7: return hgs_unit_launch_e<C, NT, WM, WN, 7>(p, st);
-    }
-    return hgs_unit_launch_e<C, NT, WM, WN, 0>(p, st);
-}
-
-extern "C" int dsp_hifigan_set_experiment(int v) { const int o = dsp::g_hgs_exp; dsp::g_hgs_exp = v; return o; }
 
 static int hgs_unit_nt(int C) { return C == 32 ? 496 : C == 64 ? 240 : C == 128 ? 112 : 48; }
 
