@@ -756,8 +756,14 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
             got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
             assert _lib.last_launch_status() == 0
             np.testing.assert_array_equal(got, ref, err_msg=f"dp_path {path}")
-    finally:
         _lib.set_option("dp_path", 0)
+        for mt in (1, 2):                       # both chunk heights of the max-plus kernel (r05: 32 rows is what the largest launches take)
+            _lib.set_option("dx_mt", mt)
+            got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
+            assert _lib.last_launch_status() == 0
+            np.testing.assert_array_equal(got, ref, err_msg=f"dx_mt {mt}")
+    finally:
+        _lib.set_option("dp_path", 0); _lib.set_option("dx_mt", 0)
     assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == 1          # no B*T*L trace tensor for dense windows either
 
 
@@ -808,8 +814,14 @@ def test_dense_kernels_edge_shapes(shape):
         np.testing.assert_allclose(gk.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
         np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
     if fin.all():
-        path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
-        np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
+        pref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+        try:
+            for mt in (0, 1, 2):                # auto, 16- and 32-row chunks of the max-plus kernel
+                _lib.set_option("dx_mt", mt)
+                path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+                np.testing.assert_array_equal(path, pref, err_msg=f"dx_mt {mt}")
+        finally:
+            _lib.set_option("dx_mt", 0)
 
 
 def _weak_links(seed, B, L, TR, ol, scale):

@@ -9,7 +9,7 @@ import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import graph_oracle as gorc
-from daspeech_amd import decode_ops
+from daspeech_amd import decode_ops, _lib
 PAD = 1
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -20,13 +20,15 @@ for case in range(n):
     d = h * ck
     TRmax = int(rng.choice([1, 3, 7, 32, 64, 99999, int(rng.integers(1, L + 5))]))
     scale = float(rng.choice([0.1, 0.3, 1.0]))
+    tile = int(rng.choice([0, 0, 32, 64, 128]))                              # r05: the tiled kernels (windows beyond the one-image LDS bound), forced on small graphs
+    _lib.set_option("xl_tile", tile)
     feats = rng.standard_normal((B, L, d)).astype(np.float32) * scale
     lens = rng.integers(1, L + 1, B); lens[0] = L
     prev = np.full((B, L), 3, np.int64); prev[np.arange(L)[None] >= lens[:, None]] = PAD
     pos_w = (rng.standard_normal((L + 2, d)) * 0.3).astype(np.float32)
     ws = {k_: (rng.standard_normal((o, 2 * d)) * (0.5 / math.sqrt(d))).astype(np.float32) for k_, o in (("q", d), ("k", d), ("g", h))}
     bs = {k_: (rng.standard_normal(o) * 0.1).astype(np.float32) for k_, o in (("q", d), ("k", d), ("g", h))}
-    tag = f"case {case}: B={B} L={L} heads={h}x{ck} TRmax={TRmax} lens={lens.tolist()} scale={scale}"
+    tag = f"case {case}: B={B} L={L} heads={h}x{ck} TRmax={TRmax} lens={lens.tolist()} scale={scale} xl_tile={tile}"
     try:
         want = gorc.extract_links(feats, prev, pos_w, ws["q"], bs["q"], ws["k"], bs["k"], ws["g"], bs["g"], TRmax, h, PAD)
         t = lambda a: torch.from_numpy(a).cuda()
@@ -63,4 +65,5 @@ for case in range(n):
             assert err <= 2e-5 * ref, f"{nm}: max diff {err:.3e} (scale {ref:.2e})"
     except Exception as e:   # noqa
         bad += 1; print("FAIL", tag, "->", repr(e)[:300])
+_lib.set_option("xl_tile", 0)
 print(f"{n} cases, {bad} failures")
