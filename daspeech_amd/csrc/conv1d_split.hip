@@ -47,12 +47,13 @@ __device__ __forceinline__ int cs_swz(int row, int chunk) {
 }
 
 template <int CI, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
+__global__ __launch_bounds__(WM * WN * 64) void conv1d_split_kernel(CsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char cs_smem[];
     constexpr int CH = CI / 8, NC = CI / 32;
     constexpr int MI = MT / WM / 16, NI = NT / WN / 16;
-    static_assert(WM * WN == 8 && MI >= 1 && NI >= 1, "8 waves");
+    constexpr int NTH = WM * WN * 64;                     // 8 waves, or 16 (r05: four waves per SIMD under one resident workgroup)
+    static_assert((WM * WN == 8 || WM * WN == 16) && MI >= 1 && NI >= 1, "8 or 16 waves");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int lr = lane & 15, lk = lane >> 4;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
         const int rows = min(NT, p.T - t0);
         float* dst = p.kparts > 1 ? p.part + ((size_t)kp * p.B + b) * p.T * p.M : p.out + (size_t)b * p.T * p.ldo;     // split-K: the partial sums are zero
         const size_t ld = p.kparts > 1 ? (size_t)p.M : (size_t)p.ldo;
-        for (int e = tid; e < rows * cw; e += 512) {
+        for (int e = tid; e < rows * cw; e += NTH) {
             const int r = e / cw, c4 = e - r * cw;
             *reinterpret_cast<float4*>(dst + (size_t)(t0 + r) * ld + m0 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -105,12 +106,12 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
     {
         constexpr int CS_U = 4;                                // 8 sixteen-byte requests per lane in flight (more spills: 256 VGPRs)
         const int n = R * CH;
-        for (int e0 = tid; e0 < n; e0 += 512 * CS_U) {
+        for (int e0 = tid; e0 < n; e0 += NTH * CS_U) {
             float4 va[CS_U], vc[CS_U];
             bool ok[CS_U];
 #pragma unroll
             for (int u = 0; u < CS_U; ++u) {
-                const int e = e0 + u * 512, ec = e < n ? e : 0;
+                const int e = e0 + u * NTH, ec = e < n ? e : 0;
                 const int row = ec / CH, ch = ec - row * CH;
                 const int tg = t0 - P + row;
                 ok[u] = e < n && tg >= 0 && tg < p.T;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(512) void conv1d_split_kernel(CsParams p)
             }
 #pragma unroll
             for (int u = 0; u < CS_U; ++u) {
-                const int e = e0 + u * 512;
+                const int e = e0 + u * NTH;
                 if (e < n) {
                     const int row = e / CH, ch = e - row * CH;
                     float f[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vc[u].x, vc[u].y, vc[u].z, vc[u].w};
@@ -317,7 +318,7 @@ static int cs_launch(const CsParams& p, hipStream_t st)
     if (lds > 160 * 1024) { set_error("conv1d_split: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = conv1d_split_kernel<CI, MT, NT, WM, WN>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, ((p.M + MT - 1) / MT) * (p.kparts > 1 ? p.kparts : 1), p.B), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, ((p.M + MT - 1) / MT) * (p.kparts > 1 ? p.kparts : 1), p.B), dim3(WM * WN * 64), lds, st, p);
     return check_launch("conv1d_split");
 }
 
@@ -385,6 +386,11 @@ static int cs_run(const float* x, long ldx, const void* w_hi, const void* w_lo, 
             // (at 192 workgroups the 64-frame tiles still win: 34.3 vs 38.9 us for 1024 -> 256 on 10.6 k positions; 128-channel tiles: no gain)
             const long wgs64 = (long)((T + 63) / 64) * ((M + 255) / 256) * B * kmul;
             if (ntaps <= 9 && wgs64 < 128) return cs_launch<512, 256, 32, 8, 1>(p, st);
+            // r05: one-tap, one-slice layers (the NAT decoder's 512 -> 512 / 1536 / 2048 projections) as 16-wave workgroups, 16 output channels per
+            // wave: four waves per SIMD under the one resident workgroup (122 VGPRs), bit-identical results, 5-8 % faster (tools/cs_var_bench.py:
+            // 39.8 -> 36.7, 98.7 -> 91.4, 116.6 -> 108.6 us; 512 output channels per workgroup: 2.2 x slower (spills), 8 x 2 waves: +18 %;
+            // multi-slice and K = 9 layers: no difference; the 256-wide instances: no gain at 64 rows, +20 % at 128 rows)
+            if (ntaps == 1 && nslices == 1 && kmul == 1) return cs_launch<512, 256, 64, 16, 1>(p, st);
             return cs_launch<512, 256, 64, 8, 1>(p, st);
         }
         case 128: return cs_launch<128, 128, 256, 4, 2>(p, st);
