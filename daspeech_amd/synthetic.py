@@ -44,6 +44,33 @@ class NATSpeechToSpeechTask:
     def get_batch(self, device, step: int = 0):
         return make_s2st_batch(self.batch_size, device, self.seed + step)
 
+    # The two entry points fairseq's trainer calls (tasks/nat_speech_to_speech.py:282-320), with the reference's profiler scopes
+    # ("forward" / "backward" record_function ranges, :299,:304 — they show up in torch.profiler and, under rocprofv3 --marker-trace with
+    # torch.autograd.profiler.emit_nvtx(), as roctx ranges).  `optimizer` is anything with backward(loss) (fp16_trainer.FP16FlatOptimizer,
+    # fairseq's optimizers); a plain torch optimizer gets loss.backward().
+    def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad: bool = False):
+        model.train()
+        sample = dict(sample)
+        sample["update_num"] = update_num
+        if hasattr(model, "set_num_updates"):
+            model.set_num_updates(update_num)
+        with torch.autograd.profiler.record_function("forward"):
+            loss, sample_size, logging_output = criterion(model, sample)
+        if ignore_grad:
+            loss = loss * 0
+        with torch.autograd.profiler.record_function("backward"):
+            if hasattr(optimizer, "backward"):
+                optimizer.backward(loss)
+            else:
+                loss.backward()
+        return loss, sample_size, logging_output
+
+    def valid_step(self, sample, model, criterion):
+        model.eval()
+        with torch.no_grad():
+            loss, sample_size, logging_output = criterion(model, sample)
+        return loss, sample_size, logging_output
+
 
 class NATSpeechToTextTask(NATSpeechToSpeechTask):
     name = "nat_speech_to_text"

@@ -63,3 +63,35 @@ def test_eval_mode_attention_blocks_agree_with_their_training_formulation_on_cpu
     f = FFTLayer(128, 2, 256, 9)
     with torch.no_grad():
         torch.testing.assert_close(f.eval()(x, pad), f.train()(x, pad), rtol=1e-5, atol=1e-5)
+
+
+def test_task_train_step_carries_the_reference_profiler_scopes():
+    """tasks/nat_speech_to_speech.py:299,304: criterion under record_function("forward"), optimizer.backward under record_function("backward");
+    valid_step in eval mode without a graph.  A stand-in model / criterion: the scopes and the call order are what is checked."""
+    import torch
+    from torch.profiler import profile, ProfilerActivity
+    from daspeech_amd.synthetic import NATSpeechToSpeechTask
+    lin = torch.nn.Linear(4, 1)
+    seen = {}
+
+    def criterion(model, sample):
+        seen["update_num"] = sample.get("update_num")
+        seen["training"] = model.training
+        loss = model(sample["x"]).sum()
+        return loss, 1, {"loss": float(loss)}
+
+    class Opt:
+        def backward(self, loss):
+            seen["backward"] = True
+            loss.backward()
+    task = NATSpeechToSpeechTask()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        loss, n, log = task.train_step({"x": torch.ones(2, 4)}, lin, criterion, Opt(), update_num=7)
+    names = {e.name for e in prof.events()}
+    assert {"forward", "backward"} <= names
+    assert seen == {"update_num": 7, "training": True, "backward": True} and n == 1 and lin.weight.grad is not None
+    lin.zero_grad()
+    loss0, _, _ = task.train_step({"x": torch.ones(2, 4)}, lin, criterion, torch.optim.SGD(lin.parameters(), lr=0.1), update_num=8, ignore_grad=True)
+    assert float(loss0) == 0.0 and float(lin.weight.grad.abs().sum()) == 0.0
+    vloss, _, _ = task.valid_step({"x": torch.ones(2, 4)}, lin, criterion)
+    assert seen["training"] is False and not vloss.requires_grad
