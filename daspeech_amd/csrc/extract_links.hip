@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void extract_links_bwd_tiled_kernel(
     }
 }
 
-static int g_xl_tile = 0;          // dsp_dag_set_option("xl_tile", n): n > 0 forces the tiled kernels with TW = n (tests); 0 = only where the image does not fit
+static thread_local int g_xl_tile = 0;          // dsp_dag_set_option("xl_tile", n): n > 0 forces the tiled kernels with TW = n (tests); 0 = only where the image does not fit
 void set_xl_tile(int v) { g_xl_tile = v > 0 ? ((v + 31) / 32) * 32 : 0; }
 }  // namespace dsp
 

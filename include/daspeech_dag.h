@@ -148,6 +148,10 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   "mx_cpl" 0|1|2|4 (r04): vertices per lane of the banded max-DP (0 = auto: 4 when that still gives >= 200 workgroups, else 2; 1 exists
  *   for the co-residency measurement of profiles/r04_dp_coresidency.txt), "bt_ring" 1|0 (r04): the LDS-ring back-trace (TR == 32) or the
  *   r01-r03 window kernel — every combination returns bit-identical paths.
+ *   "dm_mt" 3|4|14 (r05): 48- / 64-row chunks at two workgroups per CU, 64 rows at one — measurement builds, bit-identical, slower.
+ *   "dx_mt" 0|1|2 (r05): rows per chunk of the dense max-plus alignment kernel in 16-row tiles (0 = auto: 2 for launches of >= 6 rounds of
+ *   workgroups); bit-identical paths.  "xl_tile" n (r05): n > 0 forces the TILED extract_links kernels (include/daspeech_decode.h) with a tile
+ *   of n slots on any window — by default they serve the windows whose one-image score tile does not fit LDS (TR above ~1100).
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);

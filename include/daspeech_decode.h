@@ -43,7 +43,9 @@ int dsp_gather_rows(const void* features, int dtype, const int32_t* keep_idx, co
  *   log_gates [B,L,H] fp32 (log_softmax of gate_linear), out_len [B] int64, dist_bias [TR] fp32 or NULL (benchmark calibration),
  *   scale = 1/sqrt(CK).  links[b,i,d] = logsumexp_h( log_softmax_d(q_i.k_{i+d+1} * scale, over valid successors) + log_gates[b,i,h] ),
  *   -inf where i+d+1 >= out_len[b] or >= L; rows without a successor are all -inf.  Only the band is computed — the reference's
- *   [B,L,L,H] content tensor and its gather (:183-196) never exist.  Inference path (no gradient). */
+ *   [B,L,L,H] content tensor and its gather (:183-196) never exist.  Inference path (no gradient).
+ *   Any TR up to L-1: windows whose [4 vertices][TR][8 heads] score image exceeds LDS (TR above ~1100) are walked in tiles of 512 successors
+ *   (online soft-max state in a first pass, per-tile emission in a second); the same holds for the two training entry points below. */
 int dsp_extract_links(const float* q, const float* k, const float* log_gates, const int64_t* out_len,
                       const float* dist_bias, float* links, int B, int L, int H, int CK, int TR, float scale,
                       dsp_stream_t stream);
