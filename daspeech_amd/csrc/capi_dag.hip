@@ -55,7 +55,7 @@ int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, cons
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
-// 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 64).
+// 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 32).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
 static thread_local int g_path = 0;
@@ -81,7 +81,7 @@ extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
         const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
         const long NS = (2L * B * ns1024 >= 200) ? ns1024 : ns512;
         halo = (size_t)2 * B * NS * T * 32 * 8;
-    } else if (TR <= 64) {                            // banded 2-column strips of 512
+    } else if (TR <= 64 && !dense_mfma_supported(L, TR)) {      // banded 2-column strips of 512
         halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
     } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
@@ -106,7 +106,7 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
         const size_t mx = (size_t)B * NS * T * 32 * 8;
         return align256(256 + (strip > mx ? strip : mx)) + 512;
     }
-    if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
+    if (TR <= 64 && !dense_max_supported(L, TR)) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
     if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
         return align256(256 + align256((size_t)B * NJ * 4) + align256((size_t)B * T * NJ * 4) + (size_t)B * T * L * 2) + 512;     // (+ the block trace)

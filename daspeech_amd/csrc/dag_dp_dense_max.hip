@@ -449,7 +449,7 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
 static thread_local int g_dx_mt = 0;                   // diagnostic switch (dsp_dag_set_option "dx_mt"): 0 = auto, 1 / 2 = 16- / 32-row chunks
 void set_dx_mt(int v) { g_dx_mt = (v == 1 || v == 2) ? v : 0; }
 
-bool dense_max_supported(int L, int TR) { return TR > 64 && L >= 128 && (size_t)L * 4 <= 150 * 1024 && (long)L * TR < (1L << 31); }
+bool dense_max_supported(int L, int TR) { return TR > 32 && L >= 128 && (size_t)L * 4 <= 150 * 1024 && (long)L * TR < (1L << 31); }
 
 int launch_dag_dense_max(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                          float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)

@@ -914,7 +914,9 @@ int launch_dag_dense_rows_gated(const float*, const float*, const int64_t*, cons
 
 // (L beyond what the stand-by log-space kernels take has no exact fallback for transitions exp space flushes: such shapes stay with the
 // generic log-space kernel)
-bool dense_mfma_supported(int L, int TR) { return TR > 64 && L >= 128 && (long)L * TR < (1L << 31) && dense_rows_gated_supported(L); }
+// (r05: windows 33 .. 64 too — until then they fell through to the row-sequential generic kernel: 112 ms at C2 / TR = 64; the partially
+//  masked tiles of such a window take the predicated conversion path, at most two source blocks per column block)
+bool dense_mfma_supported(int L, int TR) { return TR > 32 && L >= 128 && (long)L * TR < (1L << 31) && dense_rows_gated_supported(L); }
 
 template <int D, int MT>
 static int launch_dm(const DMParams& p, int nwg, hipStream_t st)

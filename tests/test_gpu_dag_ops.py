@@ -498,7 +498,8 @@ def test_alignment_large_graph_properties(L):
 # ---------------------------------------------------------------------------------------------- dense window on the f32 matrix cores
 DENSE_SHAPES = [(3, 24, 200, 199), (2, 40, 256, 255), (4, 33, 130, 129), (2, 20, 500, 100), (2, 70, 400, 399), (1, 9, 1024, 1023),
                 (3, 18, 192, 191), (2, 50, 640, 639),
-                (44, 10, 448, 447)]       # 308 workgroups per direction: more than CUs, so the two-workgroups-per-CU builds run
+                (44, 10, 448, 447),       # 308 workgroups per direction: more than CUs, so the two-workgroups-per-CU builds run
+                (3, 30, 300, 33), (2, 25, 520, 64), (2, 40, 390, 48)]     # r05: windows 33 .. 64 are served by the dense-window kernels too
 
 
 @pytest.mark.parametrize("masked", [False, True])
@@ -539,7 +540,7 @@ def test_dense_mfma_dp_matches_oracle(shape, masked):
 
 
 @pytest.mark.parametrize("weak", [False, True])
-@pytest.mark.parametrize("shape", DENSE_SHAPES)
+@pytest.mark.parametrize("shape", [s_ for s_ in DENSE_SHAPES if s_[3] > 64])        # (K5's block products serve TR > 64; 33 .. 64 keep the tiled log-space kernel)
 def test_dense_grad_links_block_products_match_oracle(shape, weak):
     """dag_grad_dense.hip (K5 for TR > 64: per-block-pair products over the target axis on v_mfma_f32_16x16x4_f32, diagonal and
     window-edge pairs term by term) against the fp64 oracle and the tiled log-space kernel (k5_path 1): ragged lengths, windows between
