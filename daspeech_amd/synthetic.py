@@ -98,8 +98,10 @@ def calibrate_synthetic_weights(model, mean_jump: float = 6.5, frames_per_phonem
     rebound), not in the product model."""
     import types
     model.synthetic_token_cycle = 97           # distinct neighbouring tokens: no repeat-collapse, no <pad> emissions
-    d = torch.arange(1, model.args.max_target_positions + 1, dtype=torch.float)
-    model.synthetic_link_bias = -4.0 * ((d - mean_jump) / 2.0) ** 2
+    d = torch.arange(1, model.args.max_target_positions + 1, dtype=torch.float, device=next(model.parameters()).device)
+    # (a buffer: follows .to(device) — no per-call upload, which a hipGraph capture would refuse; clamped so that model.half() keeps it finite:
+    #  a distance 250 vertices off the mean jump has probability exp(-6e4) = 0 either way)
+    model.register_buffer("synthetic_link_bias", (-4.0 * ((d - mean_jump) / 2.0) ** 2).clamp(min=-6.0e4), persistent=False)
     model.decode_graph = types.MethodType(_synthetic_decode_graph, model)
     if hasattr(model, "tts"):                  # the speech-to-text model has no TTS stage
         dp = model.tts.var_adaptor.duration_predictor
