@@ -942,7 +942,7 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
     DMParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha; p.beta = beta;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NJ = NJ; p.ndir = ndir;
-    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; }
+    { static const char* const e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; }      // (read once per process: no getenv on the launch path)
     const size_t prog_bytes = ((size_t)ndir * B * NJ * sizeof(u32) + 255) / 256 * 256;
     const size_t s_bytes = ((size_t)ndir * B * T * NJ * sizeof(float2) + 255) / 256 * 256;
     // the stand-by log-space kernels (see `aborted` in the kernel).  A predecessor visited by the exact redo costs about one memory

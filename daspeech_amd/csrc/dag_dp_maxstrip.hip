@@ -686,7 +686,7 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS;
 #ifdef DSP_MX_PROF                                  // instrumentation build only (tools/prof_maxstrip.py): nothing on the product's launch path
-    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; const char* a = getenv("DSP_MX_ABLATE"); if (a) p.dbg |= atoi(a) & 28; }
+    { static const char* const e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; static const char* const a = getenv("DSP_MX_ABLATE"); if (a) p.dbg |= atoi(a) & 28; }
 #else
     p.dbg = 0;
 #endif

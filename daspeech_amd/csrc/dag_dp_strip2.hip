@@ -501,10 +501,11 @@ static int launch_strip2(const StripParams& p, int nwg, hipStream_t st)
     const size_t lds_main = (size_t)(6 * RL + S2_RING * W) * 4 + (size_t)S2_RING * 32 * 8;
     const size_t lds_tile = (size_t)(NT + 34) * 33 * 4;
     size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
-    if (getenv("DSP_S2_LDS")) lds = (size_t)atoi(getenv("DSP_S2_LDS"));
+    { static const char* const e = getenv("DSP_S2_LDS"); if (e) lds = (size_t)atoi(e); }
     auto k = dag_strip2_kernel<NT, MODE>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (getenv("DSP_DEBUG")) {
+    static const char* const e_dbg = getenv("DSP_DEBUG");
+    if (e_dbg) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k, NT + 64, lds);
         fprintf(stderr, "[dsp] strip2<%d,%d>: lds=%zu bytes, occupancy API = %d blocks/CU, grid=%d\n", NT, MODE, lds, nb, nwg);
@@ -528,7 +529,7 @@ int launch_dag_strip2(int mode, const float* match, const float* links, const in
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.dbg = 0;
     const size_t halo_bytes = (size_t)ndir * B * NS * T * 32 * sizeof(u64);
     const int nwg = ndir * B * NS;
-    const char* dbg = getenv("DSP_DEBUG");
+    static const char* const dbg = getenv("DSP_DEBUG");
     const bool census = dbg && !strcmp(dbg, "census");
     p.dbg = census ? 1 : 0;
     int rc = banded_acquire_ws(st, halo_bytes + (census ? (size_t)nwg * 32 : 0), T, &p.counters, &p.halo, &p.tag_base);

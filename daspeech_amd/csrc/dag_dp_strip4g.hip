@@ -642,7 +642,7 @@ int launch_dag_strip4g(const float* match, const float* links, const int64_t* ou
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = nullptr;
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
-    { const char* e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
+    { static const char* const e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
     const size_t halo_bytes = (size_t)ndir * B * NS * T * G4_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;

@@ -606,7 +606,8 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
                 auto kg = nvec <= 2 ? lsg_fwd_regl_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_regl_kernel<T, 4> : lsg_fwd_regl_kernel<T, 8>);
                 const long nt = (long)B * ((L + RTg - 1) / RTg);
                 int gridg = (int)(nt < 4096 ? nt : 4096);
-                if (getenv("DSP_K1_GRID")) gridg = atoi(getenv("DSP_K1_GRID"));
+                static const char* const e_grid = getenv("DSP_K1_GRID");        // (tuning switches: read once per process)
+                if (e_grid) gridg = atoi(e_grid);
                 if (ldsg > 48 * 1024) (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
                 hipLaunchKernelGGL(kg, dim3(gridg), dim3(256), ldsg, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
                                    B, L, V, S, RTg, ws, stats);
@@ -617,7 +618,8 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
         // storing the softmax makes the launch a 1:1 read/write stream: two resident workgroups per CU (64 KB of stage per
         // workgroup at RT = 32) sustain 4.9 TB/s, four only 4.1 TB/s (sweep in tools/k1_bench.py, r01)
         if (ws && (size_t)S * 32 * 4 <= 96 * 1024 && L >= 32) { RTr = 32; const long nt = (long)B * ((L + 31) / 32); gridr = (int)(nt < 4096 ? nt : 4096); }
-        if (getenv("DSP_K1_RT")) { RTr = atoi(getenv("DSP_K1_RT")); const long nt = (long)B * ((L + RTr - 1) / RTr); gridr = (int)(nt < 65535 * 4 ? nt : 65535 * 4); if (getenv("DSP_K1_GRID")) gridr = atoi(getenv("DSP_K1_GRID")); }
+        static const char* const e_rt = getenv("DSP_K1_RT"); static const char* const e_grid2 = getenv("DSP_K1_GRID");
+        if (e_rt) { RTr = atoi(e_rt); const long nt = (long)B * ((L + RTr - 1) / RTr); gridr = (int)(nt < 65535 * 4 ? nt : 65535 * 4); if (e_grid2) gridr = atoi(e_grid2); }
         const size_t ldsr = (32 + (size_t)S * RTr) * sizeof(float);
         if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
         hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
@@ -639,18 +641,19 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
     const bool vec = (V % N == 0) && ((uintptr_t)sm % 16 == 0);
     size_t lds = (16 + (size_t)V) * sizeof(float);
     if (lds > 160 * 1024) { set_error("logsoftmax_gather_bwd: V=%d exceeds the LDS row image (max ~40k)", V); return DSP_EINVAL; }
-    if (getenv("DSP_K1B_LDS")) { const size_t want = (size_t)atoi(getenv("DSP_K1B_LDS")); if (want > lds) lds = want; }
+    { static const char* const e = getenv("DSP_K1B_LDS"); if (e) { const size_t want = (size_t)atoi(e); if (want > lds) lds = want; } }
     const long nrows = (long)B * L;
     const int nvec = (V + 256 * N - 1) / (256 * N);
     {
         int RT = 16;
-        if (getenv("DSP_K1B_RT")) RT = atoi(getenv("DSP_K1B_RT"));
+        { static const char* const e = getenv("DSP_K1B_RT"); if (e) RT = atoi(e); }
         const size_t ldsr = (16 + (size_t)V + (size_t)S * RT) * sizeof(float);
-        if (vec && nvec <= 8 && ldsr <= 76 * 1024 && L >= RT && !getenv("DSP_K1B_OLD")) {     // two workgroups per CU
+        static const char* const e_old = getenv("DSP_K1B_OLD");
+        if (vec && nvec <= 8 && ldsr <= 76 * 1024 && L >= RT && !e_old) {     // two workgroups per CU
             auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2, LAZY> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4, LAZY> : lsg_bwd_reg_kernel<T, 8, LAZY>);
             const long nt = (long)B * ((L + RT - 1) / RT);
             int gridr = (int)(nt < 4096 ? nt : 4096);
-            if (getenv("DSP_K1B_GRID")) gridr = atoi(getenv("DSP_K1B_GRID"));
+            { static const char* const e = getenv("DSP_K1B_GRID"); if (e) gridr = atoi(e); }
             if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
             hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT, stats);
             return check_launch("logsoftmax_gather_bwd(reg)");
