@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
     ap.add_argument("--no-peaked", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC record instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--no-c1", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline: skip the C3 (s2tt, B=64) and C5 (train, B=32, fp16 model) legs")
     ap.add_argument("--extra-steps", type=int, default=6, help="headline: timed steps of the C3 / C5 legs")
@@ -327,6 +328,46 @@ def run_dag_ops(ctx, B, L, T, V, TR, steps, warmup, seed, peaked=False, lazy=Fal
     return phases, wall, {"finite_losses": int(torch.isfinite(out[0]).sum()), "launch_status": status}
 
 
+def live_dp_traffic(args, TR):
+    """HBM bytes per launch of the DP forward kernel, OBSERVED by this run: two short child runs of this script's `dag` workload under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes), per-dispatch
+    averages of the DP kernel, FETCH doubled (the guide's gfx950 correction for 16-byte-per-lane streams).  None if rocprofv3 is not there or
+    a pass fails — the committed record of tools/refresh_profiles.sh is used then."""
+    import csv, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("DSP_BENCH_CHILD"):
+        return None
+    kern = "dag_strip4g_kernel" if TR <= 32 else "dag_dense_mfma_kernel"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dsp_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", "dag", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-c1", "--no-peaked", "--tr", str(args.tr),
+                   "--dag-batch", str(args.dag_batch), "--graph-len", str(args.graph_len), "--tgt-len", str(args.tgt_len), "--vocab", str(args.vocab)]
+            env = dict(os.environ, DSP_BENCH_CHILD="1", TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not files:
+                return None
+            tot, disp = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if kern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"]); disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None
+            vals[counter] = tot / len(disp)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_bytes_per_launch": int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"],
+            "WRITE_SIZE_KB": vals["WRITE_SIZE"], "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over `bench.py --workload dag` "
+                                                            f"(per-dispatch mean of {kern}, FETCH doubled per MI355X_MICROARCH.md)"}
+
+
 def dag_report(ctx, args, steps, warmup):
     B, L, T, V = args.dag_batch, args.graph_len, args.tgt_len, args.vocab
     TR = min(args.tr, L - 1)
@@ -339,8 +380,14 @@ def dag_report(ctx, args, steps, warmup):
     ms = phases["dag_fwd"]
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic, src = None, None
+    live = None
+    if ctx.rank == 0 and ctx.world == 1 and not getattr(args, "no_live_traffic", False):
+        ctx.torch.cuda.synchronize()
+        live = live_dp_traffic(args, TR)
     pmc = os.path.join(ROOT, "profiles", "pmc_dag_fwd.json")
-    if os.path.exists(pmc):
+    if live is not None:
+        traffic, src = live["hbm_bytes_per_launch"], live["source"]
+    elif os.path.exists(pmc):
         try:
             rec = json.load(open(pmc)).get(f"tr{TR}", {})
             if rec.get("shape") in (None, [B, T, L, TR]):
