@@ -375,7 +375,7 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
                                 if (__any(dlim >= d0 && dlo <= d0 + 7)) {
 #pragma unroll
                                     for (int d = d0; d < d0 + 8; ++d)
-                                        sc = fmaf(__builtin_amdgcn_exp2f(aw[gqidx<BETA>(c, d)] - cmx), Eval(c, d), sc);
+                                        sc = fmaf(__builtin_amdgcn_exp2f(d <= TR ? aw[gqidx<BETA>(c, d)] - cmx : NEG_INF), Eval(c, d), sc);   // (slots past the window: 2^(-inf) = 0, not inf x 0)
                                 }
                             }
                             S[c] = sc;
