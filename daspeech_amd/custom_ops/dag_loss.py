@@ -83,11 +83,24 @@ def _workspace(dev: torch.device, nbytes: int) -> Tensor:
     return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
 
 
+# The banded fast paths (TR <= 32: exp-space strips, values-only max-DP) read rows with 16-byte loads: L must be a multiple of 4.  A graph
+# length is floor(src_upsample * frames) — any integer — and three graphs in four fell through to the 2-column log-space strips (r05 scan:
+# C2 at L = 4098 forward 1.56 ms against 0.55, alignment 1.24 against 0.41).  Such inputs are padded HERE to the next multiple of 4 with
+# vertices outside every sample's graph (-inf emissions and transitions; output_length is untouched, so the kernels never visit them) and the
+# results are cut back: one extra pass over [B,T,L] instead of a 3 x slower DP.
+def _pad4(m: Tensor, k: Tensor):
+    L, TR = m.shape[2], k.shape[2]
+    pad = (-L) % 4
+    if pad == 0 or TR > 32:
+        return m, k, 0
+    return (torch.nn.functional.pad(m, (0, pad), value=float("-inf")), torch.nn.functional.pad(k, (0, 0, 0, pad), value=float("-inf")), pad)
+
+
 def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):
     dev = _require_gpu("dag_loss", match_all, links, output_length, target_length)
     B, T, L, TR = _check_dp_args("dag_loss", match_all, links, output_length, target_length)
-    m = _f32c(match_all)
-    k = _f32c(links)
+    m, k, _pad = _pad4(_f32c(match_all), _f32c(links))
+    L = L + _pad
     ol = output_length.contiguous()
     tl = target_length.contiguous()
     lib = _lib.load()
@@ -137,6 +150,7 @@ class DagLossFunc(Function):
         m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
         ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
         ctx.in_dtypes = (match_all.dtype, links.dtype)
+        ctx.L = match_all.shape[2]
         return loss.to(match_all.dtype)
 
     @staticmethod
@@ -145,9 +159,19 @@ class DagLossFunc(Function):
             return None, None, None, None
         alpha, beta, m, k, ol, tl = ctx.saved_tensors
         gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gm, gl = _unpad_grads(gm, gl, ctx.L)
         gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
         gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
         return gm, gl, None, None
+
+
+def _unpad_grads(gm, gl, L):
+    """cut the gradients of a graph padded by _pad4 back to its L vertices"""
+    if gm is not None and gm.shape[2] != L:
+        gm = gm[:, :, :L]
+    if gl is not None and gl.shape[1] != L:
+        gl = gl[:, :L]
+    return gm, gl
 
 
 class DagLossWithAlphaBetaFunc(Function):
@@ -161,10 +185,13 @@ class DagLossWithAlphaBetaFunc(Function):
         m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
         ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
         ctx.in_dtypes = (match_all.dtype, links.dtype)
+        ctx.L = match_all.shape[2]
         if beta is None:
             # no gradient required: the reference launches no beta kernel and hands back the table as allocated, all zeros
             # (dag_loss.cu:339-340,355-371) — callers (the expect strategy in validation / while the DAG is frozen) compute with it
             beta = torch.zeros_like(alpha)
+        if alpha.shape[2] != ctx.L:                                  # (a graph padded by _pad4: the caller sees its own L vertices)
+            alpha, beta = alpha[:, :, :ctx.L].contiguous(), beta[:, :, :ctx.L].contiguous()
         ctx.mark_non_differentiable(alpha, beta)
         return loss.to(match_all.dtype), (alpha, beta)
 
@@ -174,6 +201,7 @@ class DagLossWithAlphaBetaFunc(Function):
             return None, None, None, None
         alpha, beta, m, k, ol, tl = ctx.saved_tensors
         gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gm, gl = _unpad_grads(gm, gl, ctx.L)
         gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
         gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
         return gm, gl, None, None
@@ -208,8 +236,8 @@ class DagBestAlignmentFunc(Function):
     def forward(ctx, match_all, links, output_length, target_length):
         dev = _require_gpu("dag_best_alignment", match_all, links, output_length, target_length)
         B, T, L, TR = _check_dp_args("dag_best_alignment", match_all, links, output_length, target_length)
-        m = _f32c(match_all)
-        k = _f32c(links)
+        m, k, _pad = _pad4(_f32c(match_all), _f32c(links))
+        L0, L = L, L + _pad
         ol = output_length.contiguous()
         tl = target_length.contiguous()
         lib = _lib.load()
@@ -225,6 +253,8 @@ class DagBestAlignmentFunc(Function):
                                                _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.ptr(ws), ws.numel(),
                                                _lib.current_stream_handle())
             _lib.check(rc, "dsp_dag_best_alignment_ws")
+        if L != L0:
+            path = path[:, :L0].contiguous()
         ctx.mark_non_differentiable(path)
         return path
 
