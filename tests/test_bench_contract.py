@@ -88,3 +88,38 @@ def test_bench_under_a_launcher_world2_gloo_rehearsal():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "plumbing"], capture_output=True, text=True,
                          timeout=300, env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_live_traffic_reads_the_per_dispatch_counters(tmp_path, monkeypatch):
+    """bench.live_dp_traffic: two `rocprofv3 --pmc` child passes, per-dispatch mean of the DP kernel, FETCH doubled + WRITE, in bytes.  A stand-in
+    rocprofv3 on PATH writes the counter CSV the real one writes (no GPU here); a failing pass gives None (the committed record is used then)."""
+    import stat
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+d = a[a.index("-d") + 1]; c = a[a.index("--pmc") + 1]
+if os.environ.get("FAKE_FAIL") == c: sys.exit(3)
+os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
+v = {"FETCH_SIZE": (1000.0, 3000.0), "WRITE_SIZE": (500.0, 700.0)}[c]
+with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
+    f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\\n")
+    k = '"void dsp::dag_strip4g_kernel<256, 0, false>(dsp::GStripParams)"'
+    f.write(f"1,{k},{c},{v[0]}\\n2,{k},{c},{v[1]}\\n")
+    f.write(f'3,"void dsp::lsg_fwd_regl_kernel<float, 8>(P)",{c},999999\\n')
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    monkeypatch.delenv("DSP_BENCH_CHILD", raising=False)
+    args = types.SimpleNamespace(tr=32, dag_batch=2, graph_len=64, tgt_len=8, vocab=16)
+    r = bench.live_dp_traffic(args, 32)
+    assert r is not None and r["FETCH_SIZE_KB_raw"] == 2000.0 and r["WRITE_SIZE_KB"] == 600.0
+    assert r["hbm_bytes_per_launch"] == int((2 * 2000.0 + 600.0) * 1024) and "this run" in r["source"]
+    monkeypatch.setenv("FAKE_FAIL", "WRITE_SIZE")
+    assert bench.live_dp_traffic(args, 32) is None
+    monkeypatch.delenv("FAKE_FAIL")
+    monkeypatch.setenv("DSP_BENCH_CHILD", "1")                 # a child pass never recurses
+    assert bench.live_dp_traffic(args, 32) is None
