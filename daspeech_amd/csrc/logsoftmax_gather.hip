@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void lsg_fwd_reg_kernel(
 // without; bf16 1.19 -> 1.05 ms), the
 // gather costs no L2 traffic at all, and the two-rows-ahead gather registers are gone.  Two workgroup barriers per row: the row
 // image is single (a second 32 KB image would halve the occupancy).
-template <typename T, int NV>
+// DEEP = true: two rows requested ahead (three row images in registers: NV <= 8); false: one row ahead — the NV = 16 instance (r05: rows of up to
+// 16 384 fp32 / 32 768 half-precision logits stay on this kernel instead of the two-pass generic one: 3.5 -> 5 TB/s)
+template <typename T, int NV, bool DEEP = true>
 __global__ __launch_bounds__(256) void lsg_fwd_regl_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     float* __restrict__ out, int64_t osb, int64_t osj, int64_t oss,
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void lsg_fwd_regl_kernel(
         const int b = (int)(tile / tiles_per_b);
         const int j0 = (int)(tile % tiles_per_b) * RT;
         const int nr = min(RT, L - j0);
-        uint4 cur[NV], nxt[NV], nx2[NV];
+        uint4 cur[NV], nxt[NV], nx2[DEEP ? NV : 1];
         auto load_row = [&](int r, uint4 (&dst)[NV]) {
             const T* row = x + ((size_t)b * L + (j0 + r)) * V;
 #pragma unroll
@@ -350,10 +352,11 @@ __global__ __launch_bounds__(256) void lsg_fwd_regl_kernel(
             }
         };
         load_row(0, cur); load_tok(0, tk);
-        if (nr > 1) { load_row(1, nxt); load_tok(1, tkn); }
+        if (DEEP && nr > 1) { load_row(1, nxt); load_tok(1, tkn); }
         for (int r = 0; r < nr; ++r) {
             T* row = x + ((size_t)b * L + (j0 + r)) * V;
-            if (r + 2 < nr) load_row(r + 2, nx2);
+            if constexpr (DEEP) { if (r + 2 < nr) load_row(r + 2, nx2); }
+            else { if (r + 1 < nr) { load_row(r + 1, nxt); load_tok(r + 1, tkn); } }
             float f[NV][N];
             float m = NEG_INF;
 #pragma unroll
@@ -409,10 +412,10 @@ __global__ __launch_bounds__(256) void lsg_fwd_regl_kernel(
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; if constexpr (DEEP) nxt[k] = nx2[k]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) tk[u] = tkn[u];
-            if (r + 2 < nr) load_tok(r + 2, tkn);
+            if constexpr (DEEP) { if (r + 2 < nr) load_tok(r + 2, tkn); }
         }
         __syncthreads();
         const int tot = S * nr;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_kernel(
 // different workgroups on 8 XCDs: 0.27 GB of gradients cost 1.2 GB of FETCH_SIZE at C2.  Here the [S][RT] gradient tile is
 // staged through LDS with 4*RT-byte runs along j, the softmax row is register-resident with the next row prefetched (as in
 // lsg_fwd_reg_kernel), and the per-row scatter image in LDS is unchanged.
-template <typename T, int NV, bool LAZY, int NTM = 3>       // NTM: bit 0 non-temporal row loads, bit 1 non-temporal row stores
+template <typename T, int NV, bool LAZY, int NTM = 3, bool DEEP = true>       // NTM: bit 0 non-temporal row loads, bit 1 non-temporal row stores; DEEP: two rows ahead (false: one — the wide-row instances, r05)
 __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
     T* __restrict__ x, const int64_t* __restrict__ idx, int64_t isb, int64_t isj, int64_t iss,
     const float* __restrict__ g, int64_t gsb, int64_t gsj, int64_t gss,
@@ -523,9 +526,9 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
                 if (v < V) dst[k] = lsg_ld16<(NTM & 1) != 0>(row + v);
             }
         };
-        uint4 nx2[NV];
+        uint4 nx2[DEEP ? NV : 1];
         load_row(0, cur);
-        if (nr > 1) load_row(1, nxt);
+        if (DEEP && nr > 1) load_row(1, nxt);
         __syncthreads();                                   // previous tile's gt / delta use is over
         const int tot = S * nr;
         if (gsj == 1) {                                    // [B][S][L] gradients: runs along j
@@ -536,7 +539,8 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
         __syncthreads();
         for (int r = 0; r < nr; ++r) {
             T* row = x + ((size_t)b * L + (j0 + r)) * V;
-            if (r + 2 < nr) load_row(r + 2, nx2);          // two rows ahead (see lsg_fwd_reg_kernel)
+            if constexpr (DEEP) { if (r + 2 < nr) load_row(r + 2, nx2); }          // two rows ahead (see lsg_fwd_reg_kernel)
+            else { if (r + 1 < nr) load_row(r + 1, nxt); }
             float gs = 0.f;
             for (int k = tid; k < S; k += 256) {
                 const float gv = gt[k * RT + r];
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256) void lsg_bwd_reg_kernel(
                 delta[t] = 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+            for (int k = 0; k < NV; ++k) { cur[k] = nxt[k]; if constexpr (DEEP) nxt[k] = nx2[k]; }
             __syncthreads();
         }
     }
@@ -593,8 +597,23 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     // register-resident variant when the row fits NV x 256 sixteen-byte vectors
     const int nvec = (V + 256 * N - 1) / (256 * N);
+    if (vec && sizeof(T) == 4 && nvec > 8 && nvec <= 16 && S <= 8 * 256) {      // (half precision: 128 elements per lane — the generic kernel is faster, 3.6 vs 1.9-2.3 TB/s)
+        // wide rows (8 192 < V <= 16 384 fp32, 16 384 < V <= 32 768 half precision): the LDS-gather kernel with 16 vectors per lane and one row ahead
+        int RTg = 16;
+        while (RTg > 1 && (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4 > 78 * 1024) RTg >>= 1;
+        const size_t ldsg = (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4;
+        if (ldsg <= 78 * 1024 && L >= RTg && (S * RTg) % 4 == 0) {
+            auto kg = nvec <= 10 ? lsg_fwd_regl_kernel<T, 10, false> : nvec <= 12 ? lsg_fwd_regl_kernel<T, 12, false> : nvec <= 14 ? lsg_fwd_regl_kernel<T, 14, false>
+                                                                                                                       : lsg_fwd_regl_kernel<T, 16, false>;
+            const long nt = (long)B * ((L + RTg - 1) / RTg);
+            const int gridg = (int)(nt < 4096 ? nt : 4096);
+            (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+            hipLaunchKernelGGL(kg, dim3(gridg), dim3(256), ldsg, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss, B, L, V, S, RTg, ws, stats);
+            return check_launch("logsoftmax_gather(reg, LDS gather, wide rows)");
+        }
+    }
     if (vec && nvec <= 8 && S <= 8 * 256) {
-        auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : lsg_fwd_reg_kernel<T, 8>);
+        auto kr = nvec <= 2 ? lsg_fwd_reg_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_reg_kernel<T, 4> : nvec <= 6 ? lsg_fwd_reg_kernel<T, 6> : lsg_fwd_reg_kernel<T, 8>);
         {
             // LDS-gather variant: row image V * sizeof(T) + stage [S][RTg] must leave two workgroups per CU
             static int gl = -1;
@@ -603,7 +622,7 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
             while (RTg > 1 && (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4 > 78 * 1024) RTg >>= 1;
             const size_t ldsg = (size_t)V * sizeof(T) + (32 + (size_t)S * RTg) * 4;
             if (gl && ldsg <= 78 * 1024 && L >= RTg && (S * RTg) % 4 == 0) {
-                auto kg = nvec <= 2 ? lsg_fwd_regl_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_regl_kernel<T, 4> : lsg_fwd_regl_kernel<T, 8>);
+                auto kg = nvec <= 2 ? lsg_fwd_regl_kernel<T, 2> : (nvec <= 4 ? lsg_fwd_regl_kernel<T, 4> : nvec <= 6 ? lsg_fwd_regl_kernel<T, 6> : lsg_fwd_regl_kernel<T, 8>);
                 const long nt = (long)B * ((L + RTg - 1) / RTg);
                 int gridg = (int)(nt < 4096 ? nt : 4096);
                 static const char* const e_grid = getenv("DSP_K1_GRID");        // (tuning switches: read once per process)
@@ -644,13 +663,27 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
     { static const char* const e = getenv("DSP_K1B_LDS"); if (e) { const size_t want = (size_t)atoi(e); if (want > lds) lds = want; } }
     const long nrows = (long)B * L;
     const int nvec = (V + 256 * N - 1) / (256 * N);
+    static const char* const e_old = getenv("DSP_K1B_OLD");
+    if (vec && sizeof(T) == 4 && nvec > 8 && nvec <= 16 && !e_old) {  // wide rows (8 192 < V <= 16 384 fp32): 10-16 vectors per lane, one row ahead (r05)
+        int RT = 16;
+        while (RT > 1 && (16 + (size_t)V + (size_t)S * RT) * sizeof(float) > 76 * 1024) RT >>= 1;
+        const size_t ldsr = (16 + (size_t)V + (size_t)S * RT) * sizeof(float);
+        if (ldsr <= 76 * 1024 && L >= RT) {
+            auto kr = nvec <= 10 ? lsg_bwd_reg_kernel<T, 10, LAZY, 3, false> : nvec <= 12 ? lsg_bwd_reg_kernel<T, 12, LAZY, 3, false>
+                    : nvec <= 14 ? lsg_bwd_reg_kernel<T, 14, LAZY, 3, false> : lsg_bwd_reg_kernel<T, 16, LAZY, 3, false>;
+            const long nt = (long)B * ((L + RT - 1) / RT);
+            const int gridr = (int)(nt < 4096 ? nt : 4096);
+            (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+            hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT, stats);
+            return check_launch("logsoftmax_gather_bwd(reg, wide rows)");
+        }
+    }
     {
         int RT = 16;
         { static const char* const e = getenv("DSP_K1B_RT"); if (e) RT = atoi(e); }
         const size_t ldsr = (16 + (size_t)V + (size_t)S * RT) * sizeof(float);
-        static const char* const e_old = getenv("DSP_K1B_OLD");
         if (vec && nvec <= 8 && ldsr <= 76 * 1024 && L >= RT && !e_old) {     // two workgroups per CU
-            auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2, LAZY> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4, LAZY> : lsg_bwd_reg_kernel<T, 8, LAZY>);
+            auto kr = nvec <= 2 ? lsg_bwd_reg_kernel<T, 2, LAZY> : (nvec <= 4 ? lsg_bwd_reg_kernel<T, 4, LAZY> : nvec <= 6 ? lsg_bwd_reg_kernel<T, 6, LAZY> : lsg_bwd_reg_kernel<T, 8, LAZY>);
             const long nt = (long)B * ((L + RT - 1) / RT);
             int gridr = (int)(nt < 4096 ? nt : 4096);
             { static const char* const e = getenv("DSP_K1B_GRID"); if (e) gridr = atoi(e); }

@@ -175,7 +175,8 @@ def test_invalid_samples_do_not_trap():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("dtype,V", [(torch.float32, 512), (torch.float16, 1000), (torch.bfloat16, 264), (torch.float32, 37)])
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 512), (torch.float16, 1000), (torch.bfloat16, 264), (torch.float32, 37),
+                                     (torch.float32, 9000), (torch.float32, 16384), (torch.float16, 20000), (torch.float32, 8196)])     # r05: wide rows (16 vectors per lane)
 def test_oracle_logsoftmax_gather(dtype, V):
     B, L, T = 3, 50, 17
     rng = np.random.default_rng(V)

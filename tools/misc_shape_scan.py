@@ -12,7 +12,7 @@ def timeit(f, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 print("== gather forward (in-place softmax), fp32 / fp16: ms (TB/s)")
-for V in (8192, 8200, 10000, 12288, 16384, 20000, 32000):
+for V in (4096, 5000, 6000, 8192, 8200, 10000, 12288, 16384, 20000, 32000):
     B, L, S = 16, 2048, 256
     row = []
     for dt in (torch.float32, torch.float16):
