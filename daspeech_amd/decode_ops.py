@@ -112,9 +112,24 @@ def extract_links(q: Tensor, k: Tensor, log_gates: Tensor, output_length: Tensor
     lib = _lib.load()
     with torch.cuda.device(qf.device):
         links = torch.empty((B, L, TR), dtype=torch.float32, device=qf.device)
-        _lib.check(lib.dsp_extract_links(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
-                                         B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links")
+        ws = _links_workspace(lib, B, L, H, CK, TR, 0, qf.device)
+        if ws is not None:                # the matrix-core kernels (csrc/extract_links_mfma.hip)
+            _lib.check(lib.dsp_extract_links_ws(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links), None,
+                                                B, L, H, CK, TR, float(CK) ** -0.5, _lib.ptr(ws), ws.numel(), _lib.current_stream_handle()),
+                       "dsp_extract_links_ws")
+        else:
+            _lib.check(lib.dsp_extract_links(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
+                                             B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links")
     return links
+
+
+def _links_workspace(lib, B: int, L: int, H: int, CK: int, TR: int, phase: int, device) -> Optional[Tensor]:
+    """Scratch for the matrix-core link kernels (phase 0 inference / 1 training forward / 2 backward), or None when the library serves this
+    shape with the fp32-FMA kernels (dsp_extract_links_workspace reports 0 bytes)."""
+    import ctypes
+    n = ctypes.c_size_t(0)
+    _lib.check(lib.dsp_extract_links_workspace(B, L, H, CK, TR, phase, ctypes.byref(n)), "dsp_extract_links_workspace")
+    return torch.empty(n.value, dtype=torch.uint8, device=device) if n.value else None
 
 
 class _ExtractLinksFn(torch.autograd.Function):
@@ -133,9 +148,15 @@ class _ExtractLinksFn(torch.autograd.Function):
         with torch.cuda.device(qf.device):
             links = torch.empty((B, L, TR), dtype=torch.float32, device=qf.device)
             stats = torch.empty((B, L, H, 2), dtype=torch.float32, device=qf.device)
-            _lib.check(lib.dsp_extract_links_train(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
-                                                   _lib.ptr(stats), B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()),
-                       "dsp_extract_links_train")
+            ws = _links_workspace(lib, B, L, H, CK, TR, 1, qf.device)
+            if ws is not None:
+                _lib.check(lib.dsp_extract_links_ws(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
+                                                    _lib.ptr(stats), B, L, H, CK, TR, float(CK) ** -0.5, _lib.ptr(ws), ws.numel(),
+                                                    _lib.current_stream_handle()), "dsp_extract_links_ws")
+            else:
+                _lib.check(lib.dsp_extract_links_train(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias), _lib.ptr(links),
+                                                       _lib.ptr(stats), B, L, H, CK, TR, float(CK) ** -0.5, _lib.current_stream_handle()),
+                           "dsp_extract_links_train")
         ctx.save_for_backward(qf, kf, gf, ol, links, stats, bias if bias is not None else qf.new_empty(0))
         ctx.TR, ctx.has_bias, ctx.in_dtypes = TR, bias is not None, (q.dtype, k.dtype, log_gates.dtype)
         ctx.mark_non_differentiable(output_length)
@@ -150,9 +171,16 @@ class _ExtractLinksFn(torch.autograd.Function):
         with torch.cuda.device(qf.device):
             dq, dk = torch.empty_like(qf), torch.empty_like(kf)
             dg = torch.empty_like(gf)
-            _lib.check(lib.dsp_extract_links_bwd(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias if ctx.has_bias else None),
-                                                 _lib.ptr(links), _lib.ptr(g), _lib.ptr(stats), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dg),
-                                                 B, L, H, CK, ctx.TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links_bwd")
+            ws = _links_workspace(lib, B, L, H, CK, ctx.TR, 2, qf.device)
+            if ws is not None:
+                _lib.check(lib.dsp_extract_links_bwd_ws(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias if ctx.has_bias else None),
+                                                        _lib.ptr(links), _lib.ptr(g), _lib.ptr(stats), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dg),
+                                                        B, L, H, CK, ctx.TR, float(CK) ** -0.5, _lib.ptr(ws), ws.numel(),
+                                                        _lib.current_stream_handle()), "dsp_extract_links_bwd_ws")
+            else:
+                _lib.check(lib.dsp_extract_links_bwd(_lib.ptr(qf), _lib.ptr(kf), _lib.ptr(gf), _lib.ptr(ol), _lib.ptr(bias if ctx.has_bias else None),
+                                                     _lib.ptr(links), _lib.ptr(g), _lib.ptr(stats), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dg),
+                                                     B, L, H, CK, ctx.TR, float(CK) ** -0.5, _lib.current_stream_handle()), "dsp_extract_links_bwd")
         dt = ctx.in_dtypes
         return dq.to(dt[0]), dk.to(dt[1]), dg.to(dt[2]), None, None, None
 

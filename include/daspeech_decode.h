@@ -62,6 +62,24 @@ int dsp_extract_links_bwd(const float* q, const float* k, const float* log_gates
                           float* grad_q, float* grad_k, float* grad_log_gates, int B, int L, int H, int CK, int TR, float scale,
                           dsp_stream_t stream);
 
+/* F0 on the matrix cores (r05; csrc/extract_links_mfma.hip): the same three operators for the released link predictor (H = 8, CK = 64), scores as
+ *   32 x 32 blocks on the fp16 matrix cores with fp32 accuracy (operands split hi + lo 2^-11, three MFMAs per product), the backward's
+ *   contractions on the fp32 matrix-core path; they need a scratch buffer the caller owns (the split k / q rows in MFMA fragment order):
+ *   dsp_extract_links_workspace  bytes for one call (phase 0 = inference forward, 1 = training forward, 2 = backward); 0 bytes = this shape is
+ *                                served by the entry points above (other head widths, short graphs / narrow windows — or option "xl_mfma" 0;
+ *                                "xl_mfma" 1 forces the matrix-core kernels wherever H = 8, CK = 64);
+ *   dsp_extract_links_ws         dsp_extract_links (stats = NULL) / dsp_extract_links_train (stats [B,L,H,2]) — same outputs, same `stats`;
+ *   dsp_extract_links_bwd_ws     dsp_extract_links_bwd.
+ *   B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999): see DESIGN.md §8 for the measured times. */
+int dsp_extract_links_workspace(int B, int L, int H, int CK, int TR, int phase, size_t* bytes);
+int dsp_extract_links_ws(const float* q, const float* k, const float* log_gates, const int64_t* out_len, const float* dist_bias,
+                         float* links, float* stats, int B, int L, int H, int CK, int TR, float scale,
+                         void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+int dsp_extract_links_bwd_ws(const float* q, const float* k, const float* log_gates, const int64_t* out_len, const float* dist_bias,
+                             const float* links, const float* grad_links, const float* stats,
+                             float* grad_q, float* grad_k, float* grad_log_gates, int B, int L, int H, int CK, int TR, float scale,
+                             void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */
 int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream);

@@ -439,17 +439,47 @@ def test_tiled_extract_links_equal_the_one_image_kernels(B, L, CK, TR, lens, til
     from daspeech_amd import _lib
     olen, q0, k0, g0, w, bias = _links_case(B, L, CK, TR, lens, 5)
     try:
+        _lib.set_option("xl_mfma", 0)
         _lib.set_option("xl_tile", 0)
         ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
         _lib.set_option("xl_tile", tile)
         got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
     finally:
         _lib.set_option("xl_tile", 0)
+        _lib.set_option("xl_mfma", -1)
     for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
         assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
         f = torch.isfinite(b)
         sc = max(1.0, float(b[f].abs().max()))
         assert float((a[f] - b[f]).abs().max()) <= 4e-6 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,TR,lens,use_bias", [(2, 150, 149, [150, 97], True), (3, 200, 70, [200, 131, 3], False), (2, 64, 63, [64, 33], True),
+                                                 (2, 65, 7, [65, 64], False), (3, 333, 32, [333, 2, 1], True), (2, 31, 30, [31, 17], False),
+                                                 (2, 513, 512, [513, 400], False), (1, 700, 300, [650], True), (2, 96, 1, [96, 50], False)])
+def test_matrix_core_extract_links_equal_the_fp32_kernels(B, L, TR, lens, use_bias):
+    """r05: csrc/extract_links_mfma.hip (scores on the fp16 matrix cores with split operands, contractions on the fp32 matrix-core path; forced
+    through the xl_mfma option on graphs of every size) against the fp32-FMA kernels of csrc/extract_links.hip: links, soft-max state and all
+    three gradients, inference entry point included; ragged graphs, graph lengths that are not multiples of the 32 / 64-row tiles, narrow and
+    dense windows, graphs of one and two vertices.  The split product is good to 2^-22 of sum |q_c k_c|: <= 1e-5 of the largest value."""
+    from daspeech_amd import _lib
+    olen, q0, k0, g0, w, bias = _links_case(B, L, 64, TR, lens, 9)
+    if not use_bias:
+        bias = None
+    try:
+        _lib.set_option("xl_mfma", 0)
+        ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        _lib.set_option("xl_mfma", 1)
+        got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+    finally:
+        _lib.set_option("xl_mfma", -1)
+    for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
+        assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
+        assert torch.isfinite(a[torch.isfinite(b)]).all(), name
+        f = torch.isfinite(b)
+        sc = max(1.0, float(b[f].abs().max()))
+        assert float((a[f] - b[f]).abs().max()) <= 1e-5 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
 
 
 @pytest.mark.gpu

@@ -15,20 +15,22 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n):
-    B = int(rng.integers(1, 5)); L = int(rng.integers(2, 180))
+    B = int(rng.integers(1, 5)); L = int(rng.integers(2, 180)) if rng.random() < 0.8 else int(rng.integers(180, 420))
     h, ck = [(8, 64), (8, 32), (8, 128)][int(rng.integers(0, 3))]          # (the fused kernel serves 8 heads of 32 / 64 / 128; other geometries raise and the model uses the torch form)
     d = h * ck
     TRmax = int(rng.choice([1, 3, 7, 32, 64, 99999, int(rng.integers(1, L + 5))]))
     scale = float(rng.choice([0.1, 0.3, 1.0]))
     tile = int(rng.choice([0, 0, 32, 64, 128]))                              # r05: the tiled kernels (windows beyond the one-image LDS bound), forced on small graphs
     _lib.set_option("xl_tile", tile)
+    mfma = int(rng.choice([0, 1, 1]))                                        # r05: the matrix-core kernels (8 x 64 heads), forced on graphs of every size
+    _lib.set_option("xl_mfma", mfma)
     feats = rng.standard_normal((B, L, d)).astype(np.float32) * scale
     lens = rng.integers(1, L + 1, B); lens[0] = L
     prev = np.full((B, L), 3, np.int64); prev[np.arange(L)[None] >= lens[:, None]] = PAD
     pos_w = (rng.standard_normal((L + 2, d)) * 0.3).astype(np.float32)
     ws = {k_: (rng.standard_normal((o, 2 * d)) * (0.5 / math.sqrt(d))).astype(np.float32) for k_, o in (("q", d), ("k", d), ("g", h))}
     bs = {k_: (rng.standard_normal(o) * 0.1).astype(np.float32) for k_, o in (("q", d), ("k", d), ("g", h))}
-    tag = f"case {case}: B={B} L={L} heads={h}x{ck} TRmax={TRmax} lens={lens.tolist()} scale={scale} xl_tile={tile}"
+    tag = f"case {case}: B={B} L={L} heads={h}x{ck} TRmax={TRmax} lens={lens.tolist()} scale={scale} xl_tile={tile} xl_mfma={mfma}"
     try:
         want = gorc.extract_links(feats, prev, pos_w, ws["q"], bs["q"], ws["k"], bs["k"], ws["g"], bs["g"], TRmax, h, PAD)
         t = lambda a: torch.from_numpy(a).cuda()
@@ -66,4 +68,5 @@ for case in range(n):
     except Exception as e:   # noqa
         bad += 1; print("FAIL", tag, "->", repr(e)[:300])
 _lib.set_option("xl_tile", 0)
+_lib.set_option("xl_mfma", -1)
 print(f"{n} cases, {bad} failures")
