@@ -261,6 +261,40 @@ def make_dag_inputs(torch, dev, B, L, T, V, TR, seed, peaked=False):
     return logits, links, out_len, tgt_len, tgt
 
 
+def run_links_ops(ctx, B, L, TR, steps, warmup, seed):
+    """The transition producer in front of the DP (DAGDecoder.extract_links, s2t_conformer_dag.py:171-212) at the DP leg's graph: the released
+    link predictor's geometry (8 heads x 64), random q / k / gates.  HIP-event ms of the inference call and of forward + backward under autograd."""
+    torch = ctx.torch
+    from daspeech_amd import decode_ops
+    dev = ctx.dev
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    q0 = torch.randn(B, L, 8, 64, device=dev, generator=g) * 0.5
+    k0 = torch.randn(B, L, 8, 64, device=dev, generator=g) * 0.5
+    lg = torch.log_softmax(torch.randn(B, L, 8, device=dev, generator=g), -1)
+    olen = torch.full((B,), L, device=dev, dtype=torch.long)
+    w = torch.randn(B, L, TR, device=dev, generator=g)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    def infer():
+        with torch.no_grad():
+            decode_ops.extract_links(q0, k0, lg, olen, TR)
+
+    def train():
+        q, k, gt = q0.detach().requires_grad_(), k0.detach().requires_grad_(), lg.detach().requires_grad_()
+        decode_ops.extract_links_autograd(q, k, gt, olen, TR).backward(w)
+
+    return {"links_fwd_ms": timed(infer), "links_fwd_bwd_ms": timed(train)}
+
+
 def run_dag_ops(ctx, B, L, T, V, TR, steps, warmup, seed, peaked=False, lazy=False, fresh=True):
     """K passes of the DAG hot path; returns per-phase HIP-event times (ms) and the wall time of the passes."""
     torch = ctx.torch
@@ -702,6 +736,13 @@ def main():
                                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (pf["dag_fwd"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None}
                 tr_full["alignment_roofline"] = {"bound": "valu", "kernel": "dag_dense_max (max-plus products) + block back-trace", "pair_ops": fl / 4.0,
                                                  "achieved_Gpairs_per_s": fl / 4.0 / (pf["best_alignment"] * 1e-3) / 1e9}
+                # the producer of that window's transitions (extract_links, 8 heads x 64) on the same graph: inference call, forward + backward
+                ctx.torch.cuda.empty_cache()
+                lk = run_links_ops(ctx, args.dag_batch, args.graph_len, args.graph_len - 1, 3, 1, 91 + rank)
+                tr_full["extract_links"] = {"workload": f"extract_links (8 heads x 64) B={args.dag_batch}, graph_len={args.graph_len}, TR={args.graph_len - 1}: "
+                                                        "inference call / forward + backward under autograd", **lk,
+                                            "links_bytes": 4.0 * args.dag_batch * args.graph_len * (args.graph_len - 1),
+                                            "score_flop": 2.0 * args.dag_batch * 8 * 64 * Lf * (Lf - 1) / 2}
             except Exception as e:      # noqa: a leg of its own, the headline does not depend on it
                 tr_full = {"error": repr(e)[:200]}
         # 32 < TR <= 64 is served by the older banded kernels (dag_dp_banded / strip2): one number for that window too
