@@ -152,6 +152,8 @@ int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_
  *   "dx_mt" 0|1|2 (r05): rows per chunk of the dense max-plus alignment kernel in 16-row tiles (0 = auto: 2 for launches of >= 6 rounds of
  *   workgroups); bit-identical paths.  "xl_tile" n (r05): n > 0 forces the TILED extract_links kernels (include/daspeech_decode.h) with a tile
  *   of n slots on any window — by default they serve the windows whose one-image score tile does not fit LDS (TR above ~1100).
+ *   "xl_mfma" -1|0|1 (r05): the matrix-core extract_links kernels (dsp_extract_links_ws / _bwd_ws) by size | never | wherever H = 8, CK = 64
+ *   — it steers what dsp_extract_links_workspace reports.
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);
