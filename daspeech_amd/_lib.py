@@ -38,6 +38,9 @@ SIGNATURES = {
     "dsp_dag_best_alignment_ws": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     "dsp_dag_max_alpha": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_backtrace": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_max_alpha_blocks_supported": (_c_int, [_c_int, _c_int]),
+    "dsp_dag_max_alpha_blocks": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_backtrace_blocks": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     # include/daspeech_decode.h
     "dsp_argmax_logp": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_lookahead_next": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p]),

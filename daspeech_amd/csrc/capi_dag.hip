@@ -45,7 +45,8 @@ size_t dense_rows_gated_bytes(int B, int L, int ndir);
 bool dense_rows_gated_supported(int L);
 
 bool dense_max_supported(int L, int TR);
-int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
+int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t, unsigned short* block_trace = nullptr);
+int launch_dag_dense_backtrace(const float*, const unsigned short*, const float*, const int64_t*, const int64_t*, int64_t*, int, int, int, int, hipStream_t);
 
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
@@ -223,6 +224,33 @@ extern "C" int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, c
     if (B == 0) return DSP_OK;
     if (!trace || !out_len || !tgt_len || !path) { set_error("dag_backtrace: null pointer"); return DSP_EINVAL; }
     return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, as_stream(stream));
+}
+
+// The same two halves on the dense-window kernels (blocked max-plus DP, 2-byte block trace, back-trace that recomputes the arg-max of the cells
+// it visits): what the Viterbi graph decode runs when the window is wider than 32 (the model's default: --max-transition-length 99999).
+extern "C" int dsp_dag_max_alpha_blocks_supported(int L, int TR) { return ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR)) ? 1 : 0; }
+
+extern "C" int dsp_dag_max_alpha_blocks(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                        float* alpha_max, uint16_t* block_trace, int B, int T, int L, int TR, dsp_stream_t stream)
+{
+    int rc = check_dims("dag_max_alpha_blocks", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!match || !links || !out_len || !tgt_len || !alpha_max || !block_trace) { set_error("dag_max_alpha_blocks: null pointer"); return DSP_EINVAL; }
+    if (!dense_max_supported(L, TR)) { set_error("dag_max_alpha_blocks: L=%d TR=%d is not a dense-window shape (see dsp_dag_max_alpha_blocks_supported)", L, TR); return DSP_EINVAL; }
+    CallerWsScope ws_scope(nullptr, 0, as_stream(stream));
+    return launch_dag_dense_max(match, links, out_len, tgt_len, alpha_max, nullptr, B, T, L, TR, as_stream(stream), block_trace);
+}
+
+extern "C" int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace, const float* links, const int64_t* out_len,
+                                        const int64_t* tgt_len, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream)
+{
+    int rc = check_dims("dag_backtrace_blocks", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!alpha_max || !block_trace || !links || !out_len || !tgt_len || !path) { set_error("dag_backtrace_blocks: null pointer"); return DSP_EINVAL; }
+    if (!dense_max_supported(L, TR)) { set_error("dag_backtrace_blocks: L=%d TR=%d is not a dense-window shape", L, TR); return DSP_EINVAL; }
+    return launch_dag_dense_backtrace(alpha_max, block_trace, links, out_len, tgt_len, path, B, T, L, TR, as_stream(stream));
 }
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)

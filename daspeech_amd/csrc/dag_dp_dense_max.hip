@@ -451,8 +451,13 @@ void set_dx_mt(int v) { g_dx_mt = (v == 1 || v == 2) ? v : 0; }
 
 bool dense_max_supported(int L, int TR) { return TR > 32 && L >= 128 && (size_t)L * 4 <= 150 * 1024 && (long)L * TR < (1L << 31); }
 
+static int launch_dense_backtrace(const float* alpha_max, const unsigned short* btrace, const float* links, const int64_t* out_len,
+                                  const int64_t* tgt_len, int64_t* path, int B, int T, int L, int TR, hipStream_t st);
+
+// block_trace != NULL: the caller keeps the [B,T,L] block trace (the two halves of the alignment run as separate calls: Viterbi graph decode
+// chooses the length between them) and path may be NULL (no back-trace here); NULL: the trace lives in the launch workspace.
 int launch_dag_dense_max(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                         float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+                         float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st, unsigned short* block_trace)
 {
     const int NJ = (L + DX_BW - 1) / DX_BW;
     DXParams p;
@@ -460,13 +465,13 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     p.B = B; p.T = T; p.L = L; p.TR = TR; p.NJ = NJ;
     const size_t prog_bytes = ((size_t)B * NJ * sizeof(u32) + 255) / 256 * 256;
     const size_t s_bytes = ((size_t)B * T * NJ * sizeof(float) + 255) / 256 * 256;
-    const size_t bt_bytes = (size_t)B * T * L * sizeof(unsigned short);
+    const size_t bt_bytes = block_trace ? 0 : (size_t)B * T * L * sizeof(unsigned short);
     u64* area = nullptr;
     int rc = banded_acquire_ws(st, prog_bytes + s_bytes + bt_bytes, T, &p.counters, &area, &p.tag_base);
     if (rc) return rc;
     p.progress = reinterpret_cast<u32*>(area);
     p.S = reinterpret_cast<float*>(reinterpret_cast<char*>(area) + prog_bytes);
-    p.btrace = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(area) + prog_bytes + s_bytes);
+    p.btrace = block_trace ? block_trace : reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(area) + prog_bytes + s_bytes);
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -481,15 +486,28 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");
-    if (rc) return rc;
+    if (rc || !path) return rc;
+    return launch_dense_backtrace(alpha_max, p.btrace, links, out_len, tgt_len, path, B, T, L, TR, st);
+}
+
+static int launch_dense_backtrace(const float* alpha_max, const unsigned short* btrace, const float* links, const int64_t* out_len,
+                                  const int64_t* tgt_len, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+{
     // LDS ring of (alpha row, block-trace row) pairs for the back-trace: as deep as fits (5 at L = 4096), none beyond L ~ 9000
     int ring = 5;
     while (ring > 1 && (size_t)L * 4 + (size_t)ring * L * 6 > 150 * 1024) --ring;
     if (ring < 3 || L > 48 * 192) ring = 0;
     const size_t lds2 = (size_t)L * 4 + (size_t)ring * L * 6;
     (void)hipFuncSetAttribute((const void*)dag_dense_backtrace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(dag_dense_backtrace_blk_kernel, dim3((unsigned)B), dim3(256), lds2, st, alpha_max, p.btrace, links, out_len, tgt_len, path, B, T, L, TR, ring);
+    hipLaunchKernelGGL(dag_dense_backtrace_blk_kernel, dim3((unsigned)B), dim3(256), lds2, st, alpha_max, btrace, links, out_len, tgt_len, path, B, T, L, TR, ring);
     return check_launch("dag_best_alignment(dense back-trace)");
+}
+
+// the second half alone: tgt_len may differ from the one the max-DP ran with (any row it filled)
+int launch_dag_dense_backtrace(const float* alpha_max, const unsigned short* block_trace, const float* links, const int64_t* out_len,
+                               const int64_t* tgt_len, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+{
+    return launch_dense_backtrace(alpha_max, block_trace, links, out_len, tgt_len, path, B, T, L, TR, st);
 }
 
 }  // namespace dsp

@@ -351,20 +351,31 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
     links_c = links.float().contiguous()
     rows = torch.full((B,), T, dtype=torch.int64, device=dev)
     amax = torch.empty((B, T, L), dtype=torch.float32, device=dev)
-    trace = torch.empty((B, T, L), dtype=torch.int32, device=dev)
     lib = _lib.load()
+    # windows wider than 32 (the model's default): the blocked max-plus DP + block trace of the dense-window alignment kernels; narrow windows
+    # keep the row-sequential DP with its arg-max trace.  alpha_max, tie rule and therefore tokens / lengths are the same either way.
+    blocks = bool(lib.dsp_dag_max_alpha_blocks_supported(L, TR))
+    trace = torch.empty((B, T, L), dtype=torch.int16 if blocks else torch.int32, device=dev)
     with torch.cuda.device(dev):
         st = _lib.current_stream_handle()
-        _lib.check(lib.dsp_dag_max_alpha(_lib.ptr(match), _lib.ptr(links_c), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(amax), _lib.ptr(trace),
-                                         B, T, L, TR, st), "dsp_dag_max_alpha")
+        if blocks:
+            _lib.check(lib.dsp_dag_max_alpha_blocks(_lib.ptr(match), _lib.ptr(links_c), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(amax), _lib.ptr(trace),
+                                                    B, T, L, TR, st), "dsp_dag_max_alpha_blocks")
+        else:
+            _lib.check(lib.dsp_dag_max_alpha(_lib.ptr(match), _lib.ptr(links_c), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(amax), _lib.ptr(trace),
+                                             B, T, L, TR, st), "dsp_dag_max_alpha")
         best = amax[ar, 2:, (olen - 1).clamp(min=0)]                     # [B, M]: best score of every length (:267-269)
         lengths = (torch.arange(max_length, device=dev) + 1).unsqueeze(0).float()
         _, pred_length = torch.max(best / lengths ** decode_viterbibeta, dim=1)
         pred_length = pred_length + 1                                    # (:275-276)
         path = torch.empty((B, L), dtype=torch.int64, device=dev)
         start_rows = (pred_length + 2).contiguous()                       # bound to a name: must outlive the launch
-        _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr(start_rows), _lib.ptr(path), B, T, L, st),
-                   "dsp_dag_backtrace")
+        if blocks:
+            _lib.check(lib.dsp_dag_backtrace_blocks(_lib.ptr(amax), _lib.ptr(trace), _lib.ptr(links_c), _lib.ptr(olen), _lib.ptr(start_rows), _lib.ptr(path),
+                                                    B, T, L, TR, st), "dsp_dag_backtrace_blocks")
+        else:
+            _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr(start_rows), _lib.ptr(path), B, T, L, st),
+                       "dsp_dag_backtrace")
     # vertices visited at DP rows 1 .. pred_length, in graph order (= the reference's reversed back-trace, :283-290)
     on = (path >= 1) & (path <= pred_length.unsqueeze(1))
     # the final vertex is out of reach within max_length steps (a window far narrower than the model's: L / 4 steps of at most TR

@@ -133,6 +133,16 @@ int dsp_dag_max_alpha(const float* match, const float* links, const int64_t* out
 int dsp_dag_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L,
                       dsp_stream_t stream);
 
+/* The same two halves on the dense-window kernels (TR > 32 — the model's default window, --max-transition-length 99999): the max-DP as blocked
+ * max-plus products (alpha_max bit-identical to dsp_dag_max_alpha) leaving a 2-byte BLOCK trace [B,T,L] instead of the 4-byte arg-max trace, and a
+ * back-trace that recomputes the arg-max of the cells it visits from alpha_max, the block trace and the links (same tie rule: smallest index).
+ * dsp_dag_max_alpha_blocks_supported(L, TR) tells whether a shape is served (1) or needs dsp_dag_max_alpha / dsp_dag_backtrace (0). */
+int dsp_dag_max_alpha_blocks_supported(int L, int TR);
+int dsp_dag_max_alpha_blocks(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                             float* alpha_max, uint16_t* block_trace, int B, int T, int L, int TR, dsp_stream_t stream);
+int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace, const float* links, const int64_t* out_len,
+                             const int64_t* tgt_len, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family FOR THE CALLING THREAD: 0 = auto, 1 = generic row-sequential /

@@ -315,6 +315,42 @@ def test_viterbi_decode_hip_matches_reference_loop_restatement(shape, joint):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[1], ref[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 30, 200, 199), (2, 52, 390, 64), (4, 12, 128, 127), (2, 130, 1030, 1029)])
+def test_two_half_alignment_on_the_dense_kernels_equals_the_trace_form(shape):
+    """dsp_dag_max_alpha_blocks / dsp_dag_backtrace_blocks (blocked max-plus DP + 2-byte block trace; what Viterbi decode runs for windows wider
+    than 32) against dsp_dag_max_alpha / dsp_dag_backtrace (row-sequential DP + 4-byte arg-max trace): alpha_max bit-identical on every cell,
+    and the same path from EVERY start row (the decode picks the row after the DP), ragged graphs, quantised weights that force ties."""
+    import ctypes
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    g = torch.Generator().manual_seed(5 + L)
+    match = (torch.round(torch.randn(B, T, L, generator=g) * 4) / 4).cuda()
+    out_len = torch.randint(max(T + 2, L - 40), L + 1, (B,), generator=g); out_len[0] = L
+    raw = torch.round(torch.randn(B, L, TR, generator=g) * 4) / 4
+    i = torch.arange(L).view(1, L, 1); d = torch.arange(TR).view(1, 1, TR)
+    valid = (i + d + 1) < out_len.view(B, 1, 1)
+    links = raw.masked_fill(~valid, float("-inf")).cuda().contiguous()
+    olen = out_len.cuda()
+    rows = torch.full((B,), T, dtype=torch.int64, device="cuda")
+    lib = _lib.load()
+    assert lib.dsp_dag_max_alpha_blocks_supported(L, TR) == 1 and lib.dsp_dag_max_alpha_blocks_supported(L, 32) == 0
+    st = _lib.current_stream_handle()
+    a0 = torch.empty(B, T, L, device="cuda"); tr0 = torch.empty(B, T, L, dtype=torch.int32, device="cuda")
+    a1 = torch.empty(B, T, L, device="cuda"); tr1 = torch.empty(B, T, L, dtype=torch.int16, device="cuda")
+    _lib.check(lib.dsp_dag_max_alpha(_lib.ptr(match), _lib.ptr(links), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(a0), _lib.ptr(tr0), B, T, L, TR, st), "max_alpha")
+    _lib.check(lib.dsp_dag_max_alpha_blocks(_lib.ptr(match), _lib.ptr(links), _lib.ptr(olen), _lib.ptr(rows), _lib.ptr(a1), _lib.ptr(tr1), B, T, L, TR, st), "max_alpha_blocks")
+    assert torch.equal(a0, a1)
+    for start in (T, T - 1, max(2, T // 2), 2):
+        sr = torch.full((B,), start, dtype=torch.int64, device="cuda"); sr[-1] = max(2, start - 1)
+        p0 = torch.empty(B, L, dtype=torch.int64, device="cuda"); p1 = torch.empty_like(p0)
+        _lib.check(lib.dsp_dag_backtrace(_lib.ptr(tr0), _lib.ptr(olen), _lib.ptr(sr), _lib.ptr(p0), B, T, L, st), "backtrace")
+        _lib.check(lib.dsp_dag_backtrace_blocks(_lib.ptr(a1), _lib.ptr(tr1), _lib.ptr(links), _lib.ptr(olen), _lib.ptr(sr), _lib.ptr(p1), B, T, L, TR, st), "backtrace_blocks")
+        reach = torch.isfinite(a0[torch.arange(B), sr - 1, olen - 1])
+        assert reach.any() or start < T            # (a short walk cannot cross a banded graph: nothing to compare for that start row)
+        assert torch.equal(p0[reach], p1[reach]), start
+
+
 @pytest.mark.parametrize("shape", [(3, 77, 64, 31), (2, 5, 256, 31), (1, 200, 8, 3), (4, 33, 128, 15), (2, 64, 32, 7)])
 def test_dwconv_bn_silu_matches_torch_module_chain(shape):
     """dsp_dwconv_bn_silu (channels-last, one pass) vs the torch chain it replaces in the Conformer convolution module in eval mode:
