@@ -336,8 +336,8 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
     B, L, V = logits.shape
     TR = links.shape[2]
     dev = logits.device
-    logp = torch.log_softmax(logits.float(), dim=-1)
-    sc, tok = logp.max(dim=-1)                                           # unreduced_logits / unreduced_tokens (:207-208)
+    tok32, sc = argmax_logp(logits)                                       # unreduced_logits / unreduced_tokens (:207-208), one pass over the logits
+    tok = tok32.to(torch.int64)
     max_length = max(1, int(L / 8 / src_upsample_scale))                 # (:256)
     T = max_length + 2
     olen = output_length.to(torch.int64).contiguous()
@@ -389,7 +389,7 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
     # token kept if it is the LAST visited vertex, or (not pad and differs from the next visited token)   (:291-299, backward order)
     vis_idx = torch.argsort((~on).to(torch.int8), dim=1, stable=True)   # visited vertices first, ascending
     n_vis = on.sum(1)
-    Pm = int(n_vis.max().item()) if B else 0
+    Pm = min(L, max_length)                                              # at most one vertex per DP row (no host round trip for the exact maximum)
     vpath = vis_idx[:, :Pm]
     vvalid = torch.arange(Pm, device=dev).unsqueeze(0) < n_vis.unsqueeze(1)
     ptok = tok.gather(1, vpath)
