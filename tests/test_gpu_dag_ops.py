@@ -176,7 +176,8 @@ def test_invalid_samples_do_not_trap():
 
 
 @pytest.mark.parametrize("dtype,V", [(torch.float32, 512), (torch.float16, 1000), (torch.bfloat16, 264), (torch.float32, 37),
-                                     (torch.float32, 9000), (torch.float32, 16384), (torch.float16, 20000), (torch.float32, 8196)])     # r05: wide rows (16 vectors per lane)
+                                     (torch.float32, 9000), (torch.float32, 16384), (torch.float16, 20000), (torch.float32, 8196),      # r05: wide rows (16 vectors per lane)
+                                     (torch.float16, 6004), (torch.float32, 10001), (torch.bfloat16, 1003)])                            # r05: rows off the 16-byte grid (peeled head / tail)
 def test_oracle_logsoftmax_gather(dtype, V):
     B, L, T = 3, 50, 17
     rng = np.random.default_rng(V)
