@@ -70,6 +70,8 @@ int dsp_extract_links_bwd(const float* q, const float* k, const float* log_gates
  *                                "xl_mfma" 1 forces the matrix-core kernels wherever H = 8, CK = 64);
  *   dsp_extract_links_ws         dsp_extract_links (stats = NULL) / dsp_extract_links_train (stats [B,L,H,2]) — same outputs, same `stats`;
  *   dsp_extract_links_bwd_ws     dsp_extract_links_bwd.
+ *   Operand range: the split keeps k and q * scale * log2(e) as fp16 pairs — finite for |k|, |q| * 0.18 < 65 504 (the link predictor's
+ *   projections are O(1..10)); beyond that the scores become inf / NaN where the fp32-FMA entry points above still work.
  *   B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999): see DESIGN.md §8 for the measured times. */
 int dsp_extract_links_workspace(int B, int L, int H, int CK, int TR, int phase, size_t* bytes);
 int dsp_extract_links_ws(const float* q, const float* k, const float* log_gates, const int64_t* out_len, const float* dist_bias,
