@@ -6,7 +6,7 @@
 // matrix cores with fp32 accuracy ("3 x fp16": x = xh + xl 2^-11, three MFMAs per product, see conv1d_split.hip / attention_split.hip), and the
 // backward's contractions  dq = ds . K,  dk = ds^T . Q  run on the fp32 matrix-core path (v_mfma_f32_32x32x2_f32: exact fp32 products, no range
 // assumption on the incoming gradient).  B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999), ms:
-// inference 31.8 -> 3.0, forward + backward under autograd 44.7 -> 15.8; L = 1024: 1.83 -> 0.30, 2.9 -> 1.4; L = 400: 0.26 -> 0.09, 0.56 -> 0.37
+// inference 31.8 -> 3.0, forward + backward under autograd 43.2 -> 14.3; L = 1024: 1.83 -> 0.30, 2.8 -> 1.3; L = 400: 0.26 -> 0.09, 0.54 -> 0.33
 // (tools/xl_mfma_time.py, profiles/r05_links_matrix_core.txt).
 //
 // Decomposition: a workgroup is 8 waves = the 8 heads of a tile of OWNER rows (32 or 64 source vertices i; for dk: successors j); a lane owns
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
 
     // ---- LDS
     float* img = reinterpret_cast<float*>(xm_smem);                                     // EMIT: [2][8 heads][OT][PITCH]
-    float* stg = reinterpret_cast<float*>(xm_smem);                                     // BWD:  [2][links, G][OT][PITCH]  (owner-major in both directions)
+    float* stg = reinterpret_cast<float*>(xm_smem);                                     // BWD:  [4 slots][links, G][OT][PITCH]  (owner-major in both directions); two tiles are staged per barrier
     constexpr int STG_ONE = OT * XM_PITCH;
-    float4* tab = reinterpret_cast<float4*>(xm_smem + 2 * 2 * STG_ONE * sizeof(float));    // DK: [2][32 partners][8 heads] (ca, cp, SA, -)
+    float4* tab = reinterpret_cast<float4*>(xm_smem + 4 * 2 * STG_ONE * sizeof(float));    // DK: [4 slots][32 partners][8 heads] (ca, cp, SA, -)
 
     // buffer descriptors over this sample's blocks (32-bit offsets, hardware bounds check: rows past the sample read 0)
     const __amdgpu_buffer_rsrc_t r_par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAR + (size_t)b * L * rs), 0, (int)((size_t)L * rs * 4), 0x00020000);
@@ -172,9 +172,11 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
     const int xa_voff = (int)(((size_t)(4 * g) * rs + h * XM_CK + col) * 4);
 
     // staging registers (one tile ahead)
-    float r_lkv[BWD ? NST : 1], r_gv[BWD ? NST : 1];
-    float4 r_tab = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto stage_load = [&](int t) {
+    float r_lkv2[2][BWD ? NST : 1], r_gv2[2][BWD ? NST : 1];
+    float4 r_tab2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto stage_load = [&](int t, auto which_tag) {
+        constexpr int W = decltype(which_tag)::value;
+        float (&r_lkv)[BWD ? NST : 1] = r_lkv2[W]; float (&r_gv)[BWD ? NST : 1] = r_gv2[W]; float4& r_tab = r_tab2[W];
         if constexpr (BWD) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
@@ -203,7 +205,9 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
             }
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, auto which_tag) {
+        constexpr int W = decltype(which_tag)::value;
+        const float (&r_lkv)[BWD ? NST : 1] = r_lkv2[W]; const float (&r_gv)[BWD ? NST : 1] = r_gv2[W]; const float4& r_tab = r_tab2[W];
         if constexpr (BWD) {
             float* s_lk = stg + (size_t)buf * 2 * STG_ONE; float* s_g = s_lk + STG_ONE;
 #pragma unroll
@@ -322,12 +326,19 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
 
     auto step = [&](int n, xm_h8 (&cur)[8], xm_h8 (&nxt)[8]) {
         const int t = tile_of(n);
-        const int buf = n & 1;
+        const int buf = BWD ? (n & 3) : (n & 1);
         const bool live_tile = n < nlive;
-        if (live_tile) stage_store(buf);
-        if constexpr (BWD) __syncthreads();
+        if constexpr (BWD) {
+            if ((n & 1) == 0) {                         // one barrier per PAIR of tiles: both tiles' links / G (and DK's partner table) go to LDS together
+                if (n < nlive) stage_store(n & 3, std::integral_constant<int, 0>{});
+                if (n + 1 < nlive) stage_store((n + 1) & 3, std::integral_constant<int, 1>{});
+                __syncthreads();
+                if (n + 2 < nlive) stage_load(tile_of(n + 2), std::integral_constant<int, 0>{});
+                if (n + 3 < nlive) stage_load(tile_of(n + 3), std::integral_constant<int, 1>{});
+            }
+        }
         if (live_tile) {
-            if (n + 1 < nlive) { frag_load(tile_of(n + 1), nxt); stage_load(tile_of(n + 1)); }
+            if (n + 1 < nlive) frag_load(tile_of(n + 1), nxt);
             float xa[CONTRACT ? 32 : 1];
             if constexpr (CONTRACT) {
                 // the partner rows in fp32 for the contraction: lane (col = channel, g) <-> row 8 j' + 4 g + e of the tile
@@ -375,7 +386,8 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
             }
         }
     };
-    if (nlive > 0) { frag_load(tile_of(0), fa); stage_load(tile_of(0)); }
+    if (nlive > 0) { frag_load(tile_of(0), fa); stage_load(tile_of(0), std::integral_constant<int, 0>{}); }
+    if (nlive > 1) stage_load(tile_of(1), std::integral_constant<int, 1>{});
     for (int n = 0; n < nstep; n += 2) {
         step(n, fa, fb);
         if (n + 1 < nstep) step(n + 1, fb, fa);
@@ -425,7 +437,7 @@ static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
     constexpr int OT = 32 * QG;
     size_t lds = 16;
     if (MODE == XM_EMIT) lds = (size_t)2 * XM_H * OT * XM_PITCH * sizeof(float);
-    else if (MODE >= XM_SA) lds = (size_t)2 * 2 * OT * XM_PITCH * sizeof(float) + (MODE == XM_DK ? 2 * 256 * sizeof(float4) : 0);
+    else if (MODE >= XM_SA) lds = (size_t)4 * 2 * OT * XM_PITCH * sizeof(float) + (MODE == XM_DK ? 4 * 256 * sizeof(float4) : 0);
     auto k = xl_mfma_kernel<MODE, QG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.L + OT - 1) / OT) * p.B)), dim3(512), lds, st, p);
