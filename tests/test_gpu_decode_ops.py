@@ -519,6 +519,42 @@ def test_matrix_core_extract_links_equal_the_fp32_kernels(B, L, TR, lens, use_bi
 
 
 @pytest.mark.gpu
+def test_matrix_core_extract_links_at_baseline_graph_size():
+    """BASELINE's graph (L = 4096) with the README's dense window (TR = L-1), B = 8 ragged samples: the dispatch must pick the matrix-core kernels
+    by itself; size-independent properties (every row with a successor is a distribution over its valid transitions; the -inf pattern is the
+    band / graph mask) and the full tensors — links and all three gradients — against the fp32-FMA kernels on the same inputs."""
+    import ctypes
+    from daspeech_amd import _lib
+    B, L = 8, 4096
+    TR = L - 1
+    lens = [4096, 4000, 3333, 2048, 1025, 64, 2, 1]
+    olen, q0, k0, g0, w, _ = _links_case(B, L, 64, TR, lens, 21)
+    w = w / L
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.load().dsp_extract_links_workspace(B, L, 8, 64, TR, 0, ctypes.byref(n)), "workspace")
+    assert n.value > 0, "the dispatch did not choose the matrix-core kernels for BASELINE's graph"
+    got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, None)
+    links = got[0]
+    i = torch.arange(L, device="cuda").view(1, L, 1); d = torch.arange(TR, device="cuda").view(1, 1, TR)
+    valid = (i + d + 1) < olen.view(B, 1, 1)
+    assert torch.equal(torch.isfinite(links), valid)
+    rows = valid.any(-1)
+    lse = torch.logsumexp(links.masked_fill(~valid, float("-inf"))[rows], -1)
+    assert float(lse.abs().max()) <= 1e-4, float(lse.abs().max())
+    del valid, i, d, lse
+    try:
+        _lib.set_option("xl_mfma", 0)
+        ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, None)
+    finally:
+        _lib.set_option("xl_mfma", -1)
+    for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
+        assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
+        f = torch.isfinite(b)
+        sc = max(1.0, float(b[f].abs().max()))
+        assert float((a[f] - b[f]).abs().max()) <= 2e-5 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
+
+
+@pytest.mark.gpu
 def test_extract_links_wide_window_stays_on_the_hip_path():
     """A window the one-image kernels cannot hold (L = 1500, TR = 1499: a 768 KB score image) — r04 sent it to the torch band formulation.
     Forward and backward through the model's own dispatch against that formulation; the tiled kernels must be the ones that ran."""
