@@ -45,6 +45,7 @@ SIGNATURES = {
     "dsp_argmax_logp": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_lookahead_next": (_c_int, [_c_p, _c_p, ctypes.c_float, _c_int, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_follow_path": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_viterbi_collect": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_gather_rows": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_extract_links": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),
     "dsp_extract_links_train": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p]),

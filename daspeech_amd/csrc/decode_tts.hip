@@ -394,6 +394,82 @@ extern "C" int dsp_lookahead_next(const float* links, const float* score, float 
     return check_launch("lookahead_next");
 }
 
+// F3a' — the token pass of the Viterbi strategies (s2s_conformer_dag_fastspeech2.py:283-299): the vertices the back-trace visited at DP rows
+// 1 .. pred_length, in graph order; a token is kept if it is the LAST visited one, or (not <pad> and different from the token of the next
+// visited vertex).  One workgroup per sample: thread = a contiguous chunk of vertices; the "next visited token" of a chunk's last visited
+// vertex is the first visited token of the chunks behind it (one serial pass over 256 chunk heads), the compaction an exclusive scan of
+// the per-chunk counts.  unreach[b] != 0: the final vertex was out of reach for every length — the reference's arg-maxes all return
+// index 0 and it emits the token of vertex 0 (reproduced).
+__global__ __launch_bounds__(256) void viterbi_collect_kernel(const int64_t* __restrict__ path, const int64_t* __restrict__ pred_len,
+                                                              const unsigned char* __restrict__ unreach, const int32_t* __restrict__ tok, int pad,
+                                                              int64_t* __restrict__ out_tokens, int32_t* __restrict__ keep_idx, int32_t* __restrict__ n_keep,
+                                                              int L, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t vc_smem[];
+    int32_t* tk = vc_smem;                         // [L] token of a visited vertex, SENT otherwise
+    __shared__ int32_t head[256], cnt[256], carry[256];
+    constexpr int32_t SENT = -12345;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long pl = pred_len[b];
+    const bool un = unreach[b] != 0;
+    for (int j = tid; j < L; j += 256) {
+        const long pv = path[(size_t)b * L + j];
+        const bool on = un ? (j == 0) : (pv >= 1 && pv <= pl);
+        tk[j] = on ? tok[(size_t)b * L + j] : SENT;
+    }
+    __syncthreads();
+    const int per = (L + 255) / 256, j0 = tid * per, j1 = min(L, j0 + per);
+    int32_t first = SENT;
+    for (int j = j0; j < j1; ++j) if (tk[j] != SENT) { first = tk[j]; break; }
+    head[tid] = first;
+    __syncthreads();
+    if (tid == 0) {                                // carry[c] = first visited token of the chunks behind c
+        int32_t nx = SENT;
+        for (int c = 255; c >= 0; --c) { carry[c] = nx; if (head[c] != SENT) nx = head[c]; }
+    }
+    __syncthreads();
+    // backward over the chunk (the decision needs the NEXT visited token): count first, emit in a second identical walk
+    int32_t nx = carry[tid];
+    int kept = 0;
+    for (int j = j1 - 1; j >= j0; --j) {
+        const int32_t t = tk[j];
+        if (t == SENT) continue;
+        if (nx == SENT || (t != pad && t != nx)) ++kept;
+        nx = t;
+    }
+    cnt[tid] = kept;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int c = 0; c < 256; ++c) { const int k = cnt[c]; cnt[c] = run; run += k; } n_keep[b] = run < cap ? run : cap; head[0] = run; }
+    __syncthreads();
+    const int total = head[0];
+    // forward emission needs the decisions in forward order: walk backward again, writing at base + kept - 1 downwards
+    int pos = cnt[tid] + kept - 1;
+    nx = carry[tid];
+    for (int j = j1 - 1; j >= j0; --j) {
+        const int32_t t = tk[j];
+        if (t == SENT) continue;
+        if (nx == SENT || (t != pad && t != nx)) {
+            if (pos < cap) { out_tokens[(size_t)b * cap + pos] = t; keep_idx[(size_t)b * cap + pos] = j; }
+            --pos;
+        }
+        nx = t;
+    }
+    for (int e = min(total, cap) + tid; e < cap; e += 256) { out_tokens[(size_t)b * cap + e] = pad; keep_idx[(size_t)b * cap + e] = -1; }
+}
+
+extern "C" int dsp_viterbi_collect(const int64_t* path, const int64_t* pred_length, const unsigned char* unreachable, const int32_t* tok, int pad,
+                                   int64_t* out_tokens, int32_t* keep_idx, int32_t* n_keep, int B, int L, int cap, dsp_stream_t stream)
+{
+    if (B < 0 || L < 1 || cap < 1) { set_error("viterbi_collect: bad sizes"); return DSP_EINVAL; }
+    if (B == 0) return DSP_OK;
+    if (!path || !pred_length || !unreachable || !tok || !out_tokens || !keep_idx || !n_keep) { set_error("viterbi_collect: null pointer"); return DSP_EINVAL; }
+    const size_t lds = (size_t)L * sizeof(int32_t);
+    if (lds > 150 * 1024) { set_error("viterbi_collect: L=%d too large for the LDS token image", L); return DSP_EINVAL; }
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)viterbi_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(viterbi_collect_kernel, dim3(B), dim3(256), lds, as_stream(stream), path, pred_length, unreachable, tok, pad, out_tokens, keep_idx, n_keep, L, cap);
+    return check_launch("viterbi_collect");
+}
+
 extern "C" int dsp_follow_path(const int32_t* next, const int32_t* tok, const int64_t* out_len, int pad,
                                int64_t* out_tokens, int32_t* keep_idx, int32_t* n_feat, int B, int L, int cap, dsp_stream_t stream)
 {

@@ -337,7 +337,7 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
     TR = links.shape[2]
     dev = logits.device
     tok32, sc = argmax_logp(logits)                                       # unreduced_logits / unreduced_tokens (:207-208), one pass over the logits
-    tok = tok32.to(torch.int64)
+    tok32 = tok32.contiguous()
     max_length = max(1, int(L / 8 / src_upsample_scale))                 # (:256)
     T = max_length + 2
     olen = output_length.to(torch.int64).contiguous()
@@ -376,36 +376,29 @@ def viterbi_decode(logits: Tensor, links: Tensor, features: Tensor, output_lengt
         else:
             _lib.check(lib.dsp_dag_backtrace(_lib.ptr(trace), _lib.ptr(olen), _lib.ptr(start_rows), _lib.ptr(path), B, T, L, st),
                        "dsp_dag_backtrace")
-    # vertices visited at DP rows 1 .. pred_length, in graph order (= the reference's reversed back-trace, :283-290)
-    on = (path >= 1) & (path <= pred_length.unsqueeze(1))
-    # the final vertex is out of reach within max_length steps (a window far narrower than the model's: L / 4 steps of at most TR
-    # vertices): every candidate score is -inf, the reference's arg-maxes all return index 0 (:267-278) and it emits the one token of
-    # vertex 0 — reproduced, not "fixed"
-    # (applied on the device unconditionally: a host-side `if unreach.any()` would synchronise every decode batch for a corner case)
-    unreach = torch.isneginf(best).all(dim=1, keepdim=True)
-    first = torch.arange(L, device=dev).unsqueeze(0) == 0
-    on = torch.where(unreach, first, on)
-    prev_tok = torch.full((B,), -12345, dtype=tok.dtype, device=dev)
-    # token kept if it is the LAST visited vertex, or (not pad and differs from the next visited token)   (:291-299, backward order)
-    vis_idx = torch.argsort((~on).to(torch.int8), dim=1, stable=True)   # visited vertices first, ascending
-    n_vis = on.sum(1)
-    Pm = min(L, max_length)                                              # at most one vertex per DP row (no host round trip for the exact maximum)
-    vpath = vis_idx[:, :Pm]
-    vvalid = torch.arange(Pm, device=dev).unsqueeze(0) < n_vis.unsqueeze(1)
-    ptok = tok.gather(1, vpath)
-    nxt = torch.cat([ptok[:, 1:], prev_tok.unsqueeze(1)], dim=1)
-    nxt_valid = torch.cat([vvalid[:, 1:], torch.zeros((B, 1), dtype=torch.bool, device=dev)], dim=1)
-    is_last = vvalid & ~nxt_valid
-    keep = vvalid & (is_last | ((ptok != pad) & (ptok != nxt)))
-    n_keep = keep.sum(1)
-    fmax = int(n_keep.max().item()) if B else 0
-    order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
-    fwd_path = vpath.gather(1, order)[:, :fmax]
-    fwd_tok = ptok.gather(1, order)[:, :fmax]
+    # the token pass (:283-299) in one kernel: vertices visited at DP rows 1 .. pred_length in graph order, a token kept if it is the last
+    # visited one or (not pad and different from the next visited token).  The final vertex out of reach within max_length steps (a window far
+    # narrower than the model's): every candidate score is -inf, the reference's arg-maxes all return index 0 (:267-278) and it emits the one
+    # token of vertex 0 — reproduced on the device, not "fixed" (no host-side branch: it would synchronise every decode batch for a corner case)
+    unreach = torch.isneginf(best).all(dim=1).to(torch.uint8).contiguous()
+    feats = features.detach().contiguous()
+    D = feats.shape[2]
+    with torch.cuda.device(dev):
+        cap = L
+        out_tok = torch.empty((B, cap), dtype=torch.long, device=dev)
+        keep = torch.empty((B, cap), dtype=torch.int32, device=dev)
+        nk = torch.empty((B,), dtype=torch.int32, device=dev)
+        pl = pred_length.to(torch.int64).contiguous()
+        _lib.check(lib.dsp_viterbi_collect(_lib.ptr(path), _lib.ptr(pl), _lib.ptr(unreach), _lib.ptr(tok32), int(pad), _lib.ptr(out_tok), _lib.ptr(keep),
+                                           _lib.ptr(nk), B, L, cap, _lib.current_stream_handle()), "dsp_viterbi_collect")
+        fmax = int(nk.max().item()) if B else 0              # the one sync: output shapes depend on it
+        out_feat = torch.empty((B, fmax, D), dtype=feats.dtype, device=dev)
+        if fmax:
+            _lib.check(lib.dsp_gather_rows(_lib.ptr(feats), _code(feats), _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(out_feat),
+                                           B, L, D, cap, fmax, _lib.current_stream_handle()), "dsp_gather_rows")
+    n_keep = nk.to(torch.long)
     mask = torch.arange(fmax, device=dev).unsqueeze(0) >= n_keep.unsqueeze(1)
-    out_tok = fwd_tok.masked_fill(mask, pad)
-    out_feat = features.gather(1, fwd_path.unsqueeze(-1).expand(-1, -1, features.shape[-1])).masked_fill(mask.unsqueeze(-1), 0)
-    return out_tok, out_feat, mask, n_keep
+    return out_tok[:, :fmax].contiguous(), out_feat, mask, n_keep
 
 
 def viterbi_decode_torch(logits: Tensor, links: Tensor, features: Tensor, output_length: Tensor, pad: int, decode_beta: float = 1.0,

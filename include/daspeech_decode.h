@@ -32,6 +32,15 @@ int dsp_lookahead_next(const float* links, const float* score, float beta, int g
 int dsp_follow_path(const int32_t* next, const int32_t* tok, const int64_t* out_len, int pad,
                     int64_t* out_tokens, int32_t* keep_idx, int32_t* n_feat, int B, int L, int cap, dsp_stream_t stream);
 
+/* F3a' the token pass of the viterbi / jointviterbi strategies                 (s2s_conformer_dag_fastspeech2.py:283-299)
+ *   path [B,L] int64 (DP row of every vertex on the back-traced chain, -1 elsewhere: dsp_dag_backtrace / dsp_dag_backtrace_blocks),
+ *   pred_length [B] int64 (chosen length), unreachable [B] uint8 (no length reaches the final vertex: the token of vertex 0 is emitted,
+ *   as the reference does), tok [B,L] int32.  Visited = DP rows 1 .. pred_length, graph order; a token is kept if it is the last visited
+ *   one, or not <pad> and different from the next visited token.  out_tokens [B,cap] int64 (pad-filled), keep_idx [B,cap] int32 (vertex of
+ *   each kept token, -1 padded: the index list of dsp_gather_rows), n_keep [B] int32. */
+int dsp_viterbi_collect(const int64_t* path, const int64_t* pred_length, const unsigned char* unreachable, const int32_t* tok, int pad,
+                        int64_t* out_tokens, int32_t* keep_idx, int32_t* n_keep, int B, int L, int cap, dsp_stream_t stream);
+
 /* F3b  gather the decoder states of the kept vertices, zero padded            (:232,234,241; _collate_frames)
  *   features [B,L,D] (dtype code), keep_idx [B,cap]; out [B,Fmax,D] same dtype: out[b,k] = features[b,keep_idx[b,k]] for
  *   k < n_feat[b], 0 after.  Pure copy: bit-exact. */
