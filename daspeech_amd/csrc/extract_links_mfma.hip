@@ -56,9 +56,12 @@ __device__ __forceinline__ void xm_split8(const float* x, xm_h8& hi, xm_h8& lo) 
 }
 
 // pre-pass: x [B,L,8,64] fp32 -> A fragments [B][8 heads][NT tiles of 32 rows][4 steps][hi, lo][64 lanes][8 halves]; rows past L are zeros
-__global__ __launch_bounds__(256) void xl_mfma_split_kernel(const float* __restrict__ x, char* __restrict__ xa, int L, int NT)
+// (blockIdx.z = 1: the second tensor of the backward's pair, x2 -> xa + second)
+__global__ __launch_bounds__(256) void xl_mfma_split_kernel(const float* __restrict__ x, char* __restrict__ xa, int L, int NT,
+                                                            const float* __restrict__ x2, size_t second)
 {
     const int t = blockIdx.x, b = blockIdx.y;
+    if (blockIdx.z) { x = x2; xa += second; }
     const size_t rs = XM_H * XM_CK;
     for (int it = threadIdx.x; it < 2048; it += 256) {
         const int g = it & 1, c = (it >> 1) & 3, h = (it >> 3) & 7, row = it >> 6;
@@ -490,7 +493,7 @@ extern "C" int dsp_extract_links_ws(const float* q, const float* k, const float*
     p.pa = static_cast<const char*>(workspace);
     p.stats = stats ? stats : reinterpret_cast<float*>(static_cast<char*>(workspace) + xm_split_bytes(B, L));
     p.B = B; p.L = L; p.TR = TR; p.NT = (L + 31) / 32; p.scale = scale;
-    hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, static_cast<char*>(workspace), L, p.NT);
+    hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, static_cast<char*>(workspace), L, p.NT, (const float*)nullptr, (size_t)0);
     if (int rc = check_launch("extract_links(split)")) return rc;
     if (int rc = xm_launch<XM_STATS, 2>(p, st, "extract_links(matrix-core soft-max state)")) return rc;
     return xm_launch<XM_EMIT, 2>(p, st, "extract_links(matrix-core emission)");
@@ -516,8 +519,7 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
     p.q = q; p.k = k; p.gates = log_gates; p.out_len = out_len; p.bias = dist_bias;
     p.clinks = links; p.G = grad_links; p.cstats = stats; p.dgate = grad_log_gates;
     p.B = B; p.L = L; p.TR = TR; p.NT = (L + 31) / 32; p.scale = scale;
-    hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, ws, L, p.NT);
-    hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, q, ws + one, L, p.NT);
+    hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B, 2), dim3(256), 0, st, k, ws, L, p.NT, q, one);      // k -> ws, q -> ws + one
     if (int rc = check_launch("extract_links_bwd(split)")) return rc;
     p.pa = ws;
     if (int rc = xm_launch<XM_SA, 2>(p, st, "extract_links_bwd(matrix-core SA)")) return rc;
