@@ -450,7 +450,8 @@ static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
 static thread_local int g_xl_mfma = -1;        // dsp_dag_set_option("xl_mfma", v): 1 = matrix-core kernels wherever they apply, 0 = never, -1 = by size
 void set_xl_mfma(int v) { g_xl_mfma = v; }
 
-static bool xm_supported(int L, int H, int CK, int TR) { return H == XM_H && CK == XM_CK && TR >= 1 && L >= 2; }
+// (32-bit byte offsets inside a sample's links / gradient block: L * TR * 4 < 2^31)
+static bool xm_supported(int L, int H, int CK, int TR) { return H == XM_H && CK == XM_CK && TR >= 1 && L >= 2 && (long)L * TR < (1L << 29); }
 static bool xm_preferred(int B, int L, int H, int CK, int TR)
 {
     if (!xm_supported(L, H, CK, TR) || g_xl_mfma == 0) return false;
