@@ -18,7 +18,8 @@
 // kernels share that loop:
 //   STATS   per (vertex, head): window maximum and log-sum (online) — the soft-max state, = `stats` of dsp_extract_links_train
 //   EMIT    links[i, d] = logsumexp_h(log_softmax + log_gate): the 8 waves park their head's term in an LDS image [head][owner][partner]
-//           (double-buffered, one barrier per tile); all 512 threads then reduce over the heads and store rows of the compact band
+//           (64-owner tiles: double-buffered, one barrier per tile; graphs up to ~1 500 vertices: 32-owner tiles, four slots, one barrier per
+//           two tiles); all 512 threads then reduce over the heads and store rows of the compact band
 //   SA      dgate[i, h] = sum_d A[i, d, h],  A = G exp(ls + g - links)          (the tile of links / G is staged through LDS, coalesced)
 //   DQ      ds = A - exp(ls) SA, contracted with the partner rows: dq^T[c, i] += K^T[c, j] ds^T[j, i]  (B operand = ds straight from the registers)
 //   DK      the same with owners = successors j and partners = sources i (per-partner soft-max state from an LDS table)
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
     }
 
     // ---- LDS
-    float* img = reinterpret_cast<float*>(xm_smem);                                     // EMIT: [2][8 heads][OT][PITCH]
+    float* img = reinterpret_cast<float*>(xm_smem);                                     // EMIT: [2 or 4 slots][8 heads][OT][PITCH]
     float* stg = reinterpret_cast<float*>(xm_smem);                                     // BWD:  [4 slots][links, G][OT][PITCH]  (owner-major in both directions); two tiles are staged per barrier
     constexpr int STG_ONE = OT * XM_PITCH;
     float4* tab = reinterpret_cast<float4*>(xm_smem + 4 * 2 * STG_ONE * sizeof(float));    // DK: [4 slots][32 partners][8 heads] (ca, cp, SA, -)
@@ -327,9 +328,38 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
         }
     };
 
+    // EMIT: links[i, d] = logsumexp over the heads of one tile's image; lanes along the partners: a wave stores two rows of 128 contiguous bytes
+    constexpr bool EMIT_PAIR = MODE == XM_EMIT && QG == 1;       // 32-owner tiles: 4 image slots, one barrier per pair of tiles; 64-owner tiles: 2 slots, one per tile
+    auto combine = [&](int n) {
+        if constexpr (MODE == XM_EMIT) {
+            const int t = tile_of(n), buf = EMIT_PAIR ? (n & 3) : (n & 1);
+            const bool live_tile = n < nlive;
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = it * 512 + tid, qq = idx >> 5, kk = idx & 31;
+                const int i = o0 + qq, d = 32 * t + kk - i - 1;
+                if (i < L && d >= 0 && d < TR) {
+                    float r = NEG_INF;
+                    if (live_tile) {
+                        float v[XM_H], m2 = NEG_INF;
+#pragma unroll
+                        for (int hh = 0; hh < XM_H; ++hh) { v[hh] = img[(((size_t)buf * XM_H + hh) * OT + qq) * XM_PITCH + kk]; m2 = fmaxf(m2, v[hh]); }
+                        if (m2 != NEG_INF) {
+                            float e = 0.f;
+#pragma unroll
+                            for (int hh = 0; hh < XM_H; ++hh) e += __builtin_amdgcn_exp2f(v[hh] - m2);
+                            r = (m2 + __builtin_amdgcn_logf(e)) * LN2;
+                        }
+                    }
+                    p.links[((size_t)b * L + i) * TR + d] = r;
+                }
+            }
+        }
+    };
+
     auto step = [&](int n, xm_h8 (&cur)[8], xm_h8 (&nxt)[8]) {
         const int t = tile_of(n);
-        const int buf = BWD ? (n & 3) : (n & 1);
+        const int buf = (BWD || EMIT_PAIR) ? (n & 3) : (n & 1);
         const bool live_tile = n < nlive;
         if constexpr (BWD) {
             if ((n & 1) == 0) {                         // one barrier per PAIR of tiles: both tiles' links / G (and DK's partner table) go to LDS together
@@ -365,27 +395,16 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
             }
         }
         if constexpr (MODE == XM_EMIT) {
-            __syncthreads();
-            // ---- links[i, d] = logsumexp over the heads; lanes along the partners: a wave stores two rows of 128 contiguous bytes
-#pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int idx = it * 512 + tid, qq = idx >> 5, kk = idx & 31;
-                const int i = o0 + qq, d = 32 * t + kk - i - 1;
-                if (i < L && d >= 0 && d < TR) {
-                    float r = NEG_INF;
-                    if (live_tile) {
-                        float v[XM_H], m2 = NEG_INF;
-#pragma unroll
-                        for (int hh = 0; hh < XM_H; ++hh) { v[hh] = img[(((size_t)buf * XM_H + hh) * OT + qq) * XM_PITCH + kk]; m2 = fmaxf(m2, v[hh]); }
-                        if (m2 != NEG_INF) {
-                            float e = 0.f;
-#pragma unroll
-                            for (int hh = 0; hh < XM_H; ++hh) e += __builtin_amdgcn_exp2f(v[hh] - m2);
-                            r = (m2 + __builtin_amdgcn_logf(e)) * LN2;
-                        }
-                    }
-                    p.links[((size_t)b * L + i) * TR + d] = r;
+            // the heads of a tile (of a PAIR of tiles with 32-owner tiles) meet, then all 512 threads reduce them
+            if constexpr (EMIT_PAIR) {
+                if ((n & 1) || n + 1 >= nstep) {
+                    __syncthreads();
+                    if (n & 1) combine(n - 1);
+                    combine(n);
                 }
+            } else {
+                __syncthreads();
+                combine(n);
             }
         }
     };
@@ -439,7 +458,7 @@ static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
 {
     constexpr int OT = 32 * QG;
     size_t lds = 16;
-    if (MODE == XM_EMIT) lds = (size_t)2 * XM_H * OT * XM_PITCH * sizeof(float);
+    if (MODE == XM_EMIT) lds = (size_t)(QG == 1 ? 4 : 2) * XM_H * OT * XM_PITCH * sizeof(float);
     else if (MODE >= XM_SA) lds = (size_t)4 * 2 * OT * XM_PITCH * sizeof(float) + (MODE == XM_DK ? 4 * 256 * sizeof(float4) : 0);
     auto k = xl_mfma_kernel<MODE, QG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -497,6 +516,11 @@ extern "C" int dsp_extract_links_ws(const float* q, const float* k, const float*
     hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, static_cast<char*>(workspace), L, p.NT, (const float*)nullptr, (size_t)0);
     if (int rc = check_launch("extract_links(split)")) return rc;
     if (int rc = xm_launch<XM_STATS, 2>(p, st, "extract_links(matrix-core soft-max state)")) return rc;
+    static const char* const e_qg = getenv("DSP_XM_EMIT_QG");
+    const int qg = e_qg ? atoi(e_qg) : (L <= 1536 ? 1 : 2);
+    // 32-owner tiles with one barrier per two tiles on graphs up to ~1 500 vertices (us at B = 32, 64- vs 32-owner tiles — L = 256: 28 / 18,
+    // L = 400: 42 / 39, L = 1024: 174 / 153), 64-owner tiles above (half the fragment traffic — L = 2048: 552 / 585, L = 4096: 1 950 / 2 130)
+    if (qg == 1) return xm_launch<XM_EMIT, 1>(p, st, "extract_links(matrix-core emission)");
     return xm_launch<XM_EMIT, 2>(p, st, "extract_links(matrix-core emission)");
 }
 
