@@ -475,9 +475,10 @@ static bool xm_preferred(int B, int L, int H, int CK, int TR)
 {
     if (!xm_supported(L, H, CK, TR) || g_xl_mfma == 0) return false;
     if (g_xl_mfma > 0) return true;
-    // by size (tools/xl_mfma_time.py): the 64-vertex workgroups need a window worth a 32 x 32 block and enough tiles for a quarter of the
-    // chip; below that the 4-vertex workgroups of extract_links.hip are as fast or faster (B = 2, L = 1000: 0.11 vs 0.15 ms)
-    return L >= 128 && TR >= 64 && (long)B * ((L + 63) / 64) >= 64;
+    // by size (tools/xl_mfma_time.py): three launches and a split pre-pass need a band of ~half a million slots to pay — below that the one launch of
+    // extract_links.hip wins on launch latency (ms, FMA -> matrix cores — B = 1, L = 800: 0.071 -> 0.071; B = 2, L = 400: 0.041 -> 0.046;
+    // B = 1, L = 1200: 0.22 -> 0.10; B = 8, L = 400: 0.078 -> 0.049)
+    return L >= 128 && TR >= 64 && (long)B * L * TR >= 500000;
 }
 
 static size_t xm_split_bytes(int B, int L) { return (size_t)B * XM_H * ((L + 31) / 32) * XM_TILE; }
@@ -515,7 +516,10 @@ extern "C" int dsp_extract_links_ws(const float* q, const float* k, const float*
     p.B = B; p.L = L; p.TR = TR; p.NT = (L + 31) / 32; p.scale = scale;
     hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, static_cast<char*>(workspace), L, p.NT, (const float*)nullptr, (size_t)0);
     if (int rc = check_launch("extract_links(split)")) return rc;
-    if (int rc = xm_launch<XM_STATS, 2>(p, st, "extract_links(matrix-core soft-max state)")) return rc;
+    static const char* const e_sq = getenv("DSP_XM_STATS_QG");
+    const int sq = e_sq ? atoi(e_sq) : (L <= 1536 ? 1 : 2);          // as EMIT below (us at B = 32, 64- / 32-owner tiles — L = 256: 20 / 14, L = 1024: 121 / 93)
+    if (int rc = sq == 1 ? xm_launch<XM_STATS, 1>(p, st, "extract_links(matrix-core soft-max state)")
+                         : xm_launch<XM_STATS, 2>(p, st, "extract_links(matrix-core soft-max state)")) return rc;
     static const char* const e_qg = getenv("DSP_XM_EMIT_QG");
     const int qg = e_qg ? atoi(e_qg) : (L <= 1536 ? 1 : 2);
     // 32-owner tiles with one barrier per two tiles on graphs up to ~1 500 vertices (us at B = 32, 64- vs 32-owner tiles — L = 256: 28 / 18,
@@ -547,7 +551,9 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
     hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B, 2), dim3(256), 0, st, k, ws, L, p.NT, q, one);      // k -> ws, q -> ws + one
     if (int rc = check_launch("extract_links_bwd(split)")) return rc;
     p.pa = ws;
-    if (int rc = xm_launch<XM_SA, 2>(p, st, "extract_links_bwd(matrix-core SA)")) return rc;
+    static const char* const e_aq = getenv("DSP_XM_SA_QG");
+    const int aq = e_aq ? atoi(e_aq) : (L <= 1536 ? 1 : 2);          // (L = 256: 27 / 18 us, L = 1024: 183 / 173)
+    if (int rc = aq == 1 ? xm_launch<XM_SA, 1>(p, st, "extract_links_bwd(matrix-core SA)") : xm_launch<XM_SA, 2>(p, st, "extract_links_bwd(matrix-core SA)")) return rc;
     p.dout = grad_q;
     if (int rc = xm_launch<XM_DQ, 1>(p, st, "extract_links_bwd(matrix-core dq)")) return rc;
     p.pa = ws + one; p.dout = grad_k;
