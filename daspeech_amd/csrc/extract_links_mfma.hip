@@ -6,7 +6,7 @@
 // matrix cores with fp32 accuracy ("3 x fp16": x = xh + xl 2^-11, three MFMAs per product, see conv1d_split.hip / attention_split.hip), and the
 // backward's contractions  dq = ds . K,  dk = ds^T . Q  run on the fp32 matrix-core path (v_mfma_f32_32x32x2_f32: exact fp32 products, no range
 // assumption on the incoming gradient).  B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999), ms:
-// inference 31.8 -> 3.0, forward + backward under autograd 43.2 -> 14.3; L = 1024: 1.83 -> 0.30, 2.8 -> 1.3; L = 400: 0.26 -> 0.09, 0.54 -> 0.33
+// inference 31.8 -> 3.0, forward + backward under autograd 43.2 -> 14.3; L = 1024: 1.82 -> 0.27, 2.8 -> 1.2; L = 400: 0.26 -> 0.08, 0.55 -> 0.34
 // (tools/xl_mfma_time.py, profiles/r05_links_matrix_core.txt).
 //
 // Decomposition: a workgroup is 8 waves = the 8 heads of a tile of OWNER rows (32 or 64 source vertices i; for dk: successors j); a lane owns
