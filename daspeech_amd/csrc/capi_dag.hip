@@ -40,6 +40,7 @@ void set_dm_mt(int v);
 void set_dx_mt(int v);
 void set_xl_tile(int v);
 void set_xl_mfma(int v);
+void set_xl_contract(int v);
 void set_dm_budget(int v);
 size_t dense_rows_gated_bytes(int B, int L, int ndir);
 bool dense_rows_gated_supported(int L);
@@ -270,6 +271,7 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
     if (name && !strcmp(name, "dx_mt")) { set_dx_mt(value); return DSP_OK; }
     if (name && !strcmp(name, "xl_tile")) { set_xl_tile(value); return DSP_OK; }
     if (name && !strcmp(name, "xl_mfma")) { set_xl_mfma(value); return DSP_OK; }
+    if (name && !strcmp(name, "xl_contract")) { set_xl_contract(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_budget")) { set_dm_budget(value); return DSP_OK; }
     if (name && !strcmp(name, "force_generic")) { g_path = value ? 1 : 0; return DSP_OK; }
     set_error("dsp_dag_set_option: unknown option");

@@ -5,8 +5,11 @@
 // from L2 once per four vertices — VALU- and L2-bound from L ~ 1 000 on.  Here the scores are 32 x 32 blocks of  S^T = K . Q^T  on the fp16
 // matrix cores with fp32 accuracy ("3 x fp16": x = xh + xl 2^-11, three MFMAs per product, see conv1d_split.hip / attention_split.hip), and the
 // backward's contractions  dq = ds . K,  dk = ds^T . Q  run on the fp32 matrix-core path (v_mfma_f32_32x32x2_f32: exact fp32 products, no range
-// assumption on the incoming gradient).  B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999), ms:
-// inference 31.8 -> 3.0, forward + backward under autograd 43.2 -> 14.3; L = 1024: 1.82 -> 0.27, 2.8 -> 1.2; L = 400: 0.26 -> 0.08, 0.55 -> 0.34
+// assumption on the incoming gradient) or, on graphs above ~1 500 vertices, as bf16-TRIPLE products: ds and the partner rows are cut into three
+// bf16 pieces each (8 + 8 + 8 mantissa bits by truncation: exact, and bf16 has fp32's exponent range — the gradient needs no scaling), the six
+// piece products down to 2^-16 of the leading one run on the bf16 matrix cores into fp32 accumulators (24 MFMAs of 32 cycles per block
+// instead of 32 of 64; ~2^-23 relative).  B = 32, L = 4096, TR = L-1 (BASELINE's graph with the README's --max-transition-length 99999), ms:
+// inference 31.8 -> 3.0, forward + backward under autograd 43.2 -> 13.2; L = 1024: 1.82 -> 0.27, 2.8 -> 1.2; L = 400: 0.26 -> 0.08, 0.55 -> 0.34
 // (tools/xl_mfma_time.py, profiles/r05_links_matrix_core.txt).
 //
 // Decomposition: a workgroup is 8 waves = the 8 heads of a tile of OWNER rows (32 or 64 source vertices i; for dk: successors j); a lane owns
@@ -37,7 +40,9 @@ namespace dsp {
 constexpr int XM_H = 8, XM_CK = 64;
 typedef _Float16 xm_h8 __attribute__((ext_vector_type(8)));
 typedef float xm_f16 __attribute__((ext_vector_type(16)));
+typedef __bf16 xm_b8 __attribute__((ext_vector_type(8)));
 constexpr size_t XM_FRAG = 1024;                   // one MFMA operand fragment: 64 lanes x 16 bytes
+constexpr size_t XM_TTILE = 12 * XM_FRAG;          // 32 rows of one head, TRANSPOSED, as three bf16 pieces: [2 channel blocks][2 steps][3 pieces]
 constexpr size_t XM_TILE = 8 * XM_FRAG;            // 32 rows of one head: [4 channel steps][hi, lo]
 constexpr int XM_PITCH = 36;                       // floats per owner row of an LDS tile (float4 slots of the 8 lanes of a store group on distinct banks)
 
@@ -48,6 +53,7 @@ struct XmParams {
     float* links; float* stats;                                          // forward outputs
     const float* clinks; const float* G; const float* cstats; float* dgate; float* dout;     // backward
     const char* pa;                                                      // the partner rows, split, in A-fragment order
+    const char* pt;                                                      // the partner rows TRANSPOSED as bf16 triples (contraction operand), or NULL
     int B, L, TR, NT; float scale;
 };
 
@@ -83,7 +89,43 @@ __global__ __launch_bounds__(256) void xl_mfma_split_kernel(const float* __restr
     }
 }
 
-template <int MODE, int QG>
+// pre-pass for the backward's contractions: x [B,L,8,64] fp32 -> x^T as three bf16 pieces (x = x1 + x2 + x3 exactly: 8 + 8 + 8 mantissa bits by
+// truncation) in A-fragment order of out^T[channel][owner] += x^T[channel][partner] ds^T[partner][owner]: lane (col = channel, g), element e
+// <-> partner (2 c2 + e / 4) * 8 + 4 g + e % 4 of the tile — the order in which the score accumulators hand a lane its partners.
+__global__ __launch_bounds__(256) void xl_mfma_split_t_kernel(const float* __restrict__ x, char* __restrict__ xt, int L, int NT,
+                                                              const float* __restrict__ x2, size_t second)
+{
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (blockIdx.z) { x = x2; xt += second; }
+    const size_t rs = XM_H * XM_CK;
+    for (int it = threadIdx.x; it < 2048; it += 256) {
+        const int lane = it & 63, c2 = (it >> 6) & 1, db = (it >> 7) & 1, h = it >> 8;
+        const int col = lane & 31, g = lane >> 5;
+        unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned pc[3][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 2 * w + q;
+                const int r = 32 * t + (2 * c2 + (e >> 2)) * 8 + 4 * g + (e & 3);
+                const float v = r < L ? x[((size_t)b * L + r) * rs + h * XM_CK + 32 * db + col] : 0.f;
+                const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+                const float r1 = v - __uint_as_float(b1);
+                const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+                const float r2 = r1 - __uint_as_float(b2);
+                pc[0][q] = b1; pc[1][q] = b2; pc[2][q] = __float_as_uint(r2) & 0xFFFF0000u;
+            }
+            w1[w] = pc[0][1] | (pc[0][0] >> 16); w2[w] = pc[1][1] | (pc[1][0] >> 16); w3[w] = pc[2][1] | (pc[2][0] >> 16);
+        }
+        char* dst = xt + (((size_t)b * XM_H + h) * NT + t) * XM_TTILE + (size_t)((db * 2 + c2) * 3) * XM_FRAG + lane * 16;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        *reinterpret_cast<uint4*>(dst + XM_FRAG) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * XM_FRAG) = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+    }
+}
+
+template <int MODE, int QG, int CT = 0>            // CT = 1: the contraction as bf16-triple products (6 MFMAs per 16 partners) instead of exact-fp32 MFMAs
 __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char xm_smem[];
@@ -226,6 +268,7 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
 
     // ---- A fragments of a partner tile (this wave's head)
     const char* pa_h = p.pa + (((size_t)b * XM_H + h) * p.NT) * XM_TILE + lane * 16;
+    const char* pt_h = CT == 1 ? p.pt + (((size_t)b * XM_H + h) * p.NT) * XM_TTILE + lane * 16 : nullptr;
     xm_h8 fa[8], fb[8];
     auto frag_load = [&](int t, xm_h8 (&f)[8]) {
         const char* src = pa_h + (size_t)t * XM_TILE;
@@ -238,7 +281,7 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
     auto tile_of = [&](int n) { return TRANSPOSED ? (t0 + n) : (n < nlive ? (t1 - 1 - n) : (t1 + (n - nlive))); };
 
     // one 32 x 32 block of one owner group: scores, then the mode's work.  FULL: every slot of the block is inside the band and the graph
-    auto block = [&](auto full_tag, int t, int grp, int buf, const xm_h8 (&a)[8], const float (&xa)[CONTRACT ? 32 : 1]) {
+    auto block = [&](auto full_tag, int t, int grp, int buf, const xm_h8 (&a)[8], const float (&xa)[(CONTRACT && CT == 0) ? 32 : 1]) {
         constexpr bool FULL = decltype(full_tag)::value;
         xm_f16 shh, slo;
 #pragma unroll
@@ -315,6 +358,55 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
                 for (int r = 0; r < 16; ++r) sa += ds[r];
                 sarow[grp] += sa;
             } else {
+                if constexpr (CT == 1) {
+                    // ds = d1 + d2 + d3 (bf16 pieces by truncation, exact), partner rows x = x1 + x2 + x3 from the pre-pass: the six products down to
+                    // 2^-16 of the leading one (d1 x1, d1 x2, d2 x1, d1 x3, d2 x2, d3 x1) on the bf16 matrix cores, fp32 accumulators — fp32 range,
+                    // ~2^-23 relative; 24 MFMAs of 32 cycles per block instead of 32 of 64
+                    xm_b8 dp[3][2];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            unsigned pc[3][2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const float v = ds[8 * c2 + 2 * w + q];
+                                const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+                                const float r1 = v - __uint_as_float(b1);
+                                const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+                                const float r2 = r1 - __uint_as_float(b2);
+                                pc[0][q] = __float_as_uint(v); pc[1][q] = __float_as_uint(r1); pc[2][q] = __float_as_uint(r2);
+                            }
+                            w1[w] = __builtin_amdgcn_perm(pc[0][1], pc[0][0], 0x07060302u);
+                            w2[w] = __builtin_amdgcn_perm(pc[1][1], pc[1][0], 0x07060302u);
+                            w3[w] = __builtin_amdgcn_perm(pc[2][1], pc[2][0], 0x07060302u);
+                        }
+                        dp[0][c2] = __builtin_bit_cast(xm_b8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+                        dp[1][c2] = __builtin_bit_cast(xm_b8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+                        dp[2][c2] = __builtin_bit_cast(xm_b8, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+                    }
+                    const char* tsrc = pt_h + (size_t)t * XM_TTILE;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        xm_b8 kt[2][3];
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) kt[c2][pc] = *reinterpret_cast<const xm_b8*>(tsrc + (size_t)((db * 2 + c2) * 3 + pc) * XM_FRAG);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][0], dp[0][c2], acc[grp][db], 0, 0, 0);
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][1], dp[0][c2], acc[grp][db], 0, 0, 0);
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][0], dp[1][c2], acc[grp][db], 0, 0, 0);
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][2], dp[0][c2], acc[grp][db], 0, 0, 0);
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][1], dp[1][c2], acc[grp][db], 0, 0, 0);
+                            acc[grp][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[c2][0], dp[2][c2], acc[grp][db], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
                 // the 32 MFMAs leave back to back: a VALU instruction between two MFMAs on one accumulator costs tens of cycles each (the
                 // other wave of the SIMD fills the matrix-core time with ITS VALU phase)
                 __builtin_amdgcn_sched_barrier(0);
@@ -324,6 +416,7 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
                     acc[grp][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * r + 1], ds[r], acc[grp][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     };
@@ -372,8 +465,8 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
         }
         if (live_tile) {
             if (n + 1 < nlive) frag_load(tile_of(n + 1), nxt);
-            float xa[CONTRACT ? 32 : 1];
-            if constexpr (CONTRACT) {
+            float xa[(CONTRACT && CT == 0) ? 32 : 1];
+            if constexpr (CONTRACT && CT == 0) {
                 // the partner rows in fp32 for the contraction: lane (col = channel, g) <-> row 8 j' + 4 g + e of the tile
                 const int soff = (int)((size_t)(32 * t) * rs * 4);
 #pragma unroll
@@ -453,14 +546,14 @@ __global__ __launch_bounds__(512) void xl_mfma_kernel(XmParams p)
     }
 }
 
-template <int MODE, int QG>
+template <int MODE, int QG, int CT = 0>
 static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
 {
     constexpr int OT = 32 * QG;
     size_t lds = 16;
     if (MODE == XM_EMIT) lds = (size_t)(QG == 1 ? 4 : 2) * XM_H * OT * XM_PITCH * sizeof(float);
     else if (MODE >= XM_SA) lds = (size_t)4 * 2 * OT * XM_PITCH * sizeof(float) + (MODE == XM_DK ? 4 * 256 * sizeof(float4) : 0);
-    auto k = xl_mfma_kernel<MODE, QG>;
+    auto k = xl_mfma_kernel<MODE, QG, CT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.L + OT - 1) / OT) * p.B)), dim3(512), lds, st, p);
     return check_launch(what);
@@ -482,6 +575,12 @@ static bool xm_preferred(int B, int L, int H, int CK, int TR)
 }
 
 static size_t xm_split_bytes(int B, int L) { return (size_t)B * XM_H * ((L + 31) / 32) * XM_TILE; }
+static size_t xm_split_t_bytes(int B, int L) { return (size_t)B * XM_H * ((L + 31) / 32) * XM_TTILE; }
+static thread_local int g_xl_contract = -1;    // dsp_dag_set_option("xl_contract", v): 0 = exact-fp32 MFMA contraction, 1 = bf16-triple products, -1 = default
+void set_xl_contract(int v) { g_xl_contract = v; }
+// by size: the transposed pre-pass costs 23 us at B = 32, L = 400 for 15 us saved in DQ + DK; at L = 4096 0.23 ms for 0.9 ms (DQ 4.53 -> 4.03, DK 4.88 -> 4.50)
+static bool xm_bf16_contraction(int L) { return g_xl_contract > 0 || (g_xl_contract < 0 && L > 1536); }
+static size_t xm_bwd_bytes(int B, int L) { return 2 * xm_split_bytes(B, L) + 2 * xm_split_t_bytes(B, L); }
 
 }  // namespace dsp
 
@@ -492,7 +591,7 @@ extern "C" int dsp_extract_links_workspace(int B, int L, int H, int CK, int TR, 
     *bytes = 0;
     if (B <= 0 || !xm_preferred(B, L, H, CK, TR)) return DSP_OK;            // 0 bytes: the fp32-FMA kernels of extract_links.hip serve this call
     // forward: the split k rows + a stats scratch for the inference entry point; backward: the split k and q rows
-    *bytes = training == 2 ? 2 * xm_split_bytes(B, L) : xm_split_bytes(B, L) + (size_t)B * L * XM_H * 2 * sizeof(float);
+    *bytes = training == 2 ? xm_bwd_bytes(B, L) : xm_split_bytes(B, L) + (size_t)B * L * XM_H * 2 * sizeof(float);
     return DSP_OK;
 }
 
@@ -540,8 +639,9 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
     if (!q || !k || !log_gates || !out_len || !links || !grad_links || !stats || !grad_q || !grad_k || !grad_log_gates || !workspace) {
         set_error("extract_links_bwd_ws: null pointer"); return DSP_EINVAL; }
     const size_t one = xm_split_bytes(B, L);
-    if (workspace_bytes < 2 * one || ((uintptr_t)workspace & 15) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)grad_q | (uintptr_t)grad_k) & 15)) {
-        set_error("extract_links_bwd_ws: workspace of %zu bytes (16-byte aligned) needed, %zu given; q / k / grads 16-byte aligned", 2 * one, workspace_bytes); return DSP_EINVAL; }
+    const size_t onet = xm_split_t_bytes(B, L);
+    if (workspace_bytes < xm_bwd_bytes(B, L) || ((uintptr_t)workspace & 15) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)grad_q | (uintptr_t)grad_k) & 15)) {
+        set_error("extract_links_bwd_ws: workspace of %zu bytes (16-byte aligned) needed, %zu given; q / k / grads 16-byte aligned", xm_bwd_bytes(B, L), workspace_bytes); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
     XmParams p{};
@@ -555,6 +655,15 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
     const int aq = e_aq ? atoi(e_aq) : (L <= 1536 ? 1 : 2);          // (L = 256: 27 / 18 us, L = 1024: 183 / 173)
     if (int rc = aq == 1 ? xm_launch<XM_SA, 1>(p, st, "extract_links_bwd(matrix-core SA)") : xm_launch<XM_SA, 2>(p, st, "extract_links_bwd(matrix-core SA)")) return rc;
     p.dout = grad_q;
+    if (xm_bf16_contraction(L)) {
+        char* wt = ws + 2 * one;
+        hipLaunchKernelGGL(xl_mfma_split_t_kernel, dim3((unsigned)p.NT, (unsigned)B, 2), dim3(256), 0, st, k, wt, L, p.NT, q, onet);           // k^T -> wt, q^T -> wt + onet
+        if (int rc = check_launch("extract_links_bwd(transposed split)")) return rc;
+        p.pt = wt;
+        if (int rc = xm_launch<XM_DQ, 1, 1>(p, st, "extract_links_bwd(matrix-core dq)")) return rc;
+        p.pa = ws + one; p.pt = wt + onet; p.dout = grad_k;
+        return xm_launch<XM_DK, 1, 1>(p, st, "extract_links_bwd(matrix-core dk)");
+    }
     if (int rc = xm_launch<XM_DQ, 1>(p, st, "extract_links_bwd(matrix-core dq)")) return rc;
     p.pa = ws + one; p.dout = grad_k;
     return xm_launch<XM_DK, 1>(p, st, "extract_links_bwd(matrix-core dk)");

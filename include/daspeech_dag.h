@@ -163,7 +163,9 @@ int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace
  *   workgroups); bit-identical paths.  "xl_tile" n (r05): n > 0 forces the TILED extract_links kernels (include/daspeech_decode.h) with a tile
  *   of n slots on any window — by default they serve the windows whose one-image score tile does not fit LDS (TR above ~1100).
  *   "xl_mfma" -1|0|1 (r05): the matrix-core extract_links kernels (dsp_extract_links_ws / _bwd_ws) by size | never | wherever H = 8, CK = 64
- *   — it steers what dsp_extract_links_workspace reports.
+ *   — it steers what dsp_extract_links_workspace reports.  "xl_contract" -1|0|1 (r05): the contractions of dsp_extract_links_bwd_ws as
+ *   exact-fp32 MFMAs (0), as bf16-triple products (1: both operands split into three bf16 pieces, six MFMAs per product, fp32 range and
+ *   ~2^-23 relative) or by size (-1: the latter above ~1 500 vertices).
  *   dsp_dag_last_launch_status copies the device-side status word of the last fast-path launch on `stream` to *host_word (0 = clean, bit0 = a bounded hand-off spin timed out); it synchronises
  *   the stream and is meant for tests. */
 int dsp_dag_alignment_trace_optional(int L, int TR);

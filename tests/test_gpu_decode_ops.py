@@ -507,15 +507,20 @@ def test_matrix_core_extract_links_equal_the_fp32_kernels(B, L, TR, lens, use_bi
         _lib.set_option("xl_mfma", 0)
         ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
         _lib.set_option("xl_mfma", 1)
-        got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        gots = []
+        for contract in (0, 1):            # the backward's contractions: exact-fp32 MFMAs | bf16-triple products (the default above ~1 500 vertices)
+            _lib.set_option("xl_contract", contract)
+            gots.append(_links_fwd_bwd(olen, q0, k0, g0, w, TR, bias))
     finally:
         _lib.set_option("xl_mfma", -1)
-    for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
-        assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
-        assert torch.isfinite(a[torch.isfinite(b)]).all(), name
-        f = torch.isfinite(b)
-        sc = max(1.0, float(b[f].abs().max()))
-        assert float((a[f] - b[f]).abs().max()) <= 1e-5 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
+        _lib.set_option("xl_contract", -1)
+    for got in gots:
+        for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):
+            assert torch.equal(torch.isneginf(a), torch.isneginf(b)), name
+            assert torch.isfinite(a[torch.isfinite(b)]).all(), name
+            f = torch.isfinite(b)
+            sc = max(1.0, float(b[f].abs().max()))
+            assert float((a[f] - b[f]).abs().max()) <= 1e-5 * sc, (name, float((a[f] - b[f]).abs().max()), sc)
 
 
 @pytest.mark.gpu

@@ -24,6 +24,7 @@ for case in range(n):
     _lib.set_option("xl_tile", tile)
     mfma = int(rng.choice([0, 1, 1]))                                        # r05: the matrix-core kernels (8 x 64 heads), forced on graphs of every size
     _lib.set_option("xl_mfma", mfma)
+    _lib.set_option("xl_contract", int(rng.choice([0, 1])))                 # the backward's contractions: exact-fp32 MFMAs | bf16-triple products
     feats = rng.standard_normal((B, L, d)).astype(np.float32) * scale
     lens = rng.integers(1, L + 1, B); lens[0] = L
     prev = np.full((B, L), 3, np.int64); prev[np.arange(L)[None] >= lens[:, None]] = PAD
@@ -69,4 +70,5 @@ for case in range(n):
         bad += 1; print("FAIL", tag, "->", repr(e)[:300])
 _lib.set_option("xl_tile", 0)
 _lib.set_option("xl_mfma", -1)
+_lib.set_option("xl_contract", -1)
 print(f"{n} cases, {bad} failures")
