@@ -84,7 +84,7 @@ extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
         const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
         const long NS = (2L * B * ns1024 >= 200) ? ns1024 : ns512;
         halo = (size_t)2 * B * NS * T * 32 * 8;
-    } else if (TR <= 64 && !dense_mfma_supported(L, TR)) {      // banded 2-column strips of 512
+    } else if (TR <= 64) {                            // banded 2-column strips of 512 (log-space rows: windows 33 .. 64)
         halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
     } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
@@ -109,7 +109,7 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
         const size_t mx = (size_t)B * NS * T * 32 * 8;
         return align256(256 + (strip > mx ? strip : mx)) + 512;
     }
-    if (TR <= 64 && !dense_max_supported(L, TR)) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
+    if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
     if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
         const size_t NJ = (size_t)(L + 63) / 64;
         return align256(256 + align256((size_t)B * NJ * 4) + align256((size_t)B * T * NJ * 4) + (size_t)B * T * L * 2) + 512;     // (+ the block trace)
@@ -132,7 +132,8 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    else if ((g_path == 0 || g_path == 2) && TR <= 32 && banded_supported(L, TR))
+    // windows 33 .. 64: the banded log-space strips (C2 at TR = 64: 1.35 ms; the dense-window matrix-core DP with its mostly masked tiles 3.1-3.9)
+    else if ((g_path == 0 || g_path == 2) && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 9) && dense_mfma_supported(L, TR))
         rc = launch_dag_dense_mfma(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
@@ -183,8 +184,10 @@ static int best_alignment_impl(const float* match, const float* links, const int
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    // windows 33 .. 64 with a trace buffer: the banded log-space strips + trace walk (C2 at TR = 64: 2.0 ms against 3.1 for the dense kernels)
+    const bool mid = TR > 32 && TR <= 64 && trace && g_path == 0 && (size_t)L * 4 <= 160 * 1024 && banded_supported(L, TR);
     // dense window: blocked max-plus DP + trace-free back-trace (the trace buffer, if given, is left untouched)
-    if ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR))
+    if ((g_path == 0 || g_path == 9) && !mid && dense_max_supported(L, TR))
         return launch_dag_dense_max(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
     // trace == NULL: values-only DP + lazy back-trace (no B*T*L trace tensor); only the banded strip kernel offers it
     if (!trace || g_path == 7) {
@@ -198,7 +201,7 @@ static int best_alignment_impl(const float* match, const float* links, const int
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
         }
-        if ((g_path == 0 || g_path == 2) && TR <= 32 && banded_supported(L, TR)) {
+        if ((g_path == 0 || g_path == 2) && banded_supported(L, TR)) {
             rc = launch_dag_banded(1, match, links, out_len, tgt_len, alpha_max, nullptr, trace, B, T, L, TR, st);
             if (rc) return rc;
             return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);
@@ -256,6 +259,7 @@ extern "C" int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* 
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
 {
+    if (g_path == 0 && TR > 32 && TR <= 64) return 0;                      // the banded strips of this window keep a trace
     if ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR)) return 1;
     return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 8192) ? 1 : 0;
 }

@@ -521,8 +521,9 @@ def test_dense_mfma_dp_matches_oracle(shape, masked):
     m.requires_grad_()
     try:
         res = {}
-        # 9 = matrix-core kernel (also the auto choice) with 32-row (default) and 16-row chunks, 1 = log-space row-sequential kernels
-        for path, mt in ((9, 0), (9, 1), (1, 0)):
+        # 9 = matrix-core kernel (the auto choice above 64) with 32-row (default) and 16-row chunks, 1 = log-space row-sequential kernels,
+        # 0 = auto (r05: windows 33 .. 64 take the banded log-space strips)
+        for path, mt in ((9, 0), (9, 1), (1, 0), (0, 0)):
             _lib.set_option("dp_path", path); _lib.set_option("dm_mt", mt)
             loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
             assert _lib.last_launch_status() == 0
@@ -753,13 +754,14 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
         links = np.where(np.isfinite(links), np.round(links * 2) / 2, links).astype(np.float32)
     m, k, o, t = to_dev(match, links, ol, tl)
     ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+    mid = 32 < TR <= 64                          # r05: the auto choice for these windows is the banded log-space strips (with a trace); 9 pins the dense kernels
     try:
-        for path in (0, 1):
+        for path in (0, 1, 9):
             _lib.set_option("dp_path", path)
             got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
             assert _lib.last_launch_status() == 0
             np.testing.assert_array_equal(got, ref, err_msg=f"dp_path {path}")
-        _lib.set_option("dp_path", 0)
+        _lib.set_option("dp_path", 9 if mid else 0)
         for mt in (1, 2):                       # both chunk heights of the max-plus kernel (r05: 32 rows is what the largest launches take)
             _lib.set_option("dx_mt", mt)
             got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
@@ -767,7 +769,7 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
             np.testing.assert_array_equal(got, ref, err_msg=f"dx_mt {mt}")
     finally:
         _lib.set_option("dp_path", 0); _lib.set_option("dx_mt", 0)
-    assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == 1          # no B*T*L trace tensor for dense windows either
+    assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == (0 if mid else 1)    # no B*T*L trace tensor for dense windows either (the banded strips of 33 .. 64 keep one)
 
 
 def _relink(links, ol, seed):
