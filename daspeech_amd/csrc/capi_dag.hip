@@ -20,6 +20,7 @@ struct CallerWsScope {
     ~CallerWsScope() { status_end(st); caller_ws_end(); }
 };
 void set_k5_path(int v);
+void set_k5_fuse(int v);
 void set_mx_cpl(int v);
 void set_bt_ring(int v);
 int k5_diag(unsigned int* out);
@@ -268,6 +269,7 @@ extern "C" int dsp_dag_set_option(const char* name, int value)
 {
     if (name && !strcmp(name, "dp_path")) { g_path = value; return DSP_OK; }
     if (name && !strcmp(name, "k5_path")) { set_k5_path(value); return DSP_OK; }
+    if (name && !strcmp(name, "k5_fuse")) { set_k5_fuse(value); return DSP_OK; }
     if (name && !strcmp(name, "mx_cpl")) { set_mx_cpl(value); return DSP_OK; }
     if (name && !strcmp(name, "bt_ring")) { set_bt_ring(value); return DSP_OK; }
     if (name && !strcmp(name, "dm_depth")) { set_dm_depth(value); return DSP_OK; }

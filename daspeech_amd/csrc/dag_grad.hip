@@ -143,27 +143,52 @@ __global__ __launch_bounds__(256) void dag_grad_links_tiled_kernel(
 // link more than 69 nats under 0) or a W * Ga beyond 2^120: such lanes redo their vertices with the exact per-term form.
 // A W under 2^-126 flushes: the dropped term is < 2^-126 * Ga <= 2^-6 ... in the scaled sum, i.e. an ABSOLUTE error below
 // 2^-100 * ... of the final gradient — the reference's relative accuracy on gradients that are themselves < 1e-30 is not kept.
-constexpr int GX_TC = 4;
+//
+// FUSE (r06): the same launch also writes grad_match (K4, dag_loss.cu:378-401).  A pass already holds alpha[t] and beta[t+1] of the lane's
+// own four vertices in registers before it converts them; with beta[t] carried over from the previous pass (four registers) and the
+// match rows of the pass (MREG: prefetched into 4 x GX_TC registers across the consume phase; else LDS-DMA into a third raw buffer)
+// grad_match[t] = exp(alpha + beta - match - beta00) * go leaves the wave as one 16-byte store per lane and row: alpha and beta are read
+// ONCE for both gradients (K4 + K5 as two launches fetched them twice: 1.68 GB of HBM traffic for 1.107 GB of operands).  Rows
+// t >= T_b - 1 (no transition starts there: the last real row and the padding) go through a plain streaming tail, a row per wave.
 constexpr int GX_P = 296;                     // pitch of a converted beta row: 256 own + 36 halo columns, 16-byte multiple
 constexpr int GX_G = 76;                      // group exponents per row (73 used)
 constexpr int GX_NEG = -(1 << 30);
-constexpr int GX_WAVE_WORDS = 2 * GX_TC * GX_P + GX_TC * GX_G + 2 * GX_TC * 256;   // LDS words per wave
+constexpr int gx_wave_words(int TC, bool mraw) { return 2 * TC * GX_P + TC * GX_G + 2 * TC * 256 + (mraw ? TC * 256 : 0); }   // LDS words per wave
 __device__ unsigned int g_gx_diag[4];      // [0] lanes that took the exact redo, [1] of them: unsafe factor, [2] weak transition
 
+// K4's cell, bit for bit (dag_grad_match_kernel above): the fused kernel's grad_match equals the two-launch form exactly
+__device__ __forceinline__ float4 gx_match_cell(float4 a, float4 be, float4 m, float b00, float go, bool dead)
+{
+    float4 r;
+    r.x = (dead || isinf(m.x)) ? 0.f : __expf(a.x + be.x - m.x - b00) * go;
+    r.y = (dead || isinf(m.y)) ? 0.f : __expf(a.y + be.y - m.y - b00) * go;
+    r.z = (dead || isinf(m.z)) ? 0.f : __expf(a.z + be.z - m.z - b00) * go;
+    r.w = (dead || isinf(m.w)) ? 0.f : __expf(a.w + be.w - m.w - b00) * go;
+    return r;
+}
+
+template <int GX_TC, bool FUSE, bool MREG>
 __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ links, const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-    float* __restrict__ g_links, int B, int T, int L, int TR)
+    float* __restrict__ g_links, const float* __restrict__ match, float* __restrict__ g_match, int B, int T, int L, int TR)
 {
     extern __shared__ __attribute__((aligned(16))) char gx_smem[];
     constexpr float LOG2E = 1.4426950408889634f;
-    const int b = blockIdx.y, i0 = blockIdx.x * 256;
+    constexpr int GX_WAVE_WORDS = gx_wave_words(GX_TC, FUSE && !MREG);
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so linear ids k, k+8, k+16 ... share an L2.  Give each XCD a
+    // CONTIGUOUS run of (sample, column tile) pairs: neighbouring tiles re-read each other's 36 halo columns out of that L2, not HBM.
+    const int ntile = (L + 255) / 256, nwg = ntile * B;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+    const int b = wg / ntile, i0 = (wg - b * ntile) * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* Bq = reinterpret_cast<float*>(gx_smem) + (size_t)wave * GX_WAVE_WORDS;   // [TC][GX_P] values
     int* Xq = reinterpret_cast<int*>(Bq + GX_TC * GX_P);                                            // [TC][GX_G] group exponents
     float* Aq = reinterpret_cast<float*>(Xq + GX_TC * GX_G);                                        // [TC][256]  alpha rows (own vertices)
     float* Braw = Aq + GX_TC * 256;                                                                 // [TC][GX_P] beta rows as they arrive (LDS-DMA)
     float* Araw = Braw + GX_TC * GX_P;                                                              // [TC][256]  alpha rows as they arrive
+    float* Mraw = Araw + GX_TC * 256;                                                               // [TC][256]  match rows (FUSE && !MREG only)
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const size_t TL = (size_t)T * L;
     const float* A = alpha + (size_t)b * TL;
@@ -184,11 +209,29 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     bool bad = false;                                            // a factor left its safe range: redo this lane exactly
     // The rows of pass n+1 stream into LDS (LDS-DMA, no registers) while pass n is consumed: a memory round trip per pass
     // would otherwise be exposed (the conversion needs the data, and 190+ VGPRs of accumulators leave no room to prefetch).
+    const float* Mp = FUSE ? match + (size_t)b * TL : nullptr;
+    float* Gp = FUSE ? g_match + (size_t)b * TL : nullptr;
+    const float gom = FUSE ? g_out[b] : 0.f;
+    const bool dead4 = isinf(b00);                               // K4's own test (dag_loss.cu:394)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rm[GX_TC];                                            // MREG: the match rows of the NEXT pass, in flight across the consume phase
+    float4 carry = zero4;                                        // beta[tb][own vertices]: the last beta row of the previous pass
+#pragma unroll
+    for (int r = 0; r < GX_TC; ++r) rm[r] = zero4;
+    if (FUSE && tlo < thi && v0 < L) carry = *reinterpret_cast<const float4*>(Bp + (size_t)tlo * L + v0);
     auto request = [&](int tb0) {
         const int nr = min(GX_TC, thi - tb0);
+        if (FUSE && MREG) {
+#pragma unroll
+            for (int r = 0; r < GX_TC; ++r)
+                if (r < nr && v0 < L) rm[r] = *reinterpret_cast<const float4*>(Mp + (size_t)(tb0 + r) * L + v0);
+        }
         for (int r = 0; r < nr; ++r) {
             const float* brow = Bp + (size_t)(tb0 + r + 1) * L;
             const int c0 = i0 + 4 * lane, c1 = i0 + 256 + 4 * lane;
+            if (FUSE && !MREG)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Mp + (size_t)(tb0 + r) * L + (c0 < L ? c0 : 0)),
+                                                 (__attribute__((address_space(3))) void*)(Mraw + r * 256), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c0 < L ? c0 : 0)),
                                              (__attribute__((address_space(3))) void*)(Braw + r * GX_P), 16, 0, 0);
             if (lane < 9)
@@ -212,6 +255,17 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             ra[r] = *reinterpret_cast<const float4*>(Araw + r * 256 + 4 * lane);
             rb0[r] = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * lane);
             rb1[r] = *reinterpret_cast<const float4*>(Braw + r * GX_P + 4 * g1c);
+            if (FUSE && !MREG) rm[r] = *reinterpret_cast<const float4*>(Mraw + r * 256 + 4 * lane);
+        }
+        if (FUSE) {
+            // grad_match rows tb .. tb+rows-1: alpha[t] = ra[r], beta[t] = the previous row's rb0 (row tb: carried from the last pass)
+#pragma unroll
+            for (int r = 0; r < GX_TC; ++r) {
+                const float4 bt = r == 0 ? carry : rb0[r > 0 ? r - 1 : 0];
+                if (r < rows && v0 < L)
+                    *reinterpret_cast<float4*>(Gp + (size_t)(tb + r) * L + v0) = gx_match_cell(ra[r], bt, rm[r], b00, gom, dead4);
+            }
+            carry = rb0[GX_TC - 1];
         }
         const float4 ninf4 = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
         auto convert = [&](float4 v, bool live, int r, int g, bool store) {
@@ -243,13 +297,39 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
         // ---- consume: vertex v0+c, transition d -> window element q = c + 1 + d of the lane's 36-value window (groups lane .. lane+8)
         for (int r = 0; r < rows; ++r) {
             int xw[9]; float w[36];
-#pragma unroll
-            for (int g = 0; g < 9; ++g) xw[g] = Xq[r * GX_G + lane + g];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(Bq + r * GX_P + 4 * lane + 4 * k);
-                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            // r06: the row's 15 LDS reads (alpha, nine group exponents, the 36-value window) leave as ONE inline-asm issue group.  Written as
+            // C++ loads the compiler cannot prove them disjoint from the LDS-DMA writes of the NEXT pass (same extern array) and put an
+            // `s_waitcnt vmcnt(0)` in front of the first of them: every pass then waited for the next pass's rows BEFORE consuming its own —
+            // the prefetch overlapped nothing (r03-r05: 257 us per launch).  LDS returns in order; the waits below are counted.
+            typedef int gx_v2i __attribute__((ext_vector_type(2)));
+            typedef float gx_v4f __attribute__((ext_vector_type(4)));
+            gx_v4f avv, pv[9]; gx_v2i x01, x23, x45, x67; int x8;
+            {
+                const unsigned aaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Aq + r * 256 + 4 * lane);
+                const unsigned xaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Xq + r * GX_G + lane);
+                const unsigned vaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bq + r * GX_P + 4 * lane);
+                asm volatile("ds_read_b128 %0, %15\n\t"
+                             "ds_read2_b32 %1, %16 offset1:1\n\t"
+                             "ds_read2_b32 %2, %16 offset0:2 offset1:3\n\t"
+                             "ds_read2_b32 %3, %16 offset0:4 offset1:5\n\t"
+                             "ds_read2_b32 %4, %16 offset0:6 offset1:7\n\t"
+                             "ds_read_b32 %5, %16 offset:32\n\t"
+                             "ds_read_b128 %6, %17\n\t"
+                             "ds_read_b128 %7, %17 offset:16\n\t"
+                             "ds_read_b128 %8, %17 offset:32\n\t"
+                             "ds_read_b128 %9, %17 offset:48\n\t"
+                             "ds_read_b128 %10, %17 offset:64\n\t"
+                             "ds_read_b128 %11, %17 offset:80\n\t"
+                             "ds_read_b128 %12, %17 offset:96\n\t"
+                             "ds_read_b128 %13, %17 offset:112\n\t"
+                             "ds_read_b128 %14, %17 offset:128"
+                             : "=&v"(avv), "=&v"(x01), "=&v"(x23), "=&v"(x45), "=&v"(x67), "=&v"(x8),
+                               "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]), "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8])
+                             : "v"(aaddr), "v"(xaddr), "v"(vaddr)
+                             : "memory");
             }
+            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(avv), "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67), "+v"(x8));      // alpha + exponents are in
+            xw[0] = x01.x; xw[1] = x01.y; xw[2] = x23.x; xw[3] = x23.y; xw[4] = x45.x; xw[5] = x45.y; xw[6] = x67.x; xw[7] = x67.y; xw[8] = x8;
             // Three scale domains per lane-row, so that no factor can leave fp32 whatever the slope of the rows (next to the
             // DP's diagonal neighbouring vertices sit 25-35 binades apart):
             //   groups 1..7 (inside the band of all four vertices): reference R = their largest exponent, W = value * 2^(X - R) <= 1,
@@ -259,22 +339,31 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             int R = max(max(max(xw[1], xw[2]), max(xw[3], xw[4])), max(max(xw[5], xw[6]), xw[7]));
             const bool liveM = R != GX_NEG, live0 = xw[0] != GX_NEG, live8 = xw[8] != GX_NEG;
             if (!liveM) R = 0;
+            float fg[9];
 #pragma unroll
-            for (int g = 1; g < 8; ++g) {
-                const float f = ldexpf(1.0f, xw[g] - R);                    // <= 1; 0 for dead groups (ldexp saturates)
-                w[4 * g] *= f; w[4 * g + 1] *= f; w[4 * g + 2] *= f; w[4 * g + 3] *= f;
-            }
-            const float4 av = *reinterpret_cast<const float4*>(Aq + r * 256 + 4 * lane);
-            const float ua[4] = {av.x, av.y, av.z, av.w};
+            for (int g = 1; g < 8; ++g) fg[g] = ldexpf(1.0f, xw[g] - R);    // <= 1; 0 for dead groups (ldexp saturates)
+            const float ua[4] = {avv.x, avv.y, avv.z, avv.w};
             const float RM = (float)R - b00_2, R0 = (float)(live0 ? xw[0] : 0) - b00_2, R8 = (float)(live8 ? xw[8] : 0) - b00_2;
+            float GMs[4], G0s[4], G8s[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 4; ++c) {                                   // (the twelve v_exp run under the window reads still in flight)
                 const float u2 = ua[c] * LOG2E;
                 const float eM = u2 + RM, e0 = u2 + R0, e8 = u2 + R8;
                 bad |= (liveM & (eM > 126.f)) | (live0 & (c < 3) & (e0 > 126.f)) | (live8 & (e8 > 126.f));   // only with transitions < 2^-100
-                const float GM = (liveM & (eM <= 126.f)) ? __builtin_amdgcn_exp2f(eM) : 0.f;
-                const float G0 = (live0 & (c < 3) & (e0 <= 126.f)) ? __builtin_amdgcn_exp2f(e0) : 0.f;
-                const float G8 = (live8 & (e8 <= 126.f)) ? __builtin_amdgcn_exp2f(e8) : 0.f;
+                GMs[c] = (liveM & (eM <= 126.f)) ? __builtin_amdgcn_exp2f(eM) : 0.f;
+                G0s[c] = (live0 & (c < 3) & (e0 <= 126.f)) ? __builtin_amdgcn_exp2f(e0) : 0.f;
+                G8s[c] = (live8 & (e8 <= 126.f)) ? __builtin_amdgcn_exp2f(e8) : 0.f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float f = (k >= 1 && k <= 7) ? fg[k] : 1.0f;
+                w[4 * k] = pv[k].x; w[4 * k + 1] = pv[k].y; w[4 * k + 2] = pv[k].z; w[4 * k + 3] = pv[k].w;
+                if (k >= 1 && k <= 7) { w[4 * k] *= f; w[4 * k + 1] *= f; w[4 * k + 2] *= f; w[4 * k + 3] *= f; }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float GM = GMs[c], G0 = G0s[c], G8 = G8s[c];
 #pragma unroll
                 for (int d = 0; d < 32; ++d) {
                     const int q = c + 1 + d;
@@ -283,6 +372,26 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next pass overwrites the rows
+    }
+    if (FUSE && v0 < L) {
+        // rows T_b-1 .. T-1 (and every row of a dead sample): no transition term, K4 alone — streamed, four rows in flight per wave
+        for (int t = nt + wave; t < T; t += 16) {
+            float4 a4[4], b4[4], m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + 4 * u;
+                if (tt < T) {
+                    a4[u] = *reinterpret_cast<const float4*>(A + (size_t)tt * L + v0);
+                    b4[u] = *reinterpret_cast<const float4*>(Bp + (size_t)tt * L + v0);
+                    m4[u] = *reinterpret_cast<const float4*>(Mp + (size_t)tt * L + v0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + 4 * u;
+                if (tt < T) *reinterpret_cast<float4*>(Gp + (size_t)tt * L + v0) = gx_match_cell(a4[u], b4[u], m4[u], b00, gom, dead4);
+            }
+        }
     }
     // ---- transition weights; lanes with an unsafe factor or a transition under 2^-100 redo their sums term by term ----
     const float go = dead ? 0.f : g_out[b];
@@ -357,6 +466,9 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
 // thread_local pin was silently ignored by every backward driven through torch.autograd, r02 ADVICE).  g_k5_last records which
 // family the last backward launched (1 tiled log space, 2 exp space, 3 dense block products) so a test can assert its pin took.
 static std::atomic<int> g_k5_path{0};                      // 0 auto, 1 tiled log-space kernel, 2 exp-space kernel (TR <= 32) / dense block products (TR > 64)
+static std::atomic<int> g_k5_fuse{0};                      // TR <= 32 with both gradients wanted: 0 auto (= 2), 1 one fused launch (match rows in registers),
+                                                           // 2 one fused launch (match rows by LDS-DMA, 3-row passes), 3 two launches (K4, then K5)
+                                                           // C2 (r06): 297 / 277 / 445 us, gradients bit-identical
 static std::atomic<unsigned int> g_k5_last{0};
 int k5_diag(unsigned int* out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gx_diag), 16);
@@ -369,11 +481,34 @@ bool grad_dense_supported(int L, int TR);
 int launch_dag_grad_links_dense(const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, int, hipStream_t);
 
 void set_k5_path(int v) { g_k5_path = v; }
+void set_k5_fuse(int v) { g_k5_fuse = v; }
+
+template <int TC, bool FUSE, bool MREG>
+static int launch_gx(const float* g_out, const float* alpha, const float* beta, const float* links, const int64_t* out_len,
+                     const int64_t* tgt_len, float* g_links, const float* match, float* g_match, int B, int T, int L, int TR, hipStream_t st)
+{
+    const size_t lds = (size_t)4 * gx_wave_words(TC, FUSE && !MREG) * 4;
+    auto kern = dag_grad_links_exp_kernel<TC, FUSE, MREG>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(((L + 255) / 256) * B), dim3(256), lds, st,
+                       g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR);
+    return check_launch(FUSE ? "dag_loss_bwd(grad_match + grad_links, exp space, one launch)" : "dag_loss_bwd(grad_links, exp space)");
+}
 
 int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* beta, const float* match, const float* links,
                            const int64_t* out_len, const int64_t* tgt_len, float* g_match, float* g_links,
                            int B, int T, int L, int TR, hipStream_t st)
 {
+    const bool expk = TR <= 32 && (L & 3) == 0 && ((((uintptr_t)alpha) | ((uintptr_t)beta) | ((uintptr_t)g_links)) & 15) == 0;
+    const int fuse = g_k5_fuse.load();
+    // both gradients of a banded graph: ONE launch reads alpha / beta / match once (k5_last 4 / 5)
+    if (g_match && g_links && expk && g_k5_path != 1 && fuse != 3 && ((((uintptr_t)match) | ((uintptr_t)g_match)) & 15) == 0) {
+        int rc = fuse != 1 ? launch_gx<3, true, false>(g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR, st)
+                           : launch_gx<4, true, true>(g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR, st);
+        if (rc) return rc;
+        g_k5_last = fuse != 1 ? 5u : 4u;
+        return DSP_OK;
+    }
     if (g_match) {
         const size_t TL = (size_t)T * L;
         int gx = (int)((TL / 4 + 255) / 256); if (gx < 1) gx = 1; if (gx > 1024) gx = 1024;
@@ -381,13 +516,8 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         int rc = check_launch("dag_loss_bwd(grad_match)");
         if (rc) return rc;
     }
-    const bool expk = TR <= 32 && (L & 3) == 0 && ((((uintptr_t)alpha) | ((uintptr_t)beta) | ((uintptr_t)g_links)) & 15) == 0;
     if (g_links && expk && g_k5_path != 1) {
-        const size_t lds = (size_t)4 * GX_WAVE_WORDS * 4;
-        (void)hipFuncSetAttribute((const void*)dag_grad_links_exp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(dag_grad_links_exp_kernel, dim3((L + 255) / 256, B), dim3(256), lds, st,
-                           g_out, alpha, beta, links, out_len, tgt_len, g_links, B, T, L, TR);
-        int rc = check_launch("dag_loss_bwd(grad_links, exp space)");
+        int rc = launch_gx<4, false, false>(g_out, alpha, beta, links, out_len, tgt_len, g_links, nullptr, nullptr, B, T, L, TR, st);
         if (rc) return rc;
         g_k5_last = 2u;
     } else if (g_links && g_k5_path != 1 && grad_dense_supported(L, TR)) {

@@ -440,7 +440,8 @@ def test_grad_links_exp_space_weak_and_peaked_links(shape, k5):
         _lib.load().dsp_dag_debug_k5(diag)
     finally:
         _lib.set_option("k5_path", 0)
-    assert diag[3] == (2 if (k5 == 2 and L % 4 == 0) else 1)       # the pinned kernel family is the one that ran (autograd's worker thread sees the pin)
+    # the pinned kernel family is the one that ran (autograd's worker thread sees the pin); 5 = the exp-space kernel as ONE launch with grad_match (r06)
+    assert diag[3] == (5 if (k5 == 2 and L % 4 == 0) else 1)
     if k5 == 2 and L % 4 == 0:
         assert diag[2] > 0                               # the weak-transition redo really ran
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
@@ -986,3 +987,51 @@ def test_dense_window_c1_trained_model_like_scores_stay_on_the_matrix_cores():
         fa, fb = np.isfinite(a64), np.isfinite(b64)
         np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T + 1e-4)
         np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T + 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(4, 40, 1024, 32), (3, 33, 516, 20), (2, 50, 260, 7), (5, 70, 2048, 32)])
+def test_fused_backward_equals_the_two_launches(shape):
+    """r06: grad_match + grad_links of a banded graph in ONE launch (k5_fuse 1 / 2; auto = 2) are bit-identical to K4 followed by K5
+    (k5_fuse 3) and match the fp64 oracle — ragged target lengths (the streamed tail rows T_b-1 .. T-1), a sample with an unreachable end
+    (every row through the tail, zero gradients) and a -inf emission row included."""
+    from daspeech_amd import _lib
+    import ctypes
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(170 + L, B, T, L, TR)
+    tl[0] = max(2, T // 3)                                   # long tail of padding rows
+    if (tl[0] - 1) * TR < ol[0] - 1:
+        ol[0] = (tl[0] - 1) * TR + 1                         # keep the end reachable; transitions past the shorter graph do not exist
+    ii = np.arange(L)[:, None]; dd = np.arange(TR)[None, :]
+    links[0] = np.where(ii + dd + 1 < ol[0], links[0], -np.inf)
+    match[1 % B, 3, :] = -np.inf; match[1 % B, 3, 2 * TR] = -0.5
+    if B > 2:
+        tl[2] = 2; ol[2] = L                                 # end unreachable: loss = -inf, all gradients zero
+    m, k, o, t = to_dev(match, links, ol, tl)
+    got = {}
+    diag = (ctypes.c_uint * 4)()
+    try:
+        for fuse in (3, 1, 2, 0):
+            _lib.set_option("k5_fuse", fuse)
+            _lib.load().dsp_dag_debug_k5(diag)
+            mm = m.clone().requires_grad_(); kk = k.clone().requires_grad_()
+            loss = ops().dag_loss(mm, kk, o, t)
+            fin = torch.isfinite(loss)
+            w = torch.linspace(0.5, 1.5, B, device=dev())
+            gm, gl = torch.autograd.grad((loss.nan_to_num(neginf=0.0) * w).sum(), [mm, kk])
+            torch.cuda.synchronize()
+            _lib.load().dsp_dag_debug_k5(diag)
+            assert diag[3] == {3: 2, 1: 4, 2: 5, 0: 5}[fuse]
+            got[fuse] = (gm, gl)
+    finally:
+        _lib.set_option("k5_fuse", 0)
+    for fuse in (1, 2, 0):
+        assert torch.equal(got[fuse][0], got[3][0]) and torch.equal(got[fuse][1], got[3][1]), f"k5_fuse {fuse}"
+    assert not torch.isnan(got[0][0]).any() and not torch.isnan(got[0][1]).any()
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    go = (w.cpu().numpy() * fin.cpu().numpy()).astype(np.float64)
+    gm64, gl64 = orc.dag_grad(go, a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(got[0][0].cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(got[0][1].cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
+    if B > 2:
+        assert not fin[2] and got[0][0][2].abs().max() == 0 and got[0][1][2].abs().max() == 0
