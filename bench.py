@@ -69,7 +69,6 @@ def parse():
     ap.add_argument("--decode-strategy", default="lookahead", choices=["lookahead", "greedy", "viterbi", "jointviterbi"])
     ap.add_argument("--vocoder-group", type=int, default=None,
                     help="s2st: utterances per vocoder call (length-sorted groups; default: the whole batch for the fp32 vocoder, 8 for hip_fp16)")
-    ap.add_argument("--capture-graph", action="store_true", help="s2st: replay the shape-static front of the acoustic stage (encoder, NAT decoder, links) as a hipGraph per input shape")
     ap.add_argument("--no-overlap", action="store_true", help="s2st: one batch at a time (generator.generate) instead of the two-deep batch pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the cpu_baseline leg may take")
@@ -545,8 +544,7 @@ def build_model_step(ctx, args, workload):
     elif workload == "s2st":
         model.eval()
         voc = HiFiGANGenerator(conv_backend=args.vocoder_backend).to(dev).eval()
-        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=vocoder_group(args),
-                              capture_graph=getattr(args, "capture_graph", False))
+        gen = S2SNATGenerator(voc, torch.zeros(80, device=dev), torch.ones(80, device=dev), vocoder_group=vocoder_group(args))
         state["voc"] = voc
 
         def count(out):

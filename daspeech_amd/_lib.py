@@ -8,7 +8,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "lib", "libdaspeech_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPE_CODES = {"torch.float32": 0, "torch.float16": 1, "torch.bfloat16": 2}
 
 _c_i64 = ctypes.c_int64
@@ -33,6 +33,13 @@ SIGNATURES = {
                                   _c_p, _c_sz, _c_p]),
     "dsp_dag_loss_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                   _c_p, _c_sz, _c_p]),
+    "dsp_dag_loss_fwd_ld": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                     _c_p, _c_sz, _c_p]),
+    "dsp_dag_loss_bwd_ld": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                     _c_p, _c_sz, _c_p]),
+    "dsp_dag_best_alignment_ld": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                           _c_p, _c_sz, _c_p]),
+    "dsp_dag_pitch_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_alignment_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dsp_dag_best_alignment_ws": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p, _c_sz, _c_p]),
@@ -55,6 +62,7 @@ SIGNATURES = {
     "dsp_extract_links_ws": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_p, _c_sz, _c_p]),
     "dsp_extract_links_bwd_ws": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           ctypes.c_float, _c_p, _c_sz, _c_p]),
+    "dsp_extract_links_debug_ran": (ctypes.c_uint, []),
     "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_posterior_features": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_posterior_features_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),

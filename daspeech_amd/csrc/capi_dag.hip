@@ -4,10 +4,10 @@
 
 namespace dsp {
 int launch_dag_fwd_generic(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
-int launch_pick_loss(const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, hipStream_t);
+int launch_pick_loss(const float*, const float*, const int64_t*, const int64_t*, float*, int, int, int, int, hipStream_t);
 int launch_best_alignment_generic(const float*, const float*, const int64_t*, const int64_t*, float*, int32_t*, int64_t*, int, int, int, int, hipStream_t);
 int launch_dag_bwd_generic(const float*, const float*, const float*, const float*, const float*, const int64_t*, const int64_t*,
-                           float*, float*, int, int, int, int, hipStream_t);
+                           float*, float*, int, int, int, int, int, int, int, hipStream_t);
 
 bool banded_supported(int L, int TR);
 void caller_ws_begin(void* p, size_t n);
@@ -30,8 +30,8 @@ int launch_max_alpha_generic(const float* match, const float* links, const int64
                              float* alpha, int32_t* trace, int B, int T, int L, int TR, hipStream_t st);
 int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t* tgt_len, int64_t* path, int B, int T, int L, hipStream_t st);
 
-bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR);
-int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR, int ldm, int ldo);
+int launch_dag_strip4g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, int, int, hipStream_t);
 
 
 bool dense_mfma_supported(int L, int TR);
@@ -50,8 +50,8 @@ bool dense_max_supported(int L, int TR);
 int launch_dag_dense_max(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t, unsigned short* block_trace = nullptr);
 int launch_dag_dense_backtrace(const float*, const unsigned short*, const float*, const int64_t*, const int64_t*, int64_t*, int, int, int, int, hipStream_t);
 
-bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR);
-int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
+bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR, int ldm, int ldo);
+int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, int, int, hipStream_t);
 
 bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
@@ -77,25 +77,42 @@ using namespace dsp;
 // Scratch a forward launch takes from the caller (mirrors the launchers' own sizing; a launcher that finds the workspace too small
 // falls back to the library's scratch, so an under-estimate costs a hipMalloc, not correctness).
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+static size_t dense_fwd_ws_bytes(int B, int T, int L, int TR)
+{
+    // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
+    const size_t NJ = (size_t)(L + 63) / 64;
+    const size_t halo = align256((size_t)2 * B * NJ * 4) + align256((size_t)2 * B * T * NJ * 8);
+    // ... and its stand-by log-space kernels (a batch whose transitions exp space cannot hold): hand-off rows + the re-laid-out
+    // ("incoming") copy of the transition matrix
+    if (dense_mfma_supported(L, TR) && dense_rows_gated_supported(L))
+        return align256(256 + halo + dense_rows_gated_bytes(B, L, 2)) + align256((size_t)B * L * TR * 4) + 1024;
+    return align256(256 + halo) + 512;
+}
+static size_t dense_align_ws_bytes(int B, int T, int L, int TR)
+{
+    if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
+        const size_t NJ = (size_t)(L + 63) / 64;
+        return align256(256 + align256((size_t)B * NJ * 4) + align256((size_t)B * T * NJ * 4) + (size_t)B * T * L * 2) + 512;     // (+ the block trace)
+    }
+    return align256((size_t)B * L * TR * 4) + align256(256 + (size_t)B * 2 * L * 8) + 1024;
+}
+
 extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
 {
     if (B <= 0 || T <= 0 || L <= 0 || TR <= 0) return 0;
-    size_t halo;
     if (TR <= 32 && !(L & 3)) {                       // strip4g: 1024-column strips when they still fill the chip, else 512
         const long ns1024 = (L + 1023) / 1024, ns512 = (L + 511) / 512;
         const long NS = (2L * B * ns1024 >= 200) ? ns1024 : ns512;
-        halo = (size_t)2 * B * NS * T * 32 * 8;
-    } else if (TR <= 64) {                            // banded 2-column strips of 512 (log-space rows: windows 33 .. 64)
-        halo = (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8;
-    } else {                                          // dense window on the matrix cores: progress words + (exponent, first-live) per (row, block)
-        const size_t NJ = (size_t)(L + 63) / 64;
-        halo = align256((size_t)2 * B * NJ * 4) + align256((size_t)2 * B * T * NJ * 8);
-        // ... and its stand-by log-space kernels (a batch whose transitions exp space cannot hold): hand-off rows + the re-laid-out
-        // ("incoming") copy of the transition matrix
-        if (dense_mfma_supported(L, TR) && dense_rows_gated_supported(L))
-            return align256(256 + halo + dense_rows_gated_bytes(B, L, 2)) + align256((size_t)B * L * TR * 4) + 1024;
+        return align256(256 + (size_t)2 * B * NS * T * 32 * 8) + 512;
     }
-    return align256(256 + halo) + 512;
+    if (TR <= 64) {                                   // banded 2-column strips of 512 (log-space rows: windows 33 .. 64) ...
+        const size_t banded = align256(256 + (size_t)2 * B * ((L + 511) / 512) * T * (TR <= 32 ? 32 : 64) * 8) + 512;
+        // ... which the dense kernels serve instead under dp_path 9 (r05 ADVICE: sized for whichever family runs, so that the launch never falls
+        // back to the library's own scratch — a hipMalloc per call, not capturable)
+        const size_t dense = (TR > 32 && dense_mfma_supported(L, TR)) ? dense_fwd_ws_bytes(B, T, L, TR) : 0;
+        return banded > dense ? banded : dense;
+    }
+    return dense_fwd_ws_bytes(B, T, L, TR);
 }
 
 // ... and the alignment (dsp_dag_best_alignment_ws): the value-only strip DP's hand-off rows, or for dense windows the re-laid-out
@@ -110,27 +127,44 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
         const size_t mx = (size_t)B * NS * T * 32 * 8;
         return align256(256 + (strip > mx ? strip : mx)) + 512;
     }
-    if (TR <= 64) return align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
-    if (dense_max_supported(L, TR)) {                 // blocked max-plus DP: progress words + one block maximum per (row, block)
-        const size_t NJ = (size_t)(L + 63) / 64;
-        return align256(256 + align256((size_t)B * NJ * 4) + align256((size_t)B * T * NJ * 4) + (size_t)B * T * L * 2) + 512;     // (+ the block trace)
+    if (TR <= 64) {                                   // banded strips + trace walk; without a trace buffer / under dp_path 9 / L * 4 > 160 KB: the dense kernels
+        const size_t banded = align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
+        const size_t dense = dense_max_supported(L, TR) ? dense_align_ws_bytes(B, T, L, TR) : 0;
+        return banded > dense ? banded : dense;
     }
-    return align256((size_t)B * L * TR * 4) + align256(256 + (size_t)B * 2 * L * 8) + 1024;
+    return dense_align_ws_bytes(B, T, L, TR);
 }
 
-extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                                float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
-                                void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+// Row pitches (r06, ABI 2): ld_match / ld_ab are the distances in ELEMENTS between consecutive target rows of match and of alpha / beta
+// (batch stride = T * ld).  Dense tensors have ld = L (dsp_dag_loss_fwd).  A graph whose length is not a multiple of 4 — three in four are —
+// keeps its rows on 16-byte boundaries by a pitch rounded up to 4: the TR <= 32 strip kernels then serve it without a padded copy
+// (dag_logsoftmax_gather_inplace writes `match` with such a pitch itself).  The other kernel families take dense tensors only.
+static int check_ld(const char* fn, int L, int ld_match, int ld_ab)
+{
+    if (ld_match < L || ld_ab < L) { set_error("%s: row pitch smaller than L (ld_match=%d ld_ab=%d L=%d)", fn, ld_match, ld_ab, L); return DSP_EINVAL; }
+    return DSP_OK;
+}
+
+extern "C" int dsp_dag_loss_fwd_ld(const float* match, int ld_match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                   float* alpha, float* beta, int ld_ab, float* loss, int B, int T, int L, int TR,
+                                   void* workspace, size_t workspace_bytes, dsp_stream_t stream)
 {
     CallerWsScope ws_scope(workspace, workspace_bytes, as_stream(stream));
     int rc = check_dims("dag_loss_fwd", B, T, L, TR);
     if (rc) return rc;
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd: null pointer"); return DSP_EINVAL; }
+    if ((rc = check_ld("dag_loss_fwd", L, ld_match, ld_ab))) return rc;
     hipStream_t st = as_stream(stream);
+    const bool dense = ld_match == L && ld_ab == L;
     // auto: strip4g for the log-sum DP, strip2 for the max-DP with a trace
-    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR))
-        rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
+    if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR, ld_match, ld_ab))
+        rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, ld_match, ld_ab, st);
+    else if (!dense) {
+        set_error("dag_loss_fwd: pitched rows (ld_match=%d ld_ab=%d, L=%d) are served by the TR <= 32 strip kernels only (16-byte aligned pointers, "
+                  "pitches that are multiples of 4); TR=%d / this kernel pin needs dense tensors", ld_match, ld_ab, L, TR);
+        return DSP_EINVAL;
+    }
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     // windows 33 .. 64: the banded log-space strips (C2 at TR = 64: 1.35 ms; the dense-window matrix-core DP with its mostly masked tiles 3.1-3.9)
@@ -141,8 +175,32 @@ extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const in
     else
         rc = launch_dag_fwd_generic(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     if (rc) return rc;
-    if (loss) rc = launch_pick_loss(alpha, beta, out_len, tgt_len, loss, B, T, L, st);
+    if (loss) rc = launch_pick_loss(alpha, beta, out_len, tgt_len, loss, B, T, L, ld_ab, st);
     return rc;
+}
+
+extern "C" int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
+                                void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    return dsp_dag_loss_fwd_ld(match, L, links, out_len, tgt_len, alpha, beta, L, loss, B, T, L, TR, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dsp_dag_loss_bwd_ld(const float* grad_out, const float* alpha, const float* beta, int ld_ab, const float* match, int ld_match,
+                                   const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                   float* grad_match, int ld_grad_match, float* grad_links, int B, int T, int L, int TR,
+                                   void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    (void)workspace; (void)workspace_bytes;
+    int rc = check_dims("dag_loss_bwd", B, T, L, TR);
+    if (rc) return rc;
+    if (B == 0) return DSP_OK;
+    if (!grad_out || !alpha || !beta || !match || !links || !out_len || !tgt_len) { set_error("dag_loss_bwd: null pointer"); return DSP_EINVAL; }
+    if ((rc = check_ld("dag_loss_bwd", L, ld_match, ld_ab))) return rc;
+    if (grad_match && ld_grad_match < L) { set_error("dag_loss_bwd: ld_grad_match=%d smaller than L=%d", ld_grad_match, L); return DSP_EINVAL; }
+    if (ld_ab != L && TR > 32) { set_error("dag_loss_bwd: pitched alpha / beta are served for TR <= 32 only (TR=%d)", TR); return DSP_EINVAL; }
+    return launch_dag_bwd_generic(grad_out, alpha, beta, match, links, out_len, tgt_len, grad_match, grad_links, B, T, L, TR,
+                                  ld_ab, ld_match, grad_match ? ld_grad_match : L, as_stream(stream));
 }
 
 extern "C" int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* beta, const float* match,
@@ -150,16 +208,13 @@ extern "C" int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const
                                 float* grad_match, float* grad_links, int B, int T, int L, int TR,
                                 void* workspace, size_t workspace_bytes, dsp_stream_t stream)
 {
-    (void)workspace; (void)workspace_bytes;
-    int rc = check_dims("dag_loss_bwd", B, T, L, TR);
-    if (rc) return rc;
-    if (B == 0) return DSP_OK;
-    if (!grad_out || !alpha || !beta || !match || !links || !out_len || !tgt_len) { set_error("dag_loss_bwd: null pointer"); return DSP_EINVAL; }
-    return launch_dag_bwd_generic(grad_out, alpha, beta, match, links, out_len, tgt_len, grad_match, grad_links, B, T, L, TR, as_stream(stream));
+    return dsp_dag_loss_bwd_ld(grad_out, alpha, beta, L, match, L, links, out_len, tgt_len, grad_match, L, grad_links, B, T, L, TR,
+                               workspace, workspace_bytes, stream);
 }
 
 static int best_alignment_impl(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream);
+                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream,
+                               int ld_match = 0, int ld_am = 0);
 
 extern "C" int dsp_dag_best_alignment(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                                       float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
@@ -177,14 +232,35 @@ extern "C" int dsp_dag_best_alignment_ws(const float* match, const float* links,
     return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream);
 }
 
+// ... with row pitches (see dsp_dag_loss_fwd_ld): ld_match / ld_am = elements between consecutive rows of match / alpha_max.  Pitched rows are
+// served by the values-only strip DP + lazy back-trace (TR <= 32, no trace tensor); `trace` must be dense ([B,T,L]) if given and is left untouched.
+extern "C" int dsp_dag_best_alignment_ld(const float* match, int ld_match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                                         float* alpha_max, int ld_am, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                                         void* workspace, size_t workspace_bytes, dsp_stream_t stream)
+{
+    CallerWsScope ws_scope(workspace, workspace_bytes, as_stream(stream));
+    return best_alignment_impl(match, links, out_len, tgt_len, alpha_max, trace, path, B, T, L, TR, stream, ld_match, ld_am);
+}
+
 static int best_alignment_impl(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream)
+                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream,
+                               int ld_match, int ld_am)
 {
     int rc = check_dims("dag_best_alignment", B, T, L, TR);
     if (rc) return rc;
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !path) { set_error("dag_best_alignment: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
+    if (ld_match == 0) ld_match = L;
+    if (ld_am == 0) ld_am = L;
+    if ((rc = check_ld("dag_best_alignment", L, ld_match, ld_am))) return rc;
+    if (ld_match != L || ld_am != L) {
+        if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR, ld_match, ld_am))
+            return launch_dag_maxstrip(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, ld_match, ld_am, st);
+        set_error("dag_best_alignment: pitched rows (ld_match=%d ld_alpha_max=%d, L=%d) are served by the TR <= 32 strip kernels only (L <= 8192, "
+                  "16-byte aligned pointers, pitches that are multiples of 4)", ld_match, ld_am, L);
+        return DSP_EINVAL;
+    }
     // windows 33 .. 64 with a trace buffer: the banded log-space strips + trace walk (C2 at TR = 64: 2.0 ms against 3.1 for the dense kernels)
     const bool mid = TR > 32 && TR <= 64 && trace && g_path == 0 && (size_t)L * 4 <= 160 * 1024 && banded_supported(L, TR);
     // dense window: blocked max-plus DP + trace-free back-trace (the trace buffer, if given, is left untouched)
@@ -192,8 +268,8 @@ static int best_alignment_impl(const float* match, const float* links, const int
         return launch_dag_dense_max(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
     // trace == NULL: values-only DP + lazy back-trace (no B*T*L trace tensor); only the banded strip kernel offers it
     if (!trace || g_path == 7) {
-        if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR))
-            return launch_dag_maxstrip(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
+        if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR, L, L))
+            return launch_dag_maxstrip(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, L, L, st);
         if (!trace) { set_error("dag_best_alignment: this shape / kernel family needs a trace buffer (see dsp_dag_alignment_trace_optional)"); return DSP_EINVAL; }
     }
     if ((size_t)L * 4 <= 160 * 1024) {
@@ -256,6 +332,15 @@ extern "C" int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* 
     if (!alpha_max || !block_trace || !links || !out_len || !tgt_len || !path) { set_error("dag_backtrace_blocks: null pointer"); return DSP_EINVAL; }
     if (!dense_max_supported(L, TR)) { set_error("dag_backtrace_blocks: L=%d TR=%d is not a dense-window shape", L, TR); return DSP_EINVAL; }
     return launch_dag_dense_backtrace(alpha_max, block_trace, links, out_len, tgt_len, path, B, T, L, TR, as_stream(stream));
+}
+
+// May the caller hand this op PITCHED rows (dsp_dag_loss_fwd_ld / _bwd_ld: op 0, dsp_dag_best_alignment_ld: op 1) for a graph of L vertices?  Only
+// the TR <= 32 strip families take them, so the answer follows the calling thread's dp_path pin like the dispatch itself does.
+extern "C" int dsp_dag_pitch_supported(int op, int L, int TR)
+{
+    if (TR > 32 || L < 1) return 0;
+    if (op == 0) return (g_path == 0 || g_path == 5) ? 1 : 0;
+    return ((g_path == 0 || g_path == 7) && L <= 8192) ? 1 : 0;
 }
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)

@@ -113,15 +113,15 @@ __global__ __launch_bounds__(DP_THREADS) void dag_logsum_generic_kernel(
 // (st_src / st_dst: the launch's 64 status words move from caller memory to the library's status buffer on the way — see status_end in
 //  dag_dp_banded.hip; a separate 256-byte device-to-device copy costs 5 us, 1 % of the C2 forward)
 __global__ void dag_pick_loss_kernel(const float* alpha, const float* beta, const int64_t* out_len,
-                                     const int64_t* tgt_len, float* loss, int B, int T, int L,
+                                     const int64_t* tgt_len, float* loss, int B, int T, int L, int ld,
                                      const unsigned int* st_src, unsigned int* st_dst)
 {
     if (st_src && blockIdx.x == 0 && threadIdx.x < 64) st_dst[threadIdx.x] = st_src[threadIdx.x];
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    if (beta) { loss[b] = beta[(size_t)b * T * L]; return; }
+    if (beta) { loss[b] = beta[(size_t)b * T * ld]; return; }                 // ld: row pitch of alpha / beta (= L for dense tensors)
     int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
-    loss[b] = (Tb >= 1 && Tb <= T && Lb >= 1 && Lb <= L) ? alpha[(size_t)b * T * L + (size_t)(Tb - 1) * L + (Lb - 1)] : NEG_INF;
+    loss[b] = (Tb >= 1 && Tb <= T && Lb >= 1 && Lb <= L) ? alpha[(size_t)b * T * ld + (size_t)(Tb - 1) * ld + (Lb - 1)] : NEG_INF;
 }
 
 // K6: max-DP + trace.  Tie rule = smallest predecessor index (scan predecessors ascending, strict >).
@@ -531,11 +531,11 @@ int launch_dag_dense_rows_gated(const float* match, const float* links, const in
 
 bool status_export(hipStream_t st, const unsigned int** src, unsigned int** dst);
 int launch_pick_loss(const float* alpha, const float* beta, const int64_t* out_len, const int64_t* tgt_len, float* loss,
-                     int B, int T, int L, hipStream_t st)
+                     int B, int T, int L, int ld, hipStream_t st)
 {
     const unsigned int* ssrc = nullptr; unsigned int* sdst = nullptr;
     (void)status_export(st, &ssrc, &sdst);
-    hipLaunchKernelGGL(dag_pick_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, st, alpha, beta, out_len, tgt_len, loss, B, T, L, ssrc, sdst);
+    hipLaunchKernelGGL(dag_pick_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, st, alpha, beta, out_len, tgt_len, loss, B, T, L, ld, ssrc, sdst);
     return check_launch("dag_pick_loss");
 }
 

@@ -32,6 +32,7 @@ struct MStripParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS;
+    int ldm, ldo;                             // row pitch (elements) of match / alpha_max: >= L rounded up to 4, multiples of 4 (r06)
     int dbg;                                  // DSP_DEBUG=prof (2): cycle accounting of one compute wave (counters[8..12]); DSP_MX_ABLATE bits 4 / 8 / 16: no alpha
                                               // store / no max trees / no adds either (timing experiments, results wrong)
 };
@@ -67,9 +68,10 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
     const int T = p.T, L = p.L, TR = p.TR;
     const int j0 = s * W;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
-    const float* M = p.match + (size_t)b * T * L;
+    const float* M = p.match + (size_t)b * T * p.ldm;
     const float* K = p.links + (size_t)b * L * TR;
-    float* O = p.alpha + (size_t)b * T * L;
+    float* O = p.alpha + (size_t)b * T * p.ldo;
+    const int LDM = p.ldm, LDO = p.ldo;
     const int nrows = Tb;
 
     const bool has_producer = so > 0;
@@ -249,13 +251,13 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
             const bool st_ok = col_ok && !(MX_DBG(p) & 4);
             if constexpr (CPL == 4) {
                 *reinterpret_cast<float4*>(Abuf + cur * RL + 32 + 4 * l) = make_float4(a[0], a[1], a[2], a[3]);
-                if (st_ok) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a[0], a[1], a[2], a[3]);
+                if (st_ok) *reinterpret_cast<float4*>(O + (size_t)t * LDO + j) = make_float4(a[0], a[1], a[2], a[3]);
             } else if constexpr (CPL == 1) {
                 Abuf[cur * RL + 32 + l] = a[0];
-                if (st_ok) O[(size_t)t * L + j] = a[0];
+                if (st_ok) O[(size_t)t * LDO + j] = a[0];
             } else {
                 *reinterpret_cast<float2*>(Abuf + cur * RL + 32 + 2 * l) = make_float2(a[0], a[1]);
-                if (st_ok) *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(a[0], a[1]);
+                if (st_ok) *reinterpret_cast<float2*>(O + (size_t)t * LDO + j) = make_float2(a[0], a[1]);
             }
             if (prof) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stamp(2);                                       // stores issued, LDS write done
@@ -264,14 +266,14 @@ __device__ __forceinline__ void maxstrip_body(const MStripParams& p, char* smem_
         }
         if (prof && lane == 0) { for (int i = 0; i < 4; ++i) p.counters[8 + i] = (u32)(pf[i] >> 4); p.counters[12] = (u32)nrows; }
         if (col_ok) for (int t = Tb; t < T; ++t) {
-            if constexpr (CPL == 4) *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-            else if constexpr (CPL == 1) O[(size_t)t * L + j] = NEG_INF;
-            else *reinterpret_cast<float2*>(O + (size_t)t * L + j) = make_float2(NEG_INF, NEG_INF);
+            if constexpr (CPL == 4) *reinterpret_cast<float4*>(O + (size_t)t * LDO + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            else if constexpr (CPL == 1) O[(size_t)t * LDO + j] = NEG_INF;
+            else *reinterpret_cast<float2*>(O + (size_t)t * LDO + j) = make_float2(NEG_INF, NEG_INF);
         }
     } else if (wave == NCW) {
         // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA)
         auto issue_row = [&](int itr) {
-            const float* rowp = M + (size_t)itr * L;
+            const float* rowp = M + (size_t)itr * LDM;
             float* slot = Mring + (size_t)(itr % MX_RING) * W;
 #pragma unroll
             for (int i = 0; i < DPR; ++i) {
@@ -369,10 +371,10 @@ __global__ __launch_bounds__(NT + 192) void dag_maxstrip_kernel(MStripParams p)
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
     if (!valid || j0 >= Lb) {                    // nothing reachable in this strip: -inf everywhere, no hand-off
-        float* O = p.alpha + (size_t)b * T * L;
+        float* O = p.alpha + (size_t)b * T * p.ldo;
         for (int j = j0 + 4 * tid; j < j0 + W && j < L; j += 4 * (NT + 192))
             for (int t = 0; t < T; ++t)
-                *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+                *reinterpret_cast<float4*>(O + (size_t)t * p.ldo + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
         return;
     }
     maxstrip_body<NT, CPL>(p, smem_raw + 16, b, s, so);
@@ -409,7 +411,7 @@ __device__ __forceinline__ float bt_max_lanes32(float v) {
 
 __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
     const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len,
-    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L, int TR)
+    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L, int TR, int LDA)
 {
     extern __shared__ __attribute__((aligned(16))) char bt_smem[];
     float* lk = reinterpret_cast<float*>(bt_smem);                       // [BT_LW][TR]  rows lbase .. lbase + BT_LW - 1
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
     for (int j = tid; j < L; j += 256) lp[j] = -1;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
-    const float* A = amax + (size_t)b * T * L;
+    const float* A = amax + (size_t)b * T * LDA;
     const float* K = links + (size_t)b * L * TR;
     int pos = Lb - 1, t = Tb - 1, lbase = 0x3fffffff;
     bool done = !valid;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
 #pragma unroll
         for (int k = 1; k <= BT_HOPS; ++k) {
             const int row = tF - BT_HOPS - k, col0 = pF - 32 * (BT_HOPS + k), qmax = 31 * (BT_HOPS + k);
-            const float* base = A + (long)(row < 0 ? 0 : row) * L + col0;       // wave-uniform
+            const float* base = A + (long)(row < 0 ? 0 : row) * LDA + col0;       // wave-uniform
 #pragma unroll
             for (int j = 0; j < BT_SEG / 192; ++j) {
                 const int q = q0 + 192 * j, col = col0 + q;
@@ -537,7 +539,7 @@ constexpr int BR_SEG = 448;                    // segment pitch: >= 62 H + 1 = 4
 
 __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
     const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len,
-    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L)
+    const int64_t* __restrict__ tgt_len, int64_t* __restrict__ path, int B, int T, int L, int LDA)
 {
     constexpr int TR = 32;
     extern __shared__ __attribute__((aligned(16))) char br_smem[];
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
     for (int j = tid; j < L; j += 256) lp[j] = -1;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
-    const float* A = amax + (size_t)b * T * L;
+    const float* A = amax + (size_t)b * T * LDA;
     const float* K = links + (size_t)b * L * TR;
     int pos = Lb - 1, t = Tb - 1;
     bool done = !valid;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
 #pragma unroll
         for (int k = 1; k <= BR_H; ++k) {
             const int row = tF - BR_H - k, col0 = pF - 32 * (BR_H + k), nreq = (31 * (BR_H + k) + 64) >> 6;
-            const float* rowp = A + (size_t)(row < 0 ? 0 : row) * L;          // wave-uniform
+            const float* rowp = A + (size_t)(row < 0 ? 0 : row) * LDA;          // wave-uniform
             float* dst = seg + ((size_t)buf * BR_H + (k - 1)) * BR_SEG;
 #pragma unroll
             for (int j = 0; j < (31 * (2 * BR_H) + 64) / 64; ++j) {
@@ -646,9 +648,9 @@ __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
-bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR)
+bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR, int ldm, int ldo)
 {
-    if (TR > 32 || (L & 3)) return false;
+    if (TR > 32 || (ldm & 3) || (ldo & 3) || ldm < ((L + 3) & ~3) || ldo < ((L + 3) & ~3)) return false;
     if (L > 8192) return false;                                // back-trace: path image (4L) + transition window (96 KB) + segments (25 KB) in LDS
     const uintptr_t a = (uintptr_t)match | (uintptr_t)alpha_max;
     return (a & 15) == 0;
@@ -674,7 +676,7 @@ void set_mx_cpl(int v) { g_mx_cpl = v; }
 
 // alpha_max by column strips (values only), then the lazy back-trace: no trace tensor
 int launch_dag_maxstrip(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                        float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+                        float* alpha_max, int64_t* path, int B, int T, int L, int TR, int ldm, int ldo, hipStream_t st)
 {
     // one direction only: 4 vertices per lane in 1024-vertex strips when that still fills the chip (>= ~200 workgroups),
     // otherwise 2 vertices per lane in 512-vertex strips (twice the waves for the same vertices)
@@ -684,7 +686,7 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     const int NS = cpl == 4 ? ns1024 : (cpl == 2 ? ns512 : ns256);
     MStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ldm = ldm; p.ldo = ldo;
 #ifdef DSP_MX_PROF                                  // instrumentation build only (tools/prof_maxstrip.py): nothing on the product's launch path
     { static const char* const e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "prof")) ? 2 : 0; static const char* const a = getenv("DSP_MX_ABLATE"); if (a) p.dbg |= atoi(a) & 28; }
 #else
@@ -698,12 +700,12 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     if (TR == 32 && g_bt_ring && (((uintptr_t)links) & 15) == 0) {
         const size_t lds3 = ((size_t)BR_RW * 32 + 2 * BR_H * BR_SEG + (size_t)L) * 4;
         (void)hipFuncSetAttribute((const void*)dag_backtrace_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        hipLaunchKernelGGL(dag_backtrace_ring_kernel, dim3(B), dim3(256), lds3, st, alpha_max, links, out_len, tgt_len, path, B, T, L);
+        hipLaunchKernelGGL(dag_backtrace_ring_kernel, dim3(B), dim3(256), lds3, st, alpha_max, links, out_len, tgt_len, path, B, T, L, ldo);
         return check_launch("dag_best_alignment(ring back-trace)");
     }
     const size_t lds2 = ((size_t)BT_LW * TR + BT_HOPS * BT_SEG + (size_t)L) * 4;
     (void)hipFuncSetAttribute((const void*)dag_backtrace_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(dag_backtrace_lazy_kernel, dim3(B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR);
+    hipLaunchKernelGGL(dag_backtrace_lazy_kernel, dim3(B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR, ldo);
     return check_launch("dag_best_alignment(lazy back-trace)");
 }
 

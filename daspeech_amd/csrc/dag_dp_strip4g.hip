@@ -31,6 +31,7 @@ struct GStripParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
+    int ldm, ldo;                             // row pitch (elements) of match and of alpha / beta: >= L, multiples of 4 (r06: graphs whose length is not)
     int dbg;
 };
 
@@ -91,9 +92,10 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
     const int T = p.T, L = p.L, TR = p.TR;
     const int j0 = s * W;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
-    const float* M = p.match + (size_t)b * T * L;
+    const float* M = p.match + (size_t)b * T * p.ldm;
     const float* K = p.links + (size_t)b * L * TR;
-    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * L;
+    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
+    const int LDM = p.ldm, LDO = p.ldo;
     const int nrows = Tb;
 
     const bool has_producer = so > 0 && (BETA ? (j0 + W < Lb) : true);
@@ -445,18 +447,18 @@ __device__ __forceinline__ void strip4g_body(const GStripParams& p, char* smem_r
             Xbuf[cur * GL + (own_li0 >> 2) + l] = xn;
             *reinterpret_cast<float4*>(Abuf + cur * RL + own_li0 + 4 * l) = make_float4(a2[0], a2[1], a2[2], a2[3]);
             if (col_ok)
-                *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(a2[0] * G4_LN2, a2[1] * G4_LN2, a2[2] * G4_LN2, a2[3] * G4_LN2);
+                *reinterpret_cast<float4*>(O + (size_t)t * LDO + j) = make_float4(a2[0] * G4_LN2, a2[1] * G4_LN2, a2[2] * G4_LN2, a2[3] * G4_LN2);
             g4_barrier<PROF>(pf);
         }
         // rows the recurrence never reaches
         if (col_ok) for (int t = Tb; t < T; ++t) {
-            *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            *reinterpret_cast<float4*>(O + (size_t)t * LDO + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
         }
     } else if (wave == NCW) {
         // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA)
         auto issue_row = [&](int itr) {
             const int t = BETA ? (Tb - 1 - itr) : itr;
-            const float* rowp = M + (size_t)t * L;
+            const float* rowp = M + (size_t)t * LDM;
             float* slot = Mring + (size_t)(itr % G4_RING) * W;
 #pragma unroll
             for (int i = 0; i < DPR; ++i) {
@@ -594,9 +596,9 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4g_kernel(GStripParams p)
         if (tid < NT) {
             const int j = j0 + 4 * tid;
             if (j < L) {
-                float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * L;
+                float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
                 for (int t = 0; t < T; ++t) {
-                    *reinterpret_cast<float4*>(O + (size_t)t * L + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+                    *reinterpret_cast<float4*>(O + (size_t)t * p.ldo + j) = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
                 }
             }
         }
@@ -610,9 +612,11 @@ __global__ __launch_bounds__(NT + 192) void dag_strip4g_kernel(GStripParams p)
 // ------------------------------------------------------------------------------------------------ host side
 int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, u64** halo, u32* tag_base);
 
-bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR)
+bool strip4g_supported(const void* match, const void* alpha, const void* beta, int L, int TR, int ldm, int ldo)
 {
-    if (TR > 32 || (L & 3)) return false;
+    // rows start on 16-byte boundaries: the PITCHES are multiples of 4, the graph length need not be (a lane whose four columns straddle L
+    // loads / stores inside the pitch padding; columns >= L are outside every sample's graph and come out -inf)
+    if (TR > 32 || (ldm & 3) || (ldo & 3) || ldm < ((L + 3) & ~3) || ldo < ((L + 3) & ~3)) return false;
     const uintptr_t a = (uintptr_t)match | (uintptr_t)alpha | (uintptr_t)beta;
     return (a & 15) == 0;
 }
@@ -631,7 +635,7 @@ static int launch_one_g(const GStripParams& p, int nwg, hipStream_t st)
 }
 
 int launch_dag_strip4g(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
+                       float* alpha, float* beta, int B, int T, int L, int TR, int ldm, int ldo, hipStream_t st)
 {
     const int ndir = (alpha && beta) ? 2 : 1;
     // strip width: 1024 columns when that still yields >= ~200 workgroups, else 512
@@ -641,7 +645,7 @@ int launch_dag_strip4g(const float* match, const float* links, const int64_t* ou
     GStripParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len;
     p.alpha = alpha; p.beta = beta; p.trace = nullptr;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.ldm = ldm; p.ldo = ldo;
     { static const char* const e = getenv("DSP_DEBUG"); p.dbg = (e && !strcmp(e, "medium")) ? 1 : (e && !strcmp(e, "prof")) ? 2 : (e && !strcmp(e, "nofallback")) ? 4 : 0; }
     const size_t halo_bytes = (size_t)ndir * B * NS * T * G4_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);

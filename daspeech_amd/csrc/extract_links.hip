@@ -10,6 +10,7 @@
 // over the slots inside the 32 lanes of a head, the log-sum-exp over heads through LDS; the per-head scores of the four vertices are
 // parked in LDS (any TR, incl. README's --max-transition-length 99999: TR = L-1).
 #include "common.h"
+#include <atomic>
 
 namespace dsp {
 
@@ -539,7 +540,12 @@ __global__ __launch_bounds__(256) void extract_links_bwd_tiled_kernel(
     }
 }
 
-static thread_local int g_xl_tile = 0;          // dsp_dag_set_option("xl_tile", n): n > 0 forces the tiled kernels with TW = n (tests); 0 = only where the image does not fit
+// PROCESS-wide (r06): the backward of an autograd Function runs on PyTorch's device worker thread, which never saw a thread_local pin set by the
+// test's main thread (the "forced" tiled / matrix-core backward never ran).  g_xl_ran collects the kernel families launched since the
+// last dsp_extract_links_debug_ran() so a test can assert its pin took: bit 0 one-image forward, 1 tiled forward, 2 matrix-core forward,
+// 3 one-image backward, 4 tiled backward, 5 matrix-core backward (exact-fp32 contraction), 6 matrix-core backward (bf16-triple contraction).
+static std::atomic<int> g_xl_tile{0};           // dsp_dag_set_option("xl_tile", n): n > 0 forces the tiled kernels with TW = n (tests); 0 = only where the image does not fit
+std::atomic<unsigned int> g_xl_ran{0};
 void set_xl_tile(int v) { g_xl_tile = v > 0 ? ((v + 31) / 32) * 32 : 0; }
 }  // namespace dsp
 
@@ -558,7 +564,7 @@ static int xl_check(const char* fn, const void* q, const void* k, const void* g,
 // tile width of the tiled kernels for this call, 0 = the one-image kernels serve it
 static int xl_tile_width(size_t lds_one_image)
 {
-    if (dsp::g_xl_tile > 0) return dsp::g_xl_tile;
+    if (const int forced = dsp::g_xl_tile.load()) return forced;
     return lds_one_image > 150 * 1024 ? 512 : 0;              // 512 slots: a 64 KB image, two workgroups per CU
 }
 static size_t xl_tiled_lds(int CK, int TW) { return ((size_t)dsp::XL_IT * dsp::XL_H * CK + (size_t)dsp::XL_IT * TW * dsp::XL_H + 2 * dsp::XL_IT * dsp::XL_H) * sizeof(float); }
@@ -578,12 +584,14 @@ extern "C" int dsp_extract_links_train(const float* q, const float* k, const flo
         auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
         if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
         hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale, TW);
+        g_xl_ran |= 2u;
         return check_launch("extract_links_train(tiled)");
     }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
                        q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale);
+    g_xl_ran |= 1u;
     return check_launch("extract_links_train");
 }
 
@@ -620,6 +628,7 @@ extern "C" int dsp_extract_links_bwd(const float* q, const float* k, const float
     if ((((uintptr_t)grad_q) | ((uintptr_t)grad_k)) & 15) { set_error("extract_links_bwd: grad_q / grad_k must be 16-byte aligned"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
     if (const int TW = xl_tile_width(lds)) {
+        g_xl_ran |= 16u;
         const size_t l2 = xl_tiled_lds(CK, TW);
         const dim3 grid((L + XL_IT - 1) / XL_IT, B);
         auto go = [&](auto ka, auto kb) -> int {
@@ -637,6 +646,7 @@ extern "C" int dsp_extract_links_bwd(const float* q, const float* k, const float
         if (CK == 32) return go(extract_links_bwd_tiled_kernel<8, false>, extract_links_bwd_tiled_kernel<8, true>);
         return go(extract_links_bwd_tiled_kernel<32, false>, extract_links_bwd_tiled_kernel<32, true>);
     }
+    g_xl_ran |= 8u;
     if (CK == 64) return xl_bwd_launch<16>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
     if (CK == 32) return xl_bwd_launch<8>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
     return xl_bwd_launch<32>(q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_q, grad_k, grad_log_gates, B, L, TR, scale, lds, st);
@@ -659,11 +669,15 @@ extern "C" int dsp_extract_links(const float* q, const float* k, const float* lo
         auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
         if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
         hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale, TW);
+        g_xl_ran |= 2u;
         return check_launch("extract_links(tiled)");
     }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
                        q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale);
+    g_xl_ran |= 1u;
     return check_launch("extract_links");
 }
+
+extern "C" unsigned int dsp_extract_links_debug_ran(void) { return dsp::g_xl_ran.exchange(0u); }

@@ -32,6 +32,7 @@
 // Same arithmetic as extract_links.hip (same masks, same -inf conventions, same `stats` layout), so the two families are interchangeable
 // per call (tests compare them element by element, and both with torch autograd / the fp64 oracle).
 #include "common.h"
+#include <atomic>
 #include "../../include/daspeech_decode.h"
 #include <type_traits>
 
@@ -559,15 +560,17 @@ static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
     return check_launch(what);
 }
 
-static thread_local int g_xl_mfma = -1;        // dsp_dag_set_option("xl_mfma", v): 1 = matrix-core kernels wherever they apply, 0 = never, -1 = by size
+extern std::atomic<unsigned int> g_xl_ran;       // extract_links.hip
+static std::atomic<int> g_xl_mfma{-1};        // dsp_dag_set_option("xl_mfma", v): 1 = matrix-core kernels wherever they apply, 0 = never, -1 = by size
 void set_xl_mfma(int v) { g_xl_mfma = v; }
 
 // (32-bit byte offsets inside a sample's links / gradient block: L * TR * 4 < 2^31)
 static bool xm_supported(int L, int H, int CK, int TR) { return H == XM_H && CK == XM_CK && TR >= 1 && L >= 2 && (long)L * TR < (1L << 29); }
 static bool xm_preferred(int B, int L, int H, int CK, int TR)
 {
-    if (!xm_supported(L, H, CK, TR) || g_xl_mfma == 0) return false;
-    if (g_xl_mfma > 0) return true;
+    const int pin = g_xl_mfma.load();
+    if (!xm_supported(L, H, CK, TR) || pin == 0) return false;
+    if (pin > 0) return true;
     // by size (tools/xl_mfma_time.py): three launches and a split pre-pass need a band of ~half a million slots to pay — below that the one launch of
     // extract_links.hip wins on launch latency (ms, FMA -> matrix cores — B = 1, L = 800: 0.071 -> 0.071; B = 2, L = 400: 0.041 -> 0.046;
     // B = 1, L = 1200: 0.22 -> 0.10; B = 8, L = 400: 0.078 -> 0.049)
@@ -576,10 +579,10 @@ static bool xm_preferred(int B, int L, int H, int CK, int TR)
 
 static size_t xm_split_bytes(int B, int L) { return (size_t)B * XM_H * ((L + 31) / 32) * XM_TILE; }
 static size_t xm_split_t_bytes(int B, int L) { return (size_t)B * XM_H * ((L + 31) / 32) * XM_TTILE; }
-static thread_local int g_xl_contract = -1;    // dsp_dag_set_option("xl_contract", v): 0 = exact-fp32 MFMA contraction, 1 = bf16-triple products, -1 = default
+static std::atomic<int> g_xl_contract{-1};    // dsp_dag_set_option("xl_contract", v): 0 = exact-fp32 MFMA contraction, 1 = bf16-triple products, -1 = default
 void set_xl_contract(int v) { g_xl_contract = v; }
 // by size: the transposed pre-pass costs 23 us at B = 32, L = 400 for 15 us saved in DQ + DK; at L = 4096 0.23 ms for 0.9 ms (DQ 4.53 -> 4.03, DK 4.88 -> 4.50)
-static bool xm_bf16_contraction(int L) { return g_xl_contract > 0 || (g_xl_contract < 0 && L > 1536); }
+static bool xm_bf16_contraction(int L) { const int c = g_xl_contract.load(); return c > 0 || (c < 0 && L > 1536); }
 static size_t xm_bwd_bytes(int B, int L) { return 2 * xm_split_bytes(B, L) + 2 * xm_split_t_bytes(B, L); }
 
 }  // namespace dsp
@@ -615,6 +618,7 @@ extern "C" int dsp_extract_links_ws(const float* q, const float* k, const float*
     p.B = B; p.L = L; p.TR = TR; p.NT = (L + 31) / 32; p.scale = scale;
     hipLaunchKernelGGL(xl_mfma_split_kernel, dim3((unsigned)p.NT, (unsigned)B), dim3(256), 0, st, k, static_cast<char*>(workspace), L, p.NT, (const float*)nullptr, (size_t)0);
     if (int rc = check_launch("extract_links(split)")) return rc;
+    g_xl_ran |= 4u;
     static const char* const e_sq = getenv("DSP_XM_STATS_QG");
     const int sq = e_sq ? atoi(e_sq) : (L <= 1536 ? 1 : 2);          // as EMIT below (us at B = 32, 64- / 32-owner tiles — L = 256: 20 / 14, L = 1024: 121 / 93)
     if (int rc = sq == 1 ? xm_launch<XM_STATS, 1>(p, st, "extract_links(matrix-core soft-max state)")
@@ -656,6 +660,7 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
     if (int rc = aq == 1 ? xm_launch<XM_SA, 1>(p, st, "extract_links_bwd(matrix-core SA)") : xm_launch<XM_SA, 2>(p, st, "extract_links_bwd(matrix-core SA)")) return rc;
     p.dout = grad_q;
     if (xm_bf16_contraction(L)) {
+        g_xl_ran |= 64u;
         char* wt = ws + 2 * one;
         hipLaunchKernelGGL(xl_mfma_split_t_kernel, dim3((unsigned)p.NT, (unsigned)B, 2), dim3(256), 0, st, k, wt, L, p.NT, q, onet);           // k^T -> wt, q^T -> wt + onet
         if (int rc = check_launch("extract_links_bwd(transposed split)")) return rc;
@@ -664,6 +669,7 @@ extern "C" int dsp_extract_links_bwd_ws(const float* q, const float* k, const fl
         p.pa = ws + one; p.pt = wt + onet; p.dout = grad_k;
         return xm_launch<XM_DK, 1, 1>(p, st, "extract_links_bwd(matrix-core dk)");
     }
+    g_xl_ran |= 32u;
     if (int rc = xm_launch<XM_DQ, 1>(p, st, "extract_links_bwd(matrix-core dq)")) return rc;
     p.pa = ws + one; p.dout = grad_k;
     return xm_launch<XM_DK, 1>(p, st, "extract_links_bwd(matrix-core dk)");

@@ -83,52 +83,98 @@ def _workspace(dev: torch.device, nbytes: int) -> Tensor:
     return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
 
 
-# The banded fast paths (TR <= 32: exp-space strips, values-only max-DP) read rows with 16-byte loads: L must be a multiple of 4.  A graph
-# length is floor(src_upsample * frames) — any integer — and three graphs in four fell through to the 2-column log-space strips (r05 scan:
-# C2 at L = 4098 forward 1.56 ms against 0.55, alignment 1.24 against 0.41).  Such inputs are padded HERE to the next multiple of 4 with
-# vertices outside every sample's graph (-inf emissions and transitions; output_length is untouched, so the kernels never visit them) and the
-# results are cut back: one extra pass over [B,T,L] instead of a 3 x slower DP.
-def _pad4(m: Tensor, k: Tensor):
-    L, TR = m.shape[2], k.shape[2]
-    pad = (-L) % 4
-    if pad == 0 or TR > 32:
-        return m, k, 0
-    return (torch.nn.functional.pad(m, (0, pad), value=float("-inf")), torch.nn.functional.pad(k, (0, 0, 0, pad), value=float("-inf")), pad)
+# The banded fast paths (TR <= 32: exp-space strips, values-only max-DP, fused gradients) read rows with 16-byte loads.  A graph length is
+# floor(src_upsample * frames) — any integer; three graphs in four are not a multiple of 4.  r05 padded such inputs to the next multiple with
+# F.pad copies of match / links and cut alpha / beta / the gradients back (~4 extra passes over [B,T,L]).  r06: the C ABI takes a ROW PITCH
+# (dsp_dag_loss_fwd_ld & co.), dag_logsoftmax_gather_inplace writes `match` with a pitch rounded up to 4, alpha / beta / grad_match are
+# allocated with that pitch and handed on as [:, :, :L] views: no copy on the training path.  (The reference's contract is `.contiguous()`,
+# dag_loss.py:103-104.)
+def _round4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+def _row_pitch(t: Tensor):
+    """ld if `t` [B,T,L] fp32 is laid out as rows of pitch ld (a multiple of 4 covering L, 16-byte aligned base, batch stride T*ld), else 0."""
+    if t.dtype != torch.float32 or t.dim() != 3:
+        return 0
+    B, T, L = t.shape
+    sb, st, sl = t.stride()
+    ld = st if T > 1 else (sb if B > 1 else _round4(L))
+    if sl != 1 or ld % 4 or ld < _round4(L) or (B > 1 and sb != T * ld) or t.data_ptr() % 16:
+        return 0
+    if t.storage_offset() + ((B - 1) * T + (T - 1)) * ld + _round4(L) > t.untyped_storage().nbytes() // 4:
+        return 0                                     # the last row's 16-byte tail must lie inside the allocation
+    return ld
+
+
+def _pitched_empty(B: int, T: int, L: int, dev, fill=None) -> Tensor:
+    """[B,T,L] fp32 view of a [B,T,round4(L)] buffer."""
+    buf = torch.empty((B, T, _round4(L)), dtype=torch.float32, device=dev) if fill is None else \
+        torch.full((B, T, _round4(L)), fill, dtype=torch.float32, device=dev)
+    return buf[:, :, :L] if buf.shape[2] != L else buf
+
+
+def _as_pitched(match_all: Tensor):
+    """(fp32 [B,T,L] with 16-byte aligned rows, its pitch): the caller's tensor when it already is laid out so (the gather's output, any
+    dense tensor whose L is a multiple of 4), else ONE copy into a pitched buffer."""
+    m = match_all.detach()
+    ld = _row_pitch(m)
+    if ld:
+        return m, ld
+    B, T, L = m.shape
+    out = _pitched_empty(B, T, L, m.device)
+    out.copy_(m)                                     # widens fp16 / bf16 on the way (the DP runs in fp32, see _f32c)
+    return out, _round4(L)
 
 
 def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):
+    """-> (m, k, ol, tl, alpha, beta, loss, (ld_match, ld_ab)); alpha / beta are [B,T,L] (views of pitched buffers when TR <= 32)."""
     dev = _require_gpu("dag_loss", match_all, links, output_length, target_length)
     B, T, L, TR = _check_dp_args("dag_loss", match_all, links, output_length, target_length)
-    m, k, _pad = _pad4(_f32c(match_all), _f32c(links))
-    L = L + _pad
+    if match_all.dtype == torch.float64 or links.dtype == torch.float64:
+        raise RuntimeError("internal: float64 reached the fp32 HIP launch path (dag_double.py serves double inputs)")
+    k = _f32c(links)
     ol = output_length.contiguous()
     tl = target_length.contiguous()
     lib = _lib.load()
+    pitched = bool(lib.dsp_dag_pitch_supported(0, L, TR)) and k.data_ptr() % 16 == 0
     with torch.cuda.device(dev):
-        alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
-        beta = torch.empty((B, T, L), dtype=torch.float32, device=dev) if need_beta else None
+        if pitched:
+            m, ldm = _as_pitched(match_all)
+            lda = _round4(L)
+            alpha = _pitched_empty(B, T, L, dev)
+            beta = _pitched_empty(B, T, L, dev) if need_beta else None
+        else:
+            m, ldm, lda = _f32c(match_all), L, L
+            alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+            beta = torch.empty((B, T, L), dtype=torch.float32, device=dev) if need_beta else None
         loss = torch.empty((B,), dtype=torch.float32, device=dev)
-        wsz = lib.dsp_dag_workspace_bytes(B, T, L, TR)
+        wsz = lib.dsp_dag_workspace_bytes(B, T, _round4(L) if pitched else L, TR)
         ws = _workspace(dev, wsz)
-        rc = lib.dsp_dag_loss_fwd(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta),
-                                  _lib.ptr(loss), B, T, L, TR, _lib.ptr(ws), ws.numel(), _lib.current_stream_handle())
+        rc = lib.dsp_dag_loss_fwd_ld(_lib.ptr(m), ldm, _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), lda,
+                                     _lib.ptr(loss), B, T, L, TR, _lib.ptr(ws), ws.numel(), _lib.current_stream_handle())
         _lib.check(rc, "dsp_dag_loss_fwd")
-    return m, k, ol, tl, alpha, beta, loss
+    return m, k, ol, tl, alpha, beta, loss, (ldm, lda)
 
 
-def _dag_backward(grad_output, alpha, beta, m, k, ol, tl, need_match: bool, need_links: bool):
+def _dag_backward(grad_output, alpha, beta, m, k, ol, tl, need_match: bool, need_links: bool, lds=None):
     B, T, L = m.shape
     TR = k.shape[2]
     dev = m.device
     lib = _lib.load()
+    ldm, lda = lds if lds is not None else (L, L)
     with torch.cuda.device(dev):
         go = grad_output.detach().to(torch.float32).contiguous()
-        gm = torch.empty_like(m) if need_match else None
+        gm, ldg = None, L
+        if need_match:
+            if lda != L or (TR <= 32 and lda % 4 == 0):          # (TR <= 32: the fused gradient kernel wants 16-byte rows for grad_match too)
+                gm, ldg = _pitched_empty(B, T, L, dev), _round4(L)
+            else:
+                gm = torch.empty((B, T, L), dtype=torch.float32, device=dev)
         gl = torch.empty_like(k) if need_links else None
         wsz, ws = 0, None                       # the gradient kernels keep no scratch
-        rc = lib.dsp_dag_loss_bwd(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(m), _lib.ptr(k), _lib.ptr(ol),
-                                  _lib.ptr(tl), _lib.ptr(gm), _lib.ptr(gl), B, T, L, TR, _lib.ptr(ws), wsz,
-                                  _lib.current_stream_handle())
+        rc = lib.dsp_dag_loss_bwd_ld(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), lda, _lib.ptr(m), ldm, _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl),
+                                     _lib.ptr(gm), ldg, _lib.ptr(gl), B, T, L, TR, _lib.ptr(ws), wsz, _lib.current_stream_handle())
         _lib.check(rc, "dsp_dag_loss_bwd")
     return gm, gl
 
@@ -147,10 +193,9 @@ class DagLossFunc(Function):
     @staticmethod
     def forward(ctx, match_all, links, output_length, target_length):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
+        m, k, ol, tl, alpha, beta, loss, ctx.lds = _dag_forward(match_all, links, output_length, target_length, need)
         ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
         ctx.in_dtypes = (match_all.dtype, links.dtype)
-        ctx.L = match_all.shape[2]
         return loss.to(match_all.dtype)
 
     @staticmethod
@@ -158,20 +203,10 @@ class DagLossFunc(Function):
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             return None, None, None, None
         alpha, beta, m, k, ol, tl = ctx.saved_tensors
-        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        gm, gl = _unpad_grads(gm, gl, ctx.L)
+        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.lds)
         gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
         gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
         return gm, gl, None, None
-
-
-def _unpad_grads(gm, gl, L):
-    """cut the gradients of a graph padded by _pad4 back to its L vertices"""
-    if gm is not None and gm.shape[2] != L:
-        gm = gm[:, :, :L]
-    if gl is not None and gl.shape[1] != L:
-        gl = gl[:, :L]
-    return gm, gl
 
 
 class DagLossWithAlphaBetaFunc(Function):
@@ -182,16 +217,15 @@ class DagLossWithAlphaBetaFunc(Function):
     @staticmethod
     def forward(ctx, match_all, links, output_length, target_length):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        m, k, ol, tl, alpha, beta, loss = _dag_forward(match_all, links, output_length, target_length, need)
+        m, k, ol, tl, alpha, beta, loss, ctx.lds = _dag_forward(match_all, links, output_length, target_length, need)
         ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
         ctx.in_dtypes = (match_all.dtype, links.dtype)
-        ctx.L = match_all.shape[2]
         if beta is None:
             # no gradient required: the reference launches no beta kernel and hands back the table as allocated, all zeros
             # (dag_loss.cu:339-340,355-371) — callers (the expect strategy in validation / while the DAG is frozen) compute with it
             beta = torch.zeros_like(alpha)
-        if alpha.shape[2] != ctx.L:                                  # (a graph padded by _pad4: the caller sees its own L vertices)
-            alpha, beta = alpha[:, :, :ctx.L].contiguous(), beta[:, :, :ctx.L].contiguous()
+        if not alpha.is_contiguous():                                # (graph length not a multiple of 4: the tables sit in pitched buffers; the
+            alpha, beta = alpha.contiguous(), beta.contiguous()      #  reference hands out dense tensors, and so does this operator)
         ctx.mark_non_differentiable(alpha, beta)
         return loss.to(match_all.dtype), (alpha, beta)
 
@@ -200,8 +234,7 @@ class DagLossWithAlphaBetaFunc(Function):
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             return None, None, None, None
         alpha, beta, m, k, ol, tl = ctx.saved_tensors
-        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        gm, gl = _unpad_grads(gm, gl, ctx.L)
+        gm, gl = _dag_backward(grad_output, alpha, beta, m, k, ol, tl, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.lds)
         gm = gm.to(ctx.in_dtypes[0]) if gm is not None else None
         gl = gl.to(ctx.in_dtypes[1]) if gl is not None else None
         return gm, gl, None, None
@@ -236,25 +269,32 @@ class DagBestAlignmentFunc(Function):
     def forward(ctx, match_all, links, output_length, target_length):
         dev = _require_gpu("dag_best_alignment", match_all, links, output_length, target_length)
         B, T, L, TR = _check_dp_args("dag_best_alignment", match_all, links, output_length, target_length)
-        m, k, _pad = _pad4(_f32c(match_all), _f32c(links))
-        L0, L = L, L + _pad
+        k = _f32c(links)
         ol = output_length.contiguous()
         tl = target_length.contiguous()
         lib = _lib.load()
         with torch.cuda.device(dev):
-            alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
-            # the banded fast path back-traces lazily from alpha_max: no [B,T,L] trace tensor (the reference always writes one)
-            # (that path also needs 16-byte aligned rows: a view at an odd storage offset takes the trace-based kernels)
-            lazy_ok = lib.dsp_dag_alignment_trace_optional(L, TR) and m.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0
-            trace = None if lazy_ok else torch.empty((B, T, L), dtype=torch.int32, device=dev)
+            # the banded fast path keeps values only and back-traces lazily from alpha_max: no [B,T,L] trace tensor (the reference always writes
+            # one); it reads 16-byte rows, so match / alpha_max go in with a row pitch (see _dag_forward)
+            pitched = bool(lib.dsp_dag_pitch_supported(1, L, TR)) and k.data_ptr() % 16 == 0
             path = torch.empty((B, L), dtype=torch.long, device=dev)
-            ws = _workspace(dev, lib.dsp_dag_alignment_workspace_bytes(B, T, L, TR))
-            rc = lib.dsp_dag_best_alignment_ws(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
-                                               _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.ptr(ws), ws.numel(),
-                                               _lib.current_stream_handle())
-            _lib.check(rc, "dsp_dag_best_alignment_ws")
-        if L != L0:
-            path = path[:, :L0].contiguous()
+            if pitched:
+                m, ldm = _as_pitched(match_all)
+                alpha = _pitched_empty(B, T, L, dev)
+                ws = _workspace(dev, lib.dsp_dag_alignment_workspace_bytes(B, T, _round4(L), TR))
+                rc = lib.dsp_dag_best_alignment_ld(_lib.ptr(m), ldm, _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _round4(L), None,
+                                                   _lib.ptr(path), B, T, L, TR, _lib.ptr(ws), ws.numel(), _lib.current_stream_handle())
+                _lib.check(rc, "dsp_dag_best_alignment_ld")
+            else:
+                m = _f32c(match_all)
+                alpha = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+                lazy_ok = bool(lib.dsp_dag_alignment_trace_optional(L, TR)) and m.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0
+                trace = None if lazy_ok else torch.empty((B, T, L), dtype=torch.int32, device=dev)
+                ws = _workspace(dev, lib.dsp_dag_alignment_workspace_bytes(B, T, L, TR))
+                rc = lib.dsp_dag_best_alignment_ws(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha),
+                                                   _lib.ptr(trace), _lib.ptr(path), B, T, L, TR, _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream_handle())
+                _lib.check(rc, "dsp_dag_best_alignment_ws")
         ctx.mark_non_differentiable(path)
         return path
 
@@ -307,14 +347,16 @@ def _lsg_check(word_ins_out: Tensor, select_idx: Tensor):
 
 
 def _lsg_forward(word_ins_out: Tensor, select_idx: Tensor, write_softmax: bool) -> Tensor:
-    """K1 launch: returns the contiguous [B,S,L] match buffer; word_ins_out becomes softmax if write_softmax."""
+    """K1 launch: returns the [B,S,L] match buffer (contiguous when L is a multiple of 4, else a view of rows pitched to the next multiple);
+    word_ins_out becomes softmax if write_softmax."""
     dev, code, B, L, V, S = _lsg_check(word_ins_out, select_idx)
     lib = _lib.load()
     with torch.cuda.device(dev):
-        buf = torch.empty((B, S, L), dtype=torch.float32, device=dev)      # "match_all" layout
+        buf = _pitched_empty(B, S, L, dev)                                 # "match_all" layout, rows on 16-byte boundaries (pitch = L rounded up to 4)
+        ld = _round4(L)
         isb, isj, iss = _elem_strides(select_idx)
         rc = lib.dsp_logsoftmax_gather(_lib.ptr(word_ins_out), code, _lib.ptr(select_idx), isb, isj, iss,
-                                       _lib.ptr(buf), S * L, 1, L, B, L, V, S, 1 if write_softmax else 0,
+                                       _lib.ptr(buf), S * ld, 1, ld, B, L, V, S, 1 if write_softmax else 0,
                                        _lib.current_stream_handle())
         _lib.check(rc, "dsp_logsoftmax_gather")
     return buf
@@ -325,11 +367,12 @@ def _lsg_forward_lazy(word_ins_out: Tensor, select_idx: Tensor):
     dev, code, B, L, V, S = _lsg_check(word_ins_out, select_idx)
     lib = _lib.load()
     with torch.cuda.device(dev):
-        buf = torch.empty((B, S, L), dtype=torch.float32, device=dev)
+        buf = _pitched_empty(B, S, L, dev)
+        ld = _round4(L)
         stats = torch.empty((B, L, 2), dtype=torch.float32, device=dev)
         isb, isj, iss = _elem_strides(select_idx)
         rc = lib.dsp_logsoftmax_gather_stats(_lib.ptr(word_ins_out), code, _lib.ptr(select_idx), isb, isj, iss,
-                                             _lib.ptr(buf), S * L, 1, L, _lib.ptr(stats), B, L, V, S, _lib.current_stream_handle())
+                                             _lib.ptr(buf), S * ld, 1, ld, _lib.ptr(stats), B, L, V, S, _lib.current_stream_handle())
         _lib.check(rc, "dsp_logsoftmax_gather_stats")
     return buf, stats
 

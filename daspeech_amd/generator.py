@@ -31,11 +31,8 @@ class S2SNATGenerator:
     of dense MFMA work) runs on a second, lower-priority stream and fills those gaps.  Same kernels, same results, batch by batch."""
 
     def __init__(self, vocoder=None, gcmvn_mean: Optional[Tensor] = None, gcmvn_std: Optional[Tensor] = None,
-                 vocoder_group: int = 8, capture_graph: bool = False):
-        """capture_graph: replay the shape-static front of the acoustic stage (encoder, NAT decoder, links: ~300 launches) as one hipGraph per
-        (batch, padded frames) shape — graph_capture.CapturedGraphStage; same kernels, same results, one launch of host work."""
+                 vocoder_group: int = 8):
         self.vocoder, self.mean, self.std, self.vocoder_group = vocoder, gcmvn_mean, gcmvn_std, vocoder_group
-        self.capture_graph, self._captured = capture_graph, None
         self._vocoder_takes_lengths = _accepts_lengths(vocoder)
         self._side = None            # vocoder stream of the pipelined mode
         self._pending = None         # acoustic stage issued, vocoder not yet: (stage-1 outputs, completion event)
@@ -49,17 +46,10 @@ class S2SNATGenerator:
     # ---- stage 1: fbank -> mel (forward_encoder -> graph decode -> adaptor -> tts; s2s_nat_generator.py:49-258), no host sync
     def _acoustic(self, model, sample: Dict) -> Dict[str, Tensor]:
         net = sample["net_input"]
-        if self.capture_graph and net["src_tokens"].is_cuda and not model.training:
-            if self._captured is None or self._captured.model is not model:
-                from .graph_capture import CapturedGraphStage
-                self._captured = CapturedGraphStage(model)
-            prev, enc, logits, links, feats = self._captured(net["src_tokens"], net["src_lengths"])
-            dec = model.forward_decoder(prev, enc, graph=(logits, links, feats))
-        else:
-            enc = model.forward_encoder(net["src_tokens"], net["src_lengths"])
-            # the encoder's 4x subsampling keeps lengths on the device; the padded frame count is a host integer already
-            prev = model.initialize_output_tokens_by_src(net["src_lengths"], max_src_len=net["src_tokens"].shape[1])
-            dec = model.forward_decoder(prev, enc)
+        enc = model.forward_encoder(net["src_tokens"], net["src_lengths"])
+        # the encoder's 4x subsampling keeps lengths on the device; the padded frame count is a host integer already
+        prev = model.initialize_output_tokens_by_src(net["src_lengths"], max_src_len=net["src_tokens"].shape[1])
+        dec = model.forward_decoder(prev, enc)
         tts_in = model.adaptor(dec["features"])
         mel, mel_post, out_lens, _, _, _ = model.tts(tts_in, dec["features_padding_mask"])
         if mel_post is not None:                                                                             # s2s_nat_generator.py:254-255

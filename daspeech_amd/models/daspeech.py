@@ -545,11 +545,10 @@ class S2TConformerDAGModel(nn.Module):
         return ret
 
     @torch.no_grad()
-    def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor], graph=None):
+    def forward_decoder(self, prev_output_tokens: Tensor, enc: Dict[str, Tensor]):
         """Graph decode on the GPU: lookahead / greedy (s2s_conformer_dag_fastspeech2.py:194-243) through the HIP decode ops, viterbi /
-        jointviterbi (:244-304) batched in torch on the restored dense links.  `graph` = (logits, links, features) when the caller has them
-        already (graph_capture.CapturedGraphStage)."""
-        logits, links, feats = self.decode_graph(prev_output_tokens, enc) if graph is None else graph
+        jointviterbi (:244-304) on the dense-window alignment kernels."""
+        logits, links, feats = self.decode_graph(prev_output_tokens, enc)
         out_len = prev_output_tokens.ne(self.pad).sum(-1)
         if self.args.decode_strategy in ("viterbi", "jointviterbi"):
             toks, ofeat, mask, lens = decode_ops.viterbi_decode(

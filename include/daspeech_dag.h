@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSP_ABI_VERSION 1
+#define DSP_ABI_VERSION 2      /* 2 (r06): the *_ld entry points (row pitches); every ABI-1 symbol is unchanged */
 
 #define DSP_OK 0
 #define DSP_EINVAL (-1)   /* bad size / null pointer / unsupported dtype */
@@ -95,12 +95,31 @@ int dsp_dag_loss_fwd(const float* match, const float* links, const int64_t* out_
                      float* alpha, float* beta, float* loss, int B, int T, int L, int TR,
                      void* workspace, size_t workspace_bytes, dsp_stream_t stream);
 
+/* ... with ROW PITCHES (ABI 2).  ld_match / ld_ab = elements between consecutive target rows of match and of alpha / beta (batch stride =
+ *   T * ld; dense tensors: ld = L, which is what dsp_dag_loss_fwd passes).  A graph length is floor(src_upsample * frames) — three graphs in
+ *   four are not a multiple of 4 and their dense rows are not 16-byte aligned; a pitch rounded up to 4 keeps them aligned and the TR <= 32
+ *   strip kernels (16-byte row loads) serve such a graph WITHOUT a padded copy of match / alpha / beta: columns L .. ld-1 are never read as
+ *   data, alpha / beta come back -inf there.  dsp_logsoftmax_gather writes `match` with any pitch (its out_ss stride), so the gather can
+ *   produce the pitched layout directly.  Only the TR <= 32 families take pitched rows (ld multiples of 4, >= L rounded up to 4, 16-byte
+ *   aligned bases); every other window needs ld = L and the call fails with DSP_EINVAL otherwise.  Workspace: size it for L rounded up to 4.
+ *   Reference contract this replaces: dag_loss.py:103-104 (`.contiguous()` on match_all / links before the CUDA call). */
+int dsp_dag_loss_fwd_ld(const float* match, int ld_match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                        float* alpha, float* beta, int ld_ab, float* loss, int B, int T, int L, int TR,
+                        void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
 /* K4/K5  gradients                    replaces `dag_loss_backward` (dag_loss.cpp:26; dag_loss.cu:518-571)
  *   grad_out [B]; grad_match [B,T,L]; grad_links [B,L,TR]; formulas SURVEY.md §9.1 K4/K5. Either output may be NULL. */
 int dsp_dag_loss_bwd(const float* grad_out, const float* alpha, const float* beta, const float* match,
                      const float* links, const int64_t* out_len, const int64_t* tgt_len,
                      float* grad_match, float* grad_links, int B, int T, int L, int TR,
                      void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
+/* ... with row pitches (see dsp_dag_loss_fwd_ld): alpha / beta as the pitched forward left them (ld_ab), match with ld_match, grad_match
+ *   written with ld_grad_match (columns past L inside the pitch may be written with unspecified values).  TR <= 32 only when ld_ab != L. */
+int dsp_dag_loss_bwd_ld(const float* grad_out, const float* alpha, const float* beta, int ld_ab, const float* match, int ld_match,
+                        const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                        float* grad_match, int ld_grad_match, float* grad_links, int B, int T, int L, int TR,
+                        void* workspace, size_t workspace_bytes, dsp_stream_t stream);
 
 /* K6/K7  Viterbi alignment            replaces `dag_best_alignment` (dag_loss.cpp:27; dag_best_alignment.cu:209-253)
  *   alpha_max [B,T,L] fp32 out, trace [B,T,L] int32 out (scratch the caller owns), path [B,L] int64 out
@@ -119,6 +138,16 @@ size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR);
 int dsp_dag_best_alignment_ws(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
                               float* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
                               void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
+/* ... with row pitches (see dsp_dag_loss_fwd_ld): served by the values-only strip DP + lazy back-trace (TR <= 32, L <= 8192, i.e. where
+ *   dsp_dag_alignment_trace_optional(L rounded up to 4, TR) is 1); `trace` is ignored there.  path stays dense [B,L]. */
+int dsp_dag_best_alignment_ld(const float* match, int ld_match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
+                              float* alpha_max, int ld_alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR,
+                              void* workspace, size_t workspace_bytes, dsp_stream_t stream);
+
+/* 1 if the op (0: dsp_dag_loss_fwd_ld / _bwd_ld, 1: dsp_dag_best_alignment_ld) serves pitched rows for this graph under the calling thread's
+ * kernel pin — else pass dense tensors (ld = L). */
+int dsp_dag_pitch_supported(int op, int L, int TR);
 
 /* The two halves of the alignment, separately — what the Viterbi graph decode needs
  * (s2s_conformer_dag_fastspeech2.py:244-304: max-product steps over the links, THEN the length is chosen, THEN the back-trace):

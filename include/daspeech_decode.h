@@ -91,6 +91,12 @@ int dsp_extract_links_bwd_ws(const float* q, const float* k, const float* log_ga
                              float* grad_q, float* grad_k, float* grad_log_gates, int B, int L, int H, int CK, int TR, float scale,
                              void* workspace, size_t workspace_bytes, dsp_stream_t stream);
 
+/* diagnostics (r06): the extract_links kernel families launched by this process since the last call (then cleared) — bit 0 one-image forward,
+ *   1 tiled forward, 2 matrix-core forward, 3 one-image backward, 4 tiled backward, 5 matrix-core backward with exact-fp32 contractions,
+ *   6 matrix-core backward with bf16-triple contractions.  The "xl_tile" / "xl_mfma" / "xl_contract" options are PROCESS-wide (PyTorch runs an
+ *   autograd backward on its own worker thread); tests assert through this word that the family they pinned is the one that ran. */
+unsigned int dsp_extract_links_debug_ran(void);
+
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */
 int dsp_posterior(const float* alpha, const float* beta, float* score, int B, int T, int L, dsp_stream_t stream);

@@ -82,7 +82,8 @@ def test_golden_logsoftmax_gather(golden_dir, name, dtype):
     work = x.clone()                                   # non-leaf, as the model's output is
     out_x, match = ops().dag_logsoftmax_gather_inplace(work, tgt.unsqueeze(1).expand(-1, L, -1))
     assert tuple(match.shape) == (B, L, tgt.shape[1]) and match.dtype == torch.float32
-    assert match.transpose(1, 2).is_contiguous()       # caller's transpose is free
+    mt = match.transpose(1, 2)                         # caller's transpose is free: [B,S,L] rows, dense when L is a multiple of 4, else pitched to the next
+    assert mt.stride(2) == 1 and mt.stride(1) == (L + 3) // 4 * 4 and (L % 4 != 0 or mt.is_contiguous())
     np.testing.assert_allclose(match.detach().cpu().numpy(), g["match"], rtol=1e-5, atol=1e-5)
     # in-place side effect: softmax in the input dtype (logsoftmax_gather.cu:296-307)
     tol = 1e-6 if dtype == torch.float32 else 1e-3
@@ -1035,3 +1036,57 @@ def test_fused_backward_equals_the_two_launches(shape):
     np.testing.assert_allclose(got[0][1].cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
     if B > 2:
         assert not fin[2] and got[0][0][2].abs().max() == 0 and got[0][1][2].abs().max() == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 1023, 32), (2, 30, 518, 32), (2, 17, 261, 9), (3, 12, 97, 32), (1, 2, 5, 3), (2, 40, 1030, 20)])
+@pytest.mark.parametrize("source", ["gather", "dense"])
+def test_graph_lengths_off_the_16_byte_grid_run_pitched(shape, source):
+    """r06: graph lengths that are not multiples of 4 (three real graphs in four) reach the TR <= 32 strip kernels through ROW PITCHES
+    (dsp_dag_loss_fwd_ld / _bwd_ld / dsp_dag_best_alignment_ld), not through F.pad copies: `match` straight from
+    dag_logsoftmax_gather_inplace (written with the pitch) or a dense caller tensor (one copy into a pitched buffer).  Loss, alpha, beta, both
+    gradients against the fp64 oracle; the Viterbi path bit-exact; the fast kernel families are the ones that ran."""
+    from daspeech_amd import _lib
+    import ctypes
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(230 + L, B, T, L, TR)
+    V = 40
+    rng = np.random.default_rng(L)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    if source == "gather":
+        # logits whose log-softmax at the target tokens is the oracle's match: build them from match directly
+        tgt = rng.integers(0, V, (B, T))
+        logits = rng.standard_normal((B, L, V)).astype(np.float32)
+        x = torch.from_numpy(logits).to(dev())
+        _, sel = ops().dag_logsoftmax_gather_inplace(x.clone(), torch.from_numpy(tgt).to(dev()).unsqueeze(1).expand(-1, L, -1))
+        mt = sel.transpose(1, 2)                                   # [B,T,L] view of the pitched buffer
+        assert mt.stride(2) == 1 and mt.stride(1) % 4 == 0 and (L % 4 == 0 or not mt.is_contiguous())
+        match = mt.cpu().numpy().astype(np.float32)
+        m = mt.detach()
+    m = m.clone().requires_grad_() if source == "dense" else m.requires_grad_()
+    k.requires_grad_()
+    diag = (ctypes.c_uint * 4)()
+    _lib.load().dsp_dag_debug_k5(diag)
+    loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, o, t)
+    assert alpha.is_contiguous() and alpha.shape == (B, T, L)
+    fin = torch.isfinite(loss)
+    w = torch.linspace(0.5, 1.5, B, device=dev())
+    gm, gl = torch.autograd.grad((loss.nan_to_num(neginf=0.0) * w).sum(), [m, k])
+    torch.cuda.synchronize()
+    _lib.load().dsp_dag_debug_k5(diag)
+    assert diag[3] == 5, "the fused exp-space gradient kernel ran (pitched rows), not the log-space fallback"
+    assert gm.shape == (B, T, L) and gl.shape == (B, L, TR)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    a = alpha.cpu().numpy(); b = beta.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
+    fa = np.isfinite(a64); fb = np.isfinite(b64)
+    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T)
+    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), b64[:, 0, 0], rtol=3e-6, atol=2e-5 * T)
+    go = (w.cpu().numpy() * fin.cpu().numpy()).astype(np.float64)
+    gm64, gl64 = orc.dag_grad(go, a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(gl.cpu().numpy(), gl64, rtol=2e-3, atol=1e-7)
+    path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
+    np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
+    assert _lib.last_launch_status() == 0

@@ -477,9 +477,14 @@ def test_tiled_extract_links_equal_the_one_image_kernels(B, L, CK, TR, lens, til
     try:
         _lib.set_option("xl_mfma", 0)
         _lib.set_option("xl_tile", 0)
+        _lib.load().dsp_extract_links_debug_ran()
         ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        torch.cuda.synchronize()
+        assert _lib.load().dsp_extract_links_debug_ran() == 0b0001001, "reference = the one-image kernels, forward and backward"
         _lib.set_option("xl_tile", tile)
         got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        torch.cuda.synchronize()
+        assert _lib.load().dsp_extract_links_debug_ran() == 0b0010010, "the pinned tiled kernels ran, in the autograd backward too"
     finally:
         _lib.set_option("xl_tile", 0)
         _lib.set_option("xl_mfma", -1)
@@ -505,12 +510,17 @@ def test_matrix_core_extract_links_equal_the_fp32_kernels(B, L, TR, lens, use_bi
         bias = None
     try:
         _lib.set_option("xl_mfma", 0)
+        _lib.load().dsp_extract_links_debug_ran()
         ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, bias)
+        torch.cuda.synchronize()
+        assert _lib.load().dsp_extract_links_debug_ran() & 0b1100100 == 0, "reference = the fp32-FMA kernels"
         _lib.set_option("xl_mfma", 1)
         gots = []
         for contract in (0, 1):            # the backward's contractions: exact-fp32 MFMAs | bf16-triple products (the default above ~1 500 vertices)
             _lib.set_option("xl_contract", contract)
             gots.append(_links_fwd_bwd(olen, q0, k0, g0, w, TR, bias))
+            torch.cuda.synchronize()
+            assert _lib.load().dsp_extract_links_debug_ran() == (0b1000100 if contract else 0b0100100), "matrix-core forward + the pinned contraction, in the autograd backward too"
     finally:
         _lib.set_option("xl_mfma", -1)
         _lib.set_option("xl_contract", -1)
@@ -538,7 +548,10 @@ def test_matrix_core_extract_links_at_baseline_graph_size():
     n = ctypes.c_size_t(0)
     _lib.check(_lib.load().dsp_extract_links_workspace(B, L, 8, 64, TR, 0, ctypes.byref(n)), "workspace")
     assert n.value > 0, "the dispatch did not choose the matrix-core kernels for BASELINE's graph"
+    _lib.load().dsp_extract_links_debug_ran()
     got = _links_fwd_bwd(olen, q0, k0, g0, w, TR, None)
+    torch.cuda.synchronize()
+    assert _lib.load().dsp_extract_links_debug_ran() == 0b1000100, "default at L = 4096: matrix-core forward, bf16-triple contractions in the backward"
     links = got[0]
     i = torch.arange(L, device="cuda").view(1, L, 1); d = torch.arange(TR, device="cuda").view(1, 1, TR)
     valid = (i + d + 1) < olen.view(B, 1, 1)
@@ -550,6 +563,8 @@ def test_matrix_core_extract_links_at_baseline_graph_size():
     try:
         _lib.set_option("xl_mfma", 0)
         ref = _links_fwd_bwd(olen, q0, k0, g0, w, TR, None)
+        torch.cuda.synchronize()
+        assert _lib.load().dsp_extract_links_debug_ran() == 0b0010010, "reference at this size = the tiled fp32-FMA kernels (the bf16 contraction is checked against THEM)"
     finally:
         _lib.set_option("xl_mfma", -1)
     for name, a, b in zip(("links", "dq", "dk", "dgate", "links (inference)"), got, ref):

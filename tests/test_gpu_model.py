@@ -201,32 +201,6 @@ def test_generator_batch_pipeline_equals_one_batch_at_a_time():
     assert gen.flush() is None and gen.submit(m, batches[0]) is None and len(gen.flush()) == 3
 
 
-def test_captured_graph_stage_equals_the_eager_acoustic_stage():
-    """graph_capture.CapturedGraphStage (encoder -> NAT decoder -> links as one hipGraph per input shape) behind S2SNATGenerator(capture_graph=True):
-    the same kernels on the same inputs — decoded tokens identical, mel within the run-to-run spread of the eager stage (1e-5), over batches
-    of different shapes, replayed twice (a cache hit re-uses the graph's static inputs / outputs), also through the two-deep pipeline."""
-    from daspeech_amd.generator import S2SNATGenerator
-    from daspeech_amd.models import HiFiGANGenerator
-    from daspeech_amd.synthetic import calibrate_synthetic_weights, make_s2st_batch
-    m = calibrate_synthetic_weights(small_model().eval())
-    voc = HiFiGANGenerator(conv_backend="hip").cuda().eval()
-    eager = S2SNATGenerator(voc, torch.zeros(80), torch.ones(80), vocoder_group=2)
-    capt = S2SNATGenerator(voc, torch.zeros(80), torch.ones(80), vocoder_group=2, capture_graph=True)
-    batches = [make_s2st_batch(3, "cuda", seed=40 + i, min_frames=90 + 15 * (i % 2), max_frames=150) for i in range(4)]
-    want = [eager.generate(m, s) for s in batches]
-    for rep in range(2):
-        got = [capt.generate(m, s) for s in batches] if rep == 0 else list(capt.generate_batches(m, batches))
-        for gb, wb in zip(got, want):
-            assert len(gb) == len(wb)
-            for g, w in zip(gb, wb):
-                assert torch.equal(g["tokens"], w["tokens"]) and g["feature"].shape == w["feature"].shape
-                torch.testing.assert_close(g["feature"], w["feature"], rtol=0, atol=1e-5)
-                torch.testing.assert_close(g["waveform"], w["waveform"], rtol=0, atol=1e-3)
-    st = capt._captured
-    shapes = {tuple(s["net_input"]["src_tokens"].shape) for s in batches}
-    assert st.captures == len(shapes) and st.replays == 2 * len(batches)
-
-
 def test_split_gemm_inference_matches_torch_fp32_within_mel_tolerance():
     """The eval-mode inference path runs its Linear layers and FFT convolutions as fp32-accurate split GEMMs on the fp16 matrix cores
     (decode_ops.split_linear / SplitConv1d).  Same batch through the released architecture with the path on and off: same decoded

@@ -15,18 +15,18 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     B, T, L, TR = [int(v) for v in args[:4]] if len(args) >= 4 else (32, 512, 4096, 32)
     m, k, ol, tl = inputs(B, T, L, TR)
-    mm, kk, ol, tl, alpha, beta, loss = dl._dag_forward(m, k, ol, tl, True)
+    mm, kk, ol, tl, alpha, beta, loss, (ldm, lda) = dl._dag_forward(m, k, ol, tl, True)
     go = -(1.0 / tl.float()) / B
     lib = _lib.load()
     st = _lib.current_stream_handle()
     out = {}
     for fuse in (3, 1, 2):
         _lib.set_option("k5_fuse", fuse)
-        gm = torch.full_like(mm, float("nan")); gl = torch.full_like(kk, float("nan"))
+        gm = dl._pitched_empty(B, T, L, mm.device, fill=float("nan")); gl = torch.full_like(kk, float("nan"))
 
         def run():
-            rc = lib.dsp_dag_loss_bwd(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(mm), _lib.ptr(kk), _lib.ptr(ol), _lib.ptr(tl),
-                                      _lib.ptr(gm), _lib.ptr(gl), B, T, L, TR, None, 0, st)
+            rc = lib.dsp_dag_loss_bwd_ld(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), lda, _lib.ptr(mm), ldm, _lib.ptr(kk), _lib.ptr(ol), _lib.ptr(tl),
+                                         _lib.ptr(gm), dl._round4(L), _lib.ptr(gl), B, T, L, TR, None, 0, st)
             _lib.check(rc, "bwd")
         for _ in range(3):
             run()
