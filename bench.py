@@ -183,7 +183,16 @@ class Ctx:
         if flush is not None:
             flush()
         self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0), out
+        self.last_local_s = time.perf_counter() - t0      # this rank's own clock (scaling_diag); the reported time is the max over ranks
+        return self.max_over_ranks(self.last_local_s), out
+
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (a list of one without a process group)."""
+        if self.world > 1:
+            out = [None] * self.world
+            self.dist.all_gather_object(out, obj)
+            return out
+        return [obj]
 
 
 # ======================================================================================================================
@@ -633,6 +642,27 @@ def vocoder_roofline(ctx, args, state):
             **({"mfma_issue_factor": 3, "frac_of_issue_peak": 3 * tf / MFMA_F16_PEAK_TFLOPS} if f32 else {})}
 
 
+def scaling_diag(ctx, batches, steps):
+    """Per-rank record for the 1 -> 8 GPU runs the driver times (r06): which device every rank ran on, how many utterances / source frames /
+    DAG cells (sum of T*L*TR, distributed.dag_cost) its shard of each step's pool held, and its OWN wall time next to the reported maximum — so
+    that a scaling efficiency below 1 can be read as imbalance (spread of cost or of time) or as interference.  No efficiency is computed here."""
+    from daspeech_amd.distributed import dag_cost
+    torch = ctx.torch
+    lens = [b["net_input"]["src_lengths"].detach().cpu() for b in batches]
+    mine = {"rank": ctx.rank, "device": str(ctx.dev),
+            "device_name": torch.cuda.get_device_name(ctx.dev) if ctx.dev.type == "cuda" else "cpu",
+            "utterances_per_step": [int(x.numel()) for x in lens], "src_frames_per_step": [int(x.sum()) for x in lens],
+            "dag_cells_per_step": [float(dag_cost(x).sum()) for x in lens],
+            "local_ms_per_step": getattr(ctx, "last_local_s", 0.0) * 1e3 / max(1, steps)}
+    ranks = ctx.gather_objects(mine)
+    cost = [sum(r["dag_cells_per_step"]) for r in ranks]
+    frames = [sum(r["src_frames_per_step"]) for r in ranks]
+    tms = [r["local_ms_per_step"] for r in ranks]
+    spread = lambda v: (max(v) - min(v)) / max(v) if max(v) > 0 else 0.0
+    return {"ranks": ranks, "dag_cells_spread": spread(cost), "src_frames_spread": spread(frames), "local_time_spread": spread(tms),
+            "backend": ctx.backend if ctx.world > 1 else "none (single rank)"}
+
+
 def run_model(ctx, args, workload, steps, warmup, sustain=0):
     step, wl, state = build_model_step(ctx, args, workload)
     warmup = max(warmup, 2 * len(state["batches"]))      # MIOpen / hipBLASLt pick algorithms per new shape: keep that out of the timing
@@ -640,6 +670,7 @@ def run_model(ctx, args, workload, steps, warmup, sustain=0):
     B = state["B"]
     rep = {"workload": wl, "value": ctx.world * B * steps / elapsed, "unit": "utt/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps,
            "warmup": warmup, "batch_per_gpu": B}
+    rep["scaling_diag"] = scaling_diag(ctx, state["batches"], steps)
     if sustain > 0:                                      # the same step, many more times (not the contract's K: reported beside it)
         el2, _ = ctx.timed(step, sustain, 0, flush=state.get("flush"))
         rep["sustained"] = {"steps": sustain, "value": ctx.world * B * sustain / el2, "unit": "utt/s", "ms_per_step": el2 * 1e3 / sustain}
@@ -683,12 +714,13 @@ def main():
         shards = balanced_shards(frames, world)
         mine = float(frames[ctx.torch.tensor(shards[rank])].sum())
         el, _ = ctx.timed(lambda i: time.sleep(mine * 1e-8), args.steps, args.warmup)
+        diag = scaling_diag(ctx, [{"net_input": {"src_lengths": frames[ctx.torch.tensor(shards[rank])]}}], args.steps)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "none", "data": "none", "config": {"workload": "plumbing rehearsal: no kernels, NOT a measurement",
                                                                            "backend": ctx.backend, "shard_spread": shard_spread(frames, shards)},
-                              "roofline": None, "cpu_baseline": None}))
+                              "roofline": None, "cpu_baseline": None, "scaling_diag": diag}))
         if world > 1:
             ctx.dist.destroy_process_group()
         return
@@ -702,7 +734,7 @@ def main():
                   "config": {"workload": rep["workload"], "batch_per_gpu": rep["batch_per_gpu"], "parallelism": par,
                              **({"mel_frames_per_utt": rep["mel_frames_per_utt"]} if "mel_frames_per_utt" in rep else {}),
                              **({"peak_memory_GB": rep["peak_memory_GB"]} if "peak_memory_GB" in rep else {})},
-                  "roofline": rep.get("roofline"), "cpu_baseline": None}
+                  "roofline": rep.get("roofline"), "cpu_baseline": None, "scaling_diag": rep.get("scaling_diag")}
     elif args.workload == "dag":
         rep, roofline = dag_report(ctx, args, args.steps, args.warmup)
         result = {**base, "value": rep["utt_per_s"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["step_ms"], "dtype": "f32",
@@ -762,7 +794,8 @@ def main():
                              "batch_per_gpu": s2st["batch_per_gpu"], "dag_batch_per_gpu": args.dag_batch, "graph_len": args.graph_len,
                              "tgt_len": args.tgt_len, "vocab": args.vocab, "trans_len": min(args.tr, args.graph_len - 1),
                              "mel_frames_per_utt": s2st.get("mel_frames_per_utt"), "parallelism": par},
-                  "roofline": roofline, "s2st_vocoder_roofline": s2st.get("roofline"), "dag": dag, "cpu_baseline": None}
+                  "roofline": roofline, "s2st_vocoder_roofline": s2st.get("roofline"), "dag": dag, "cpu_baseline": None,
+                  "scaling_diag": s2st.get("scaling_diag")}
         result["config"]["vocoder_arithmetic"] = VOCODER_ARITH[args.vocoder_backend]
         if "sustained" in s2st:
             result["s2st_sustained"] = s2st["sustained"]

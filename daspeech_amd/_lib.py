@@ -39,6 +39,9 @@ SIGNATURES = {
                                      _c_p, _c_sz, _c_p]),
     "dsp_dag_best_alignment_ld": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                            _c_p, _c_sz, _c_p]),
+    "dsp_dag_loss_fwd_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_loss_bwd_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "dsp_dag_best_alignment_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_pitch_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "dsp_dag_best_alignment": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_dag_alignment_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),

@@ -1,11 +1,15 @@
 """float64 inputs to the DAG operators.
 
 The reference instantiates its kernels for float and double (AT_DISPATCH_FLOATING_TYPES_AND_HALF: dag_loss.cu:160,294,415,499,
-dag_best_alignment.cu:143).  The HIP kernels of this package compute in fp32 only (exp-space strips, fp32 matrix cores) — narrowing a
-double tensor silently would hand back fp32 accuracy under a float64 dtype.  Double inputs are therefore routed HERE: the same
-recurrences on the COMPACT band `links[B, L, TR]` (never the reference's dense [B, L, L] torch form, which needs B·L²·8 bytes), written
-with torch ops in the caller's dtype on the caller's device, differentiable by autograd.  T sequential steps of [B, L, TR] tensor ops:
-a correctness path for double-precision checks, not a fast path (C2 in double: ~0.4 s on an MI355X).
+dag_best_alignment.cu:143).  The fast HIP kernels of this package compute in fp32 (exp-space strips, fp32 matrix cores) — narrowing a
+double tensor silently would hand back fp32 accuracy under a float64 dtype.  Double inputs are routed HERE:
+
+  * GPU tensors (r06): the double-precision HIP kernels of csrc/dag_dp_f64.hip (dsp_dag_loss_fwd_f64 / _bwd_f64 /
+    dsp_dag_best_alignment_f64) behind autograd Functions shaped like the fp32 ones — alpha / beta tables, no autograd through T steps;
+  * the torch band DP below (alpha_table / beta_table / ...): the same recurrences on the COMPACT band `links[B, L, TR]` written with
+    torch ops, device-agnostic and differentiable by autograd — what r05 ran on the GPU too (T tensors of [B, L, TR] doubles kept alive
+    for autograd: out of memory on dense windows); kept as the CPU-tensor form the tests pin to the fp64 oracle and cross-check the
+    kernels against.
 
 Semantics follow the kernels (dag_loss.cu:40-140 alpha, :178-274 beta, dag_best_alignment.cu:39-253): cells outside
 {t < T_b, t <= j < L_b} are -inf, an all -inf predecessor set stays -inf (no emission added), Viterbi ties take the smallest predecessor
@@ -93,12 +97,70 @@ def _pick_loss(a: Tensor, output_length: Tensor, target_length: Tensor) -> Tenso
     return torch.where(torch.isfinite(loss), loss, loss.detach())
 
 
+# ---- GPU: native double-precision kernels ------------------------------------------------------------------------------------------
+
+def _native_forward(match_all, links, output_length, target_length, need_beta):
+    from .. import _lib
+    lib = _lib.load()
+    m = match_all.detach().contiguous(); k = links.detach().contiguous()
+    ol = output_length.contiguous(); tl = target_length.contiguous()
+    B, T, L = m.shape
+    TR = k.shape[2]
+    with torch.cuda.device(m.device):
+        alpha = torch.empty_like(m)
+        beta = torch.empty_like(m) if need_beta else None
+        loss = torch.empty((B,), dtype=torch.float64, device=m.device)
+        _lib.check(lib.dsp_dag_loss_fwd_f64(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(loss),
+                                            B, T, L, TR, _lib.current_stream_handle()), "dsp_dag_loss_fwd_f64")
+    return m, k, ol, tl, alpha, beta, loss
+
+
+class _DagLossF64(torch.autograd.Function):
+    """dag_loss / dag_loss_with_alpha_beta for float64 CUDA tensors (the contract of custom_ops.dag_loss.DagLossWithAlphaBetaFunc)."""
+
+    @staticmethod
+    def forward(ctx, match_all, links, output_length, target_length):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        m, k, ol, tl, alpha, beta, loss = _native_forward(match_all, links, output_length, target_length, need)
+        ctx.save_for_backward(alpha, beta if need else alpha, m, k, ol, tl)
+        if beta is None:
+            beta = torch.zeros_like(alpha)                   # the reference's un-launched beta table (dag_loss.cu:339-340)
+        ctx.mark_non_differentiable(alpha, beta)
+        return loss, alpha, beta
+
+    @staticmethod
+    def backward(ctx, grad_output, _ga, _gb):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None
+        from .. import _lib
+        lib = _lib.load()
+        alpha, beta, m, k, ol, tl = ctx.saved_tensors
+        B, T, L = m.shape
+        TR = k.shape[2]
+        with torch.cuda.device(m.device):
+            go = grad_output.detach().to(torch.float64).contiguous()
+            gm = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+            gl = torch.empty_like(k) if ctx.needs_input_grad[1] else None
+            _lib.check(lib.dsp_dag_loss_bwd_f64(_lib.ptr(go), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl),
+                                                _lib.ptr(gm), _lib.ptr(gl), B, T, L, TR, _lib.current_stream_handle()), "dsp_dag_loss_bwd_f64")
+        return gm, gl, None, None
+
+
+def _native(match_all: Tensor, links: Tensor) -> bool:
+    return match_all.is_cuda and links.is_cuda and match_all.shape[2] <= 10240
+
+
 def dag_loss(match_all: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor) -> Tensor:
+    if _native(match_all, links):
+        return _DagLossF64.apply(match_all, links, output_length, target_length)[0]
     a = alpha_table(match_all, links, output_length, target_length)
     return _pick_loss(a, output_length, target_length)
 
 
 def dag_loss_with_alpha_beta(match_all: Tensor, links: Tensor, output_length: Tensor, target_length: Tensor):
+    if _native(match_all, links):
+        loss, a, b = _DagLossF64.apply(match_all, links, output_length, target_length)
+        return loss, (a, b)
     a = alpha_table(match_all, links, output_length, target_length)
     loss = _pick_loss(a, output_length, target_length)
     need = match_all.requires_grad or links.requires_grad
@@ -113,6 +175,18 @@ def dag_best_alignment(match_all: Tensor, links: Tensor, output_length: Tensor, 
     """path[B, L]: the target position each vertex of the best path emits, -1 off the path (dag_best_alignment.cu:182-253)."""
     B, T, L = match_all.shape
     TR = links.shape[2]
+    if _native(match_all, links):
+        from .. import _lib
+        lib = _lib.load()
+        m = match_all.detach().contiguous(); k = links.detach().contiguous()
+        ol = output_length.contiguous(); tl = target_length.contiguous()
+        with torch.cuda.device(m.device):
+            amax = torch.empty_like(m)
+            trace = torch.empty((B, T, L), dtype=torch.int32, device=m.device)
+            path = torch.empty((B, L), dtype=torch.long, device=m.device)
+            _lib.check(lib.dsp_dag_best_alignment_f64(_lib.ptr(m), _lib.ptr(k), _lib.ptr(ol), _lib.ptr(tl), _lib.ptr(amax), _lib.ptr(trace),
+                                                      _lib.ptr(path), B, T, L, TR, _lib.current_stream_handle()), "dsp_dag_best_alignment_f64")
+        return path
     a = alpha_table(match_all, links, output_length, target_length, use_max=True)
     lt, pred, ok = _links_by_target(links)
     path = torch.full((B, L), -1, dtype=torch.long, device=match_all.device)

@@ -10,12 +10,14 @@ import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
-def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int = None, bucket_elems: int = 2 ** 28):
-    """grad <- sum over ranks of grad / world_size, in place, through flat buckets of at most `bucket_elems` elements."""
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int = None, bucket_elems: int = 2 ** 28, force: bool = False):
+    """grad <- sum over ranks of grad / world_size, in place, through flat buckets of at most `bucket_elems` elements.
+    force: run the flatten / all-reduce / unflatten path even in a world of one rank (single_rank_self_test: the bucket code and the
+    collective backend are exercised on a 1-GPU box, where the call is otherwise a no-op)."""
     if not dist.is_available() or not dist.is_initialized():
         return
     world_size = world_size or dist.get_world_size()
-    if world_size == 1:
+    if world_size == 1 and not force:
         return
     # every rank must flatten the SAME layout: a parameter without a gradient on this rank (unused branch, zero_grad(set_to_none))
     # gets a zero gradient, as the reference's legacy DDP does (legacy_distributed_data_parallel.py:134-137)
@@ -43,6 +45,42 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int =
             n += g.numel()
         if bucket:
             reduce_bucket(bucket)
+
+
+def single_rank_self_test(device, backend: str = "nccl", bucket_elems: int = 1000) -> dict:
+    """A process group of ONE rank on `device` (backend "nccl" = RCCL) and the flat-bucket exchange forced through it: several buckets, two
+    dtypes, a parameter without a gradient.  In a world of one the all-reduce is the identity, so every gradient must come back bit-identical
+    (and the missing one as zeros).  What a 1-GPU box can verify of the multi-GPU path: RCCL initialises on this device, the bucket layout
+    round-trips, the collective runs on the device's stream.  Returns what it did; raises on any mismatch."""
+    import socket
+    own_group = not dist.is_initialized()
+    if own_group:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+    try:
+        g = torch.Generator().manual_seed(5)
+        shapes = [(300,), (17, 40), (900,), (5, 5, 5), (64,)]
+        params = [torch.nn.Parameter(torch.randn(s, generator=g).to(device)) for s in shapes]
+        params.append(torch.nn.Parameter(torch.randn(33, generator=g).to(device).half()))
+        for p in params[:-2] + params[-1:]:
+            p.grad = torch.randn(p.shape, generator=g).to(device).to(p.dtype)
+        want = [None if p.grad is None else p.grad.clone() for p in params]
+        all_reduce_gradients(params, bucket_elems=bucket_elems, force=True)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+        for p, w in zip(params, want):
+            assert p.grad is not None
+            assert torch.equal(p.grad, torch.zeros_like(p) if w is None else w), "flat-bucket round trip changed a gradient"
+        probe = torch.ones(4, device=device)
+        dist.all_reduce(probe)
+        assert float(probe.sum()) == 4.0
+        return {"backend": dist.get_backend(), "world": dist.get_world_size(), "params": len(params), "bucket_elems": bucket_elems}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 # ----------------------------------------------------------------------------------------------------------------------------

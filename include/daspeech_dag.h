@@ -149,6 +149,19 @@ int dsp_dag_best_alignment_ld(const float* match, int ld_match, const float* lin
  * kernel pin — else pass dense tensors (ld = L). */
 int dsp_dag_pitch_supported(int op, int L, int TR);
 
+/* ------------------------------------------------------------------------------------------------
+ * The three DP operators in DOUBLE precision (r06; csrc/dag_dp_f64.hip) — the reference dispatches its kernels for double as well
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, dag_loss.cu:160,294,415,499, dag_best_alignment.cu:143,219).  Dense [B,T,L] / [B,L,TR] double tensors,
+ * every intermediate a double, log space, one workgroup per (sample, direction): a correctness path (L <= 10240), not a fast one.  Same
+ * semantics as the fp32 entry points; dsp_dag_best_alignment_f64 always needs its int32 trace [B,T,L]. */
+int dsp_dag_loss_fwd_f64(const double* match, const double* links, const int64_t* out_len, const int64_t* tgt_len,
+                         double* alpha, double* beta, double* loss, int B, int T, int L, int TR, dsp_stream_t stream);
+int dsp_dag_loss_bwd_f64(const double* grad_out, const double* alpha, const double* beta, const double* match, const double* links,
+                         const int64_t* out_len, const int64_t* tgt_len, double* grad_match, double* grad_links,
+                         int B, int T, int L, int TR, dsp_stream_t stream);
+int dsp_dag_best_alignment_f64(const double* match, const double* links, const int64_t* out_len, const int64_t* tgt_len,
+                               double* alpha_max, int32_t* trace, int64_t* path, int B, int T, int L, int TR, dsp_stream_t stream);
+
 /* The two halves of the alignment, separately — what the Viterbi graph decode needs
  * (s2s_conformer_dag_fastspeech2.py:244-304: max-product steps over the links, THEN the length is chosen, THEN the back-trace):
  *   dsp_dag_max_alpha   alpha_max[b,t,j] = match[b,t,j] + max_d(alpha_max[b,t-1,j-d] + links[b,j-d,d-1]) and its arg-max

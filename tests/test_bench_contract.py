@@ -67,6 +67,12 @@ def test_bench_self_spawn_world2_gloo_rehearsal():
     d = _json_line(out.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["shard_spread"] <= 0.05
+    # r06: per-rank record for the scaling runs — device, shard sizes, cost and its spread, each rank's own clock
+    sd = d["scaling_diag"]
+    assert [r["rank"] for r in sd["ranks"]] == [0, 1] and sd["backend"] == "gloo"
+    assert all(r["utterances_per_step"] == [32] and r["src_frames_per_step"][0] > 0 and r["dag_cells_per_step"][0] > 0 for r in sd["ranks"])
+    assert sd["src_frames_spread"] <= 0.05 and sd["dag_cells_spread"] <= 0.10 and 0.0 <= sd["local_time_spread"] <= 1.0
+    assert all(r["local_ms_per_step"] > 0 for r in sd["ranks"])
     assert out.stderr.count("all-reduce ok") == 2
     assert len([l for l in out.stdout.split("\n") if l.startswith("{")]) == 1          # rank 0 only
 

@@ -87,3 +87,14 @@ def test_shard_sample_trims_to_the_shard():
             assert torch.equal(sub["target_audio"][j, :m], pool["target_audio"][i, :m])
         seen += shards[r]
     assert sorted(seen) == list(range(12))
+
+
+def test_single_rank_self_test_gloo():
+    """distributed.single_rank_self_test on CPU (gloo): the forced flat-bucket round trip in a world of one (the GPU twin runs it over RCCL)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch; from daspeech_amd.distributed import single_rank_self_test; "
+            "r = single_rank_self_test(torch.device('cpu'), backend='gloo'); assert r['world'] == 1 and r['params'] == 6, r; print('ok')" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

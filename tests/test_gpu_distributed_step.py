@@ -6,6 +6,7 @@ the mean of the per-rank gradients (legacy_distributed_data_parallel.py:107-110,
   * `gloo`, 2 processes sharing ONE GPU: runs on the single-GPU box of the driver (gloo reduces CUDA tensors through the host);
   * `nccl` (= RCCL over xGMI), one process per GPU: skipped unless >= 2 GPUs are visible — the rehearsal for the 8-GPU node."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PICK = ("decoder.gate_linear.weight", "encoder.conformer_layers.1.ffn1.w_1.weight", "decoder.layers.0.fc1.weight", "adaptor.fc1.weight",
         "tts.out_proj.weight", "tts.var_adaptor.embed_pitch.weight", "decoder.embed_tokens.weight")
 
@@ -93,7 +95,10 @@ def _run(backend, one_gpu):
         assert o["total"] == pytest.approx(total, rel=2e-4)
         for k in PICK:
             w = want[k].cpu()
-            assert float(np.abs(o["grads"][k] - w.numpy()).max()) <= 2e-4 * float(w.abs().max()) + 1e-7 * total, k
+            # (r06: the step's stock-torch layers are not run-to-run deterministic on this stack — tools/train_step_determinism.py measures up to
+            #  ~1e-3 of a gradient's own maximum between two identical single-process steps, 1e-2 on one TTS convolution weight; the DAG ops
+            #  themselves are bit-reproducible, tools/determinism_stress.py.  A wrong exchange (sum instead of mean, a missing rank) is O(1).)
+            assert float(np.abs(o["grads"][k] - w.numpy()).max()) <= 3e-3 * float(w.abs().max()) + 1e-7 * total, k
     assert all(np.array_equal(res[0]["grads"][k], res[1]["grads"][k]) for k in PICK)       # both ranks hold the same reduced gradient
 
 
@@ -129,3 +134,17 @@ def test_bench_dag_workload_two_ranks_through_its_own_launcher():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dag"]["finite_losses"] == 4 and d["dag"]["launch_status"] == 0
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job: both ranks' utterances
     assert d["roofline"]["frac"] > 0
+
+
+def test_single_rank_rccl_flat_bucket_self_test():
+    """r06: what a 1-GPU box can verify of the multi-GPU gradient exchange — a one-rank "nccl" (= RCCL) process group on cuda:0 and the
+    flat-bucket all-reduce forced through it (several buckets, two dtypes, a parameter without a gradient): gradients come back bit-identical.
+    Run in a child process: the test session itself must not keep a process group."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import torch; from daspeech_amd.distributed import single_rank_self_test; "
+            "r = single_rank_self_test(torch.device('cuda:0')); assert r['backend'] == 'nccl' and r['world'] == 1, r; print('ok', r)" % ROOT)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
