@@ -274,11 +274,22 @@ def test_full_size_properties(TR):
         best.append(s)
     best = np.array(best)
     assert np.all(best <= loss.detach().cpu().numpy() + 1e-3)                  # best path <= marginal
-    # compare with the max-DP score recomputed by torch on a banded formulation for a few samples
-    ref = orc.dag_best_alignment(mc[:2], kc[:2], ol.cpu().numpy()[:2], tl.cpu().numpy()[:2], np.float32)
-    np.testing.assert_array_equal(pc[:2], ref)
-    # ... and one utterance's GRADIENTS element by element against the fp64 oracle (K4 / K5 at full size, not only their row sums)
-    _check_grads_against_oracle(mc, kc, ol, tl, gm, gl, bs=7)
+    # r06: EVERY utterance of the batch against the oracle, not one — the Viterbi paths bit for bit (the oracle's sequential fp32 max-DP +
+    # back-trace), the loss and the alpha / beta tables element-wise against the fp64 recurrences (4.3e9 terms per direction on the host cores)
+    oln, tln = ol.cpu().numpy(), tl.cpu().numpy()
+    np.testing.assert_array_equal(pc, orc.dag_best_alignment(mc, kc, oln, tln, np.float32))
+    for name, got, fn in (("alpha", alpha, orc.dag_alpha), ("beta", beta, orc.dag_beta)):
+        want = fn(mc, kc, oln, tln, np.float64)
+        g = got.detach().cpu().numpy()
+        assert np.array_equal(np.isneginf(g), np.isneginf(want)), name
+        f = np.isfinite(want)
+        np.testing.assert_allclose(g[f], want[f], rtol=3e-6, atol=2e-5 * T, err_msg=name)
+        if name == "beta":
+            np.testing.assert_allclose(loss.detach().cpu().numpy(), want[:, 0, 0], rtol=3e-6, atol=2e-5 * T)
+        del want, g, f
+    # ... and four utterances' GRADIENTS element by element against the fp64 oracle (K4 / K5 at full size, not only their row sums)
+    for bs in (0, 7, 19, 31):
+        _check_grads_against_oracle(mc, kc, ol, tl, gm, gl, bs=bs)
 
 
 # ---------------------------------------------------------------------------------------------- fast path vs generic

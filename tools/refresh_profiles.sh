@@ -28,9 +28,9 @@ echo "# rocprofv3 --pmc passes (separate runs, --kernel-trace only) over: $DAGCM
 echo "## FETCH_SIZE (raw KB; double it for 16-byte-per-lane streams, MI355X_MICROARCH.md HBM section)"; pmc FETCH_SIZE "dsp::" $DAGCMD
 echo "## WRITE_SIZE (KB)"; pmc WRITE_SIZE "dsp::" $DAGCMD
 echo "## SQ issue / wait counters of the DP kernels (quad-cycle units)"
-pmc "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "strip|maxstrip|grad_links" $DAGCMD
-pmc "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "strip|maxstrip|grad_links" $DAGCMD
-pmc "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "strip|maxstrip|grad_links" $DAGCMD
+pmc "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "strip|maxstrip|grad_links|backtrace" $DAGCMD
+pmc "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "strip|maxstrip|grad_links|backtrace" $DAGCMD
+pmc "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "strip|maxstrip|grad_links|backtrace" $DAGCMD
 } > $OUT/pmc_dag.txt 2>&1
 # the bench line's roofline.traffic comes from THIS pass: per-dispatch FETCH_SIZE (doubled: 16-byte-per-lane streams on gfx950) + WRITE_SIZE of the DP forward
 python - "$OUT/pmc_dag.txt" "$TAG" <<'PY'
