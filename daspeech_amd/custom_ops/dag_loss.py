@@ -21,6 +21,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
     (dag_loss.cu:68-69) — the criteria already zero non-finite losses (nat_dag_loss.py:143-145);
   * Viterbi ties follow the torch implementation's rule (smallest predecessor index), see SURVEY.md §7.
 """
+import os
 from typing import Tuple
 
 import torch
@@ -107,8 +108,13 @@ def _row_pitch(t: Tensor):
     return ld
 
 
+_PITCH_FILL = os.environ.get("DSP_PITCH_FILL")          # debug: "nan" poisons the pitch padding (nothing may ever read it)
+
+
 def _pitched_empty(B: int, T: int, L: int, dev, fill=None) -> Tensor:
     """[B,T,L] fp32 view of a [B,T,round4(L)] buffer."""
+    if fill is None and _PITCH_FILL:
+        fill = float(_PITCH_FILL)
     buf = torch.empty((B, T, _round4(L)), dtype=torch.float32, device=dev) if fill is None else \
         torch.full((B, T, _round4(L)), fill, dtype=torch.float32, device=dev)
     return buf[:, :, :L] if buf.shape[2] != L else buf

@@ -92,13 +92,18 @@ def _run(backend, one_gpu):
         assert o["world"] == 2
         assert o["loss"] == pytest.approx(losses[o["rank"]], rel=1e-5)
         assert o["n_grads"] == len(want)                      # a parameter without a local gradient still takes part (zero), as legacy DDP
-        assert o["total"] == pytest.approx(total, rel=2e-4)
+        # Tolerances (r06).  The step's stock-torch layers (MIOpen / hipBLASLt kernels with atomics and run-time algorithm choice) are not
+        # run-to-run reproducible on this stack: tools/train_step_determinism.py finds identical single-process steps up to 1e-3 of a gradient's
+        # maximum apart (1e-2 on one TTS convolution weight), in discrete alternatives; the DAG ops themselves are bit-reproducible
+        # (tools/determinism_stress.py).  The ranks here are fresh processes, the reference below runs in a process earlier tests have warmed.
+        # What this test pins is the EXCHANGE — mean over ranks, every parameter taking part: a sum instead of the mean is a factor 2, a
+        # missing rank ~50 %.
+        assert o["total"] == pytest.approx(total, rel=5e-3)
         for k in PICK:
-            w = want[k].cpu()
-            # (r06: the step's stock-torch layers are not run-to-run deterministic on this stack — tools/train_step_determinism.py measures up to
-            #  ~1e-3 of a gradient's own maximum between two identical single-process steps, 1e-2 on one TTS convolution weight; the DAG ops
-            #  themselves are bit-reproducible, tools/determinism_stress.py.  A wrong exchange (sum instead of mean, a missing rank) is O(1).)
-            assert float(np.abs(o["grads"][k] - w.numpy()).max()) <= 3e-3 * float(w.abs().max()) + 1e-7 * total, k
+            w = want[k].cpu().numpy().astype(np.float64)
+            d = o["grads"][k].astype(np.float64) - w
+            assert np.linalg.norm(d) <= 2e-2 * np.linalg.norm(w) + 1e-7 * total, (k, np.linalg.norm(d) / max(np.linalg.norm(w), 1e-30))
+            assert float(np.abs(d).max()) <= 3e-2 * float(np.abs(w).max()) + 1e-7 * total, k
     assert all(np.array_equal(res[0]["grads"][k], res[1]["grads"][k]) for k in PICK)       # both ranks hold the same reduced gradient
 
 
