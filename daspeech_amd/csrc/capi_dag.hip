@@ -53,12 +53,16 @@ int launch_dag_dense_backtrace(const float*, const unsigned short*, const float*
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR, int ldm, int ldo);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, int, int, hipStream_t);
 
+bool strip2g_supported(int L, int TR);
+int launch_dag_strip2g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+
 bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
 
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
+// 8 = strip2g (2 columns/lane, exp space, windows 33 .. 64: the auto choice there since r06),
 // 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 32).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
@@ -167,7 +171,9 @@ extern "C" int dsp_dag_loss_fwd_ld(const float* match, int ld_match, const float
     }
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    // windows 33 .. 64: the banded log-space strips (C2 at TR = 64: 1.35 ms; the dense-window matrix-core DP with its mostly masked tiles 3.1-3.9)
+    // windows 33 .. 64 (r06): exp-space strips with two vertices per lane (dag_dp_strip2g.hip); dp_path 2 keeps the log-space strips they replace
+    else if ((g_path == 0 || g_path == 8) && strip2g_supported(L, TR))
+        rc = launch_dag_strip2g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 2) && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 9) && dense_mfma_supported(L, TR))

@@ -1101,3 +1101,70 @@ def test_graph_lengths_off_the_16_byte_grid_run_pitched(shape, source):
     path = ops().dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
     np.testing.assert_array_equal(path, orc.dag_best_alignment(match, links, ol, tl, np.float32))
     assert _lib.last_launch_status() == 0
+
+
+@pytest.mark.parametrize("shape", [(3, 30, 1031, 64), (2, 40, 2048, 33), (4, 20, 513, 48), (2, 25, 700, 63), (40, 9, 512, 64), (2, 12, 70, 40),
+                                   (3, 70, 1537, 64)])
+def test_windows_33_to_64_exp_space_strips(shape):
+    """r06: windows 33 .. 64 run dag_dp_strip2g.hip (exp space, two vertices per lane, one exponent per lane pair; dp_path 8 = the auto choice)
+    instead of the log-space strips (dp_path 2) and the generic kernel (dp_path 1): alpha / beta / loss of all three against the fp64 oracle,
+    -inf patterns equal, ragged lengths, graph lengths off every grid, several strips per sample (hand-off of 64 boundary columns), more
+    samples than CUs' worth of strips, a forced-emission row."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(300 + L, B, T, L, TR)
+    match[0, min(3, T - 1), :] = -np.inf; match[0, min(3, T - 1), min(3, T - 1) * (TR // 2) if T > 3 else 0] = -0.25        # forced vertex on one row
+    m, k, o, t = to_dev(match, links, ol, tl)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    fa, fb = np.isfinite(a64), np.isfinite(b64)
+    try:
+        for path in (0, 8, 2, 1):
+            _lib.set_option("dp_path", path)
+            mm = m.clone().requires_grad_()
+            loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(mm, k, o, t)
+            assert _lib.last_launch_status() == 0, path
+            a, b = alpha.cpu().numpy(), beta.cpu().numpy()
+            assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64)), path
+            np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=2e-5 * T, err_msg=str(path))
+            np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=2e-5 * T, err_msg=str(path))
+            ln = loss.detach().cpu().numpy(); want = b64[:, 0, 0]
+            assert np.array_equal(np.isneginf(ln), np.isneginf(want))
+            f = np.isfinite(want)
+            np.testing.assert_allclose(ln[f], want[f], rtol=3e-6, atol=2e-5 * T)
+            # alpha only (no gradient): the one-direction launch
+            with torch.no_grad():
+                l0 = ops().dag_loss(m, k, o, t).cpu().numpy()
+            np.testing.assert_allclose(l0[f], want[f], rtol=3e-6, atol=2e-5 * T)
+    finally:
+        _lib.set_option("dp_path", 0)
+
+
+@pytest.mark.parametrize("slope,scale", [(2.0, 1.0), (12.0, 4.0), (40.0, 12.0)])
+def test_windows_33_to_64_on_peaked_scores(slope, scale):
+    """The 33 .. 64 exp-space strips where their shared exponents run out: emissions that fall `slope` nats per vertex away from the aligned
+    position and transition logits stretched by `scale` (weights over 100 binades under their column's strongest) — the single-transition
+    shortcut on the diagonal and the exact log-space path must give the fp64 oracle's tables."""
+    from daspeech_amd import _lib
+    B, T, L, TR = 2, 30, 1100, 64
+    match, links, ol, tl = make_dag_inputs(777, B, T, L, TR, ragged=True)
+    jj = np.arange(L, dtype=np.float32)[None, None, :]
+    centre = (np.arange(T, dtype=np.float32) * (L - 1) / (T - 1))[None, :, None]
+    match = (match * 0.1 - slope * np.abs(jj - centre)).astype(np.float32)
+    fin = np.isfinite(links)
+    links = np.where(fin, links * scale, links)
+    mx = np.max(np.where(fin, links, -1e30), -1, keepdims=True)
+    ssum = np.where(fin, np.exp(links - mx), 0).sum(-1, keepdims=True)
+    links = np.where(fin, links - mx - np.log(np.where(ssum > 0, ssum, 1)), links).astype(np.float32)
+    m, k, o, t = to_dev(match, links, ol, tl)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    try:
+        _lib.set_option("dp_path", 8)
+        loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m.requires_grad_(), k, o, t)
+        assert _lib.last_launch_status() == 0
+    finally:
+        _lib.set_option("dp_path", 0)
+    a, b = alpha.cpu().numpy(), beta.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(a64)) and np.array_equal(np.isneginf(b), np.isneginf(b64))
+    fa, fb = np.isfinite(a64), np.isfinite(b64)
+    np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
+    np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
