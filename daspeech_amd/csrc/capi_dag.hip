@@ -53,6 +53,9 @@ int launch_dag_dense_backtrace(const float*, const unsigned short*, const float*
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR, int ldm, int ldo);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, int, int, hipStream_t);
 
+bool strip1g_supported(int L, int TR);
+size_t strip1g_ws_bytes(int B, int T, int L, int ndir);
+int launch_dag_strip1g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 bool strip2g_supported(int L, int TR);
 int launch_dag_strip2g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
 
@@ -62,7 +65,7 @@ int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, cons
 // test hook: dsp_dag_set_option("dp_path", n): 0 = auto, 1 = generic row-sequential, 2 = banded 2-column log-space,
 // 4 = strip2 (2 columns/lane, loader wave), 5 = strip4g (4 columns/lane, exp space, one exponent per lane group),
 // 7 = values-only max-DP strips + lazy back-trace for dag_best_alignment (the auto choice when trace == NULL),
-// 8 = strip2g (2 columns/lane, exp space, windows 33 .. 64: the auto choice there since r06),
+// 8 = strip2g / strip1g (2 columns/lane x 64 transitions, 1 x 128: exp space, windows 33 .. 64 / 65 .. 128: the auto choice there since r06),
 // 9 = dense-window exp-space blocked product on the f32 matrix cores (the auto choice for TR > 32).
 // (3 and 6 were the strip4 / strip4h generations, removed in r02.)  Per THREAD: a test pinning a kernel family does not change what
 // another thread's calls launch.
@@ -116,7 +119,12 @@ extern "C" size_t dsp_dag_workspace_bytes(int B, int T, int L, int TR)
         const size_t dense = (TR > 32 && dense_mfma_supported(L, TR)) ? dense_fwd_ws_bytes(B, T, L, TR) : 0;
         return banded > dense ? banded : dense;
     }
-    return dense_fwd_ws_bytes(B, T, L, TR);
+    const size_t dense = dense_fwd_ws_bytes(B, T, L, TR);
+    if (strip1g_supported(L, TR)) {                   // windows 65 .. 128: exp-space strips of 256 columns, 128 granules per row and strip
+        const size_t strips = align256(strip1g_ws_bytes(B, T, L, 2)) + 512;
+        return strips > dense ? strips : dense;
+    }
+    return dense;
 }
 
 // ... and the alignment (dsp_dag_best_alignment_ws): the value-only strip DP's hand-off rows, or for dense windows the re-laid-out
@@ -176,6 +184,9 @@ extern "C" int dsp_dag_loss_fwd_ld(const float* match, int ld_match, const float
         rc = launch_dag_strip2g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 2) && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
+    // windows 65 .. 128 (r06): exp-space strips with one vertex per lane (dag_dp_strip1g.hip); dp_path 9 keeps the dense-window kernels on them
+    else if ((g_path == 0 || g_path == 8) && strip1g_supported(L, TR))
+        rc = launch_dag_strip1g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 9) && dense_mfma_supported(L, TR))
         rc = launch_dag_dense_mfma(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else

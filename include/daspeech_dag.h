@@ -189,8 +189,9 @@ int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace
  * Diagnostics (no reference counterpart).
  *   dsp_dag_set_option("dp_path", n) pins the DP kernel family FOR THE CALLING THREAD: 0 = auto, 1 = generic row-sequential /
  *   log-space dense, 2 = banded 2-column log-space strips, 4 = strip2 (2 vertices per lane), 5 = strip4g (exp-space, one exponent per
- *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment), 8 = strip2g (r06: exp space,
- *   2 vertices per lane, one exponent per lane pair; the auto choice of the forward for windows 33 .. 64, where 2 keeps the log-space strips),
+ *   lane group; the auto choice for TR <= 32), 7 = values-only max-DP strips + lazy back-trace (dag_best_alignment), 8 = strip2g / strip1g (r06: exp space,
+ *   2 vertices x 64 transitions / 1 x 128 per lane; the auto choice of the forward for windows 33 .. 64 / 65 .. 128, where 2 / 9 keep the log-space
+ *   strips / the dense-window kernels),
  *   9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
  *   cross-check the families.  "k5_path": 0 = auto, 1 = tiled log-space grad_links kernel, 2 = exp-space (TR <= 32) / block products
  *   (TR > 64).  "k5_fuse" 0|1|2|3 (r06): dsp_dag_loss_bwd on a banded graph (TR <= 32) asked for BOTH gradients — 0 = auto (2), 1 / 2 = ONE

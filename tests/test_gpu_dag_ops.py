@@ -1104,21 +1104,24 @@ def test_graph_lengths_off_the_16_byte_grid_run_pitched(shape, source):
 
 
 @pytest.mark.parametrize("shape", [(3, 30, 1031, 64), (2, 40, 2048, 33), (4, 20, 513, 48), (2, 25, 700, 63), (40, 9, 512, 64), (2, 12, 70, 40),
-                                   (3, 70, 1537, 64)])
+                                   (3, 70, 1537, 64),
+                                   (3, 20, 1031, 128), (2, 30, 2048, 65), (4, 16, 513, 96), (2, 25, 700, 127), (70, 6, 256, 128), (2, 12, 140, 100),
+                                   (3, 40, 1537, 128)])
 def test_windows_33_to_64_exp_space_strips(shape):
-    """r06: windows 33 .. 64 run dag_dp_strip2g.hip (exp space, two vertices per lane, one exponent per lane pair; dp_path 8 = the auto choice)
-    instead of the log-space strips (dp_path 2) and the generic kernel (dp_path 1): alpha / beta / loss of all three against the fp64 oracle,
-    -inf patterns equal, ragged lengths, graph lengths off every grid, several strips per sample (hand-off of 64 boundary columns), more
-    samples than CUs' worth of strips, a forced-emission row."""
+    """r06: windows 33 .. 64 run dag_dp_strip2g.hip (exp space, two vertices per lane, one exponent per lane pair) and windows 65 .. 128
+    dag_dp_strip1g.hip (one vertex per lane, the window streamed through two register buffers) — dp_path 8 = the auto choice — instead of the
+    log-space strips (dp_path 2, windows up to 64) / the dense-window kernels (dp_path 9) and the generic kernel (dp_path 1): alpha / beta /
+    loss of all of them against the fp64 oracle, -inf patterns equal, ragged lengths, graph lengths off every grid, several strips per sample
+    (hand-off of 64 / 128 boundary columns), more samples than CUs' worth of strips, a forced-emission row."""
     from daspeech_amd import _lib
     B, T, L, TR = shape
     match, links, ol, tl = make_dag_inputs(300 + L, B, T, L, TR)
-    match[0, min(3, T - 1), :] = -np.inf; match[0, min(3, T - 1), min(3, T - 1) * (TR // 2) if T > 3 else 0] = -0.25        # forced vertex on one row
+    match[0, min(3, T - 1), :] = -np.inf; match[0, min(3, T - 1), min(min(3, T - 1) * (TR // 2), L // 2) if T > 3 else 0] = -0.25        # forced vertex on one row
     m, k, o, t = to_dev(match, links, ol, tl)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
     fa, fb = np.isfinite(a64), np.isfinite(b64)
     try:
-        for path in (0, 8, 2, 1):
+        for path in ((0, 8, 2, 1) if TR <= 64 else ((0, 8, 9, 1) if L >= 128 else (0, 8, 1))):
             _lib.set_option("dp_path", path)
             mm = m.clone().requires_grad_()
             loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(mm, k, o, t)
@@ -1139,13 +1142,14 @@ def test_windows_33_to_64_exp_space_strips(shape):
         _lib.set_option("dp_path", 0)
 
 
+@pytest.mark.parametrize("window", [64, 128, 80])
 @pytest.mark.parametrize("slope,scale", [(2.0, 1.0), (12.0, 4.0), (40.0, 12.0)])
-def test_windows_33_to_64_on_peaked_scores(slope, scale):
+def test_windows_33_to_64_on_peaked_scores(slope, scale, window):
     """The 33 .. 64 exp-space strips where their shared exponents run out: emissions that fall `slope` nats per vertex away from the aligned
     position and transition logits stretched by `scale` (weights over 100 binades under their column's strongest) — the single-transition
     shortcut on the diagonal and the exact log-space path must give the fp64 oracle's tables."""
     from daspeech_amd import _lib
-    B, T, L, TR = 2, 30, 1100, 64
+    B, T, L, TR = 2, 30, 1100, window
     match, links, ol, tl = make_dag_inputs(777, B, T, L, TR, ragged=True)
     jj = np.arange(L, dtype=np.float32)[None, None, :]
     centre = (np.arange(T, dtype=np.float32) * (L - 1) / (T - 1))[None, :, None]

@@ -23,7 +23,7 @@ for case in range(n):
         TR = int(rng.choice([L - 1, L - 1, int(rng.integers(65, L))]))
         T = int(min(L, rng.integers(2, 90 if not big else 200)))
     else:
-        B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32] if not (len(sys.argv) > 3 and sys.argv[3] == "mid") else [33, 40, 48, 63, 64, 64]))
+        B = int(rng.integers(1, 5)); TR = int(rng.choice([1, 2, 5, 8, 16, 20, 31, 32, 32, 32] if not (len(sys.argv) > 3 and sys.argv[3] in ("mid", "mid2")) else ([33, 40, 48, 63, 64, 64] if sys.argv[3] == "mid" else [65, 72, 96, 100, 127, 128, 128])))
         L = int(rng.integers(2, 1500));
         if rng.random() < 0.6: L = max(4, L // 4 * 4)
         TR = min(TR, L - 1) if L > 1 else 1
