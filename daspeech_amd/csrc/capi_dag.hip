@@ -53,6 +53,9 @@ int launch_dag_dense_backtrace(const float*, const unsigned short*, const float*
 bool maxstrip_supported(const void* match, const void* alpha_max, int L, int TR, int ldm, int ldo);
 int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, int, int, hipStream_t);
 
+bool maxstripw_supported(int L, int TR);
+size_t maxstripw_ws_bytes(int B, int T, int L, int TR);
+int launch_dag_maxstripw(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
 bool strip1g_supported(int L, int TR);
 size_t strip1g_ws_bytes(int B, int T, int L, int ndir);
 int launch_dag_strip1g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
@@ -139,12 +142,17 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
         const size_t mx = (size_t)B * NS * T * 32 * 8;
         return align256(256 + (strip > mx ? strip : mx)) + 512;
     }
-    if (TR <= 64) {                                   // banded strips + trace walk; without a trace buffer / under dp_path 9 / L * 4 > 160 KB: the dense kernels
+    if (TR <= 64) {                                   // values-only strips (r06) / banded strips + trace walk; under dp_path 9 or L * 4 > 150 KB: the dense kernels
         const size_t banded = align256(256 + (size_t)B * ((L + 511) / 512) * T * 64 * 8) + 512;
         const size_t dense = dense_max_supported(L, TR) ? dense_align_ws_bytes(B, T, L, TR) : 0;
         return banded > dense ? banded : dense;
     }
-    return dense_align_ws_bytes(B, T, L, TR);
+    const size_t dense = dense_align_ws_bytes(B, T, L, TR);
+    if (maxstripw_supported(L, TR)) {                 // windows 65 .. 128: values-only strips of 256 columns, 128 granules per row and strip
+        const size_t strips = align256(maxstripw_ws_bytes(B, T, L, TR)) + 512;
+        return strips > dense ? strips : dense;
+    }
+    return dense;
 }
 
 // Row pitches (r06, ABI 2): ld_match / ld_ab are the distances in ELEMENTS between consecutive target rows of match and of alpha / beta
@@ -278,8 +286,12 @@ static int best_alignment_impl(const float* match, const float* links, const int
                   "16-byte aligned pointers, pitches that are multiples of 4)", ld_match, ld_am, L);
         return DSP_EINVAL;
     }
+    // windows 33 .. 128 (r06): values-only max-DP strips with 2 x 64 / 1 x 128 transitions per lane + the wide back-trace (dag_dp_maxstripw.hip):
+    // no trace tensor.  dp_path 2 / 9 keep the log-space strips + trace walk / the blocked max-plus kernels on these windows.
+    if ((g_path == 0 || g_path == 7) && maxstripw_supported(L, TR))
+        return launch_dag_maxstripw(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
     // windows 33 .. 64 with a trace buffer: the banded log-space strips + trace walk (C2 at TR = 64: 2.0 ms against 3.1 for the dense kernels)
-    const bool mid = TR > 32 && TR <= 64 && trace && g_path == 0 && (size_t)L * 4 <= 160 * 1024 && banded_supported(L, TR);
+    const bool mid = TR > 32 && TR <= 64 && trace && (g_path == 0 || g_path == 2) && (size_t)L * 4 <= 160 * 1024 && banded_supported(L, TR);
     // dense window: blocked max-plus DP + trace-free back-trace (the trace buffer, if given, is left untouched)
     if ((g_path == 0 || g_path == 9) && !mid && dense_max_supported(L, TR))
         return launch_dag_dense_max(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
@@ -362,7 +374,8 @@ extern "C" int dsp_dag_pitch_supported(int op, int L, int TR)
 
 extern "C" int dsp_dag_alignment_trace_optional(int L, int TR)
 {
-    if (g_path == 0 && TR > 32 && TR <= 64) return 0;                      // the banded strips of this window keep a trace
+    if ((g_path == 0 || g_path == 7) && maxstripw_supported(L, TR)) return 1;     // windows 33 .. 128: values-only strips + wide back-trace
+    if ((g_path == 0 || g_path == 2) && TR > 32 && TR <= 64) return 0;             // the banded log-space strips of this window keep a trace
     if ((g_path == 0 || g_path == 9) && dense_max_supported(L, TR)) return 1;
     return ((g_path == 0 || g_path == 7) && TR <= 32 && (L & 3) == 0 && L <= 8192) ? 1 : 0;
 }

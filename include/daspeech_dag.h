@@ -125,7 +125,8 @@ int dsp_dag_loss_bwd_ld(const float* grad_out, const float* alpha, const float* 
  *   alpha_max [B,T,L] fp32 out, trace [B,T,L] int32 out (scratch the caller owns), path [B,L] int64 out
  *   (the reference returns int32 and casts in Python, dag_loss.py:228).  path[b,j] = t or -1.
  *   Tie rule: smallest predecessor index among equal maxima (torch.max rule, dag_loss.py:320).
- *   trace may be NULL where dsp_dag_alignment_trace_optional(L, TR) returns 1: the DP then keeps values only and the
+ *   trace may be NULL where dsp_dag_alignment_trace_optional(L, TR) returns 1 (r06: every window — TR <= 32 on 16-byte rows, 33 .. 128 on the
+ *   values-only strips of dag_dp_maxstripw.hip, dense windows; 0 remains for TR <= 32 with L off the 16-byte grid or L > 8192, and under kernel pins): the DP then keeps values only and the
  *   back-trace recomputes the arg-max of the T cells it visits (same tie rule) — no B*T*L int32 trace tensor is produced
  *   (for dense windows, TR > 64, the scratch of dsp_dag_alignment_workspace_bytes holds a 2-byte block index per cell that narrows
  *   that recomputation to 64 candidates).

@@ -767,7 +767,7 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
         links = np.where(np.isfinite(links), np.round(links * 2) / 2, links).astype(np.float32)
     m, k, o, t = to_dev(match, links, ol, tl)
     ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
-    mid = 32 < TR <= 64                          # r05: the auto choice for these windows is the banded log-space strips (with a trace); 9 pins the dense kernels
+    mid = 32 < TR <= 128                         # r06: the auto choice for these windows is the values-only max-DP strips (dag_dp_maxstripw.hip); 9 pins the dense kernels
     try:
         for path in (0, 1, 9):
             _lib.set_option("dp_path", path)
@@ -782,7 +782,7 @@ def test_dense_alignment_bit_exact_with_ties(shape, quant):
             np.testing.assert_array_equal(got, ref, err_msg=f"dx_mt {mt}")
     finally:
         _lib.set_option("dp_path", 0); _lib.set_option("dx_mt", 0)
-    assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == (0 if mid else 1)    # no B*T*L trace tensor for dense windows either (the banded strips of 33 .. 64 keep one)
+    assert _lib.load().dsp_dag_alignment_trace_optional(L, TR) == 1    # no B*T*L trace tensor for any window above 32 (r06: 33 .. 64 included)
 
 
 def _relink(links, ol, seed):
@@ -1172,3 +1172,36 @@ def test_windows_33_to_64_on_peaked_scores(slope, scale, window):
     fa, fb = np.isfinite(a64), np.isfinite(b64)
     np.testing.assert_allclose(a[fa], a64[fa], rtol=3e-6, atol=1e-3)
     np.testing.assert_allclose(b[fb], b64[fb], rtol=3e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(3, 30, 1031, 64), (2, 40, 2048, 33), (4, 20, 513, 48), (40, 9, 512, 64), (2, 12, 70, 40), (3, 70, 1537, 64),
+                                   (3, 20, 1031, 128), (2, 30, 2048, 65), (4, 16, 513, 96), (70, 6, 256, 128), (2, 12, 140, 100), (3, 40, 1537, 128)])
+def test_windows_33_to_128_alignment_without_a_trace_tensor(shape):
+    """r06: dag_best_alignment for windows 33 .. 128 = values-only max-DP strips (2 x 64 / 1 x 128 transitions per lane) + a back-trace that
+    recomputes the arg-max of the cells it visits (dag_dp_maxstripw.hip; the auto choice, dp_path 7) — bit-exact against the oracle's sequential
+    max-DP + back-trace and against the kernels that served these windows before (dp_path 2: log-space strips + trace walk, 9: blocked max-plus),
+    on scores quantised to half-integers so that exact ties occur (smallest predecessor index wins), ragged lengths, several strips per sample,
+    an unreachable sample (path = -1 beyond what the chain visits)."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(400 + L, B, T, L, TR)
+    match = (np.round(match * 2) / 2).astype(np.float32)
+    links = np.where(np.isfinite(links), np.round(links * 2) / 2, links).astype(np.float32)
+    if B > 2 and L > 2 * TR + 4:
+        tl = tl.copy(); tl[2] = 2                              # two rows cannot span the graph: the end is unreachable
+    m, k, o, t = to_dev(match, links, ol, tl)
+    ref = orc.dag_best_alignment(match, links, ol, tl, np.float32)
+    assert lib_trace_optional(L, TR), "windows 33 .. 128 take no trace tensor"
+    try:
+        for path in (0, 7) + ((2,) if TR <= 64 else ((9,) if L >= 128 else ())) + (1,):
+            _lib.set_option("dp_path", path)
+            got = ops().dag_best_alignment(m, k, o, t).cpu().numpy()
+            assert _lib.last_launch_status() == 0, path
+            np.testing.assert_array_equal(got, ref, err_msg=f"dp_path {path}")
+    finally:
+        _lib.set_option("dp_path", 0)
+
+
+def lib_trace_optional(L, TR):
+    from daspeech_amd import _lib
+    return bool(_lib.load().dsp_dag_alignment_trace_optional(L, TR))
