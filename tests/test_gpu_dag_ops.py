@@ -716,7 +716,7 @@ def test_workspace_sizes_are_reported_and_library_scratch_still_works():
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("shape", [(4, 20, 512, 32), (3, 24, 200, 199)])
+@pytest.mark.parametrize("shape", [(4, 20, 512, 32), (3, 24, 200, 199), (3, 20, 1100, 64), (3, 16, 700, 100), (3, 20, 515, 32)])
 def test_dag_ops_are_graph_capturable(shape):
     """dag_loss forward + backward and dag_best_alignment captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on new inputs:
     the launches keep no host-side state (caller workspace zeroed on the stream, tags start at 1), so the replay must give what eager
