@@ -55,12 +55,12 @@ int launch_dag_maxstrip(const float*, const float*, const int64_t*, const int64_
 
 bool maxstripw_supported(int L, int TR);
 size_t maxstripw_ws_bytes(int B, int T, int L, int TR);
-int launch_dag_maxstripw(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, hipStream_t);
+int launch_dag_maxstripw(const float*, const float*, const int64_t*, const int64_t*, float*, int64_t*, int, int, int, int, int, int, hipStream_t);
 bool strip1g_supported(int L, int TR);
 size_t strip1g_ws_bytes(int B, int T, int L, int ndir);
-int launch_dag_strip1g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+int launch_dag_strip1g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, int, int, hipStream_t);
 bool strip2g_supported(int L, int TR);
-int launch_dag_strip2g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, hipStream_t);
+int launch_dag_strip2g(const float*, const float*, const int64_t*, const int64_t*, float*, float*, int, int, int, int, int, int, hipStream_t);
 
 bool strip2_supported(const void* match, const void* alpha, const void* beta, const void* trace, int L, int TR);
 int launch_dag_strip2(int mode, const float*, const float*, const int64_t*, const int64_t*, float*, float*, int32_t*, int, int, int, int, hipStream_t);
@@ -157,7 +157,7 @@ extern "C" size_t dsp_dag_alignment_workspace_bytes(int B, int T, int L, int TR)
 
 // Row pitches (r06, ABI 2): ld_match / ld_ab are the distances in ELEMENTS between consecutive target rows of match and of alpha / beta
 // (batch stride = T * ld).  Dense tensors have ld = L (dsp_dag_loss_fwd).  A graph whose length is not a multiple of 4 — three in four are —
-// keeps its rows on 16-byte boundaries by a pitch rounded up to 4: the TR <= 32 strip kernels then serve it without a padded copy
+// keeps its rows on 16-byte boundaries by a pitch rounded up to 4: the strip kernels (windows <= 128) then serve it without a padded copy
 // (dag_logsoftmax_gather_inplace writes `match` with such a pitch itself).  The other kernel families take dense tensors only.
 static int check_ld(const char* fn, int L, int ld_match, int ld_ab)
 {
@@ -180,21 +180,21 @@ extern "C" int dsp_dag_loss_fwd_ld(const float* match, int ld_match, const float
     // auto: strip4g for the log-sum DP, strip2 for the max-DP with a trace
     if ((g_path == 0 || g_path == 5) && strip4g_supported(match, alpha, beta, L, TR, ld_match, ld_ab))
         rc = launch_dag_strip4g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, ld_match, ld_ab, st);
+    // windows 33 .. 64 (r06): exp-space strips with two vertices per lane (dag_dp_strip2g.hip); dp_path 2 keeps the log-space strips they replace
+    else if ((g_path == 0 || g_path == 8) && strip2g_supported(L, TR))
+        rc = launch_dag_strip2g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, ld_match, ld_ab, st);
+    // windows 65 .. 128 (r06): exp-space strips with one vertex per lane (dag_dp_strip1g.hip); dp_path 9 keeps the dense-window kernels on them
+    else if ((g_path == 0 || g_path == 8) && strip1g_supported(L, TR))
+        rc = launch_dag_strip1g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, ld_match, ld_ab, st);
     else if (!dense) {
-        set_error("dag_loss_fwd: pitched rows (ld_match=%d ld_ab=%d, L=%d) are served by the TR <= 32 strip kernels only (16-byte aligned pointers, "
-                  "pitches that are multiples of 4); TR=%d / this kernel pin needs dense tensors", ld_match, ld_ab, L, TR);
+        set_error("dag_loss_fwd: pitched rows (ld_match=%d ld_ab=%d, L=%d) are served by the strip kernels of windows <= 128 only (TR <= 32: 16-byte "
+                  "aligned pointers, pitches that are multiples of 4); TR=%d / this kernel pin needs dense tensors", ld_match, ld_ab, L, TR);
         return DSP_EINVAL;
     }
     else if (g_path == 4 && strip2_supported(match, alpha, beta, nullptr, L, TR))
         rc = launch_dag_strip2(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    // windows 33 .. 64 (r06): exp-space strips with two vertices per lane (dag_dp_strip2g.hip); dp_path 2 keeps the log-space strips they replace
-    else if ((g_path == 0 || g_path == 8) && strip2g_supported(L, TR))
-        rc = launch_dag_strip2g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 2) && banded_supported(L, TR))
         rc = launch_dag_banded(0, match, links, out_len, tgt_len, alpha, beta, nullptr, B, T, L, TR, st);
-    // windows 65 .. 128 (r06): exp-space strips with one vertex per lane (dag_dp_strip1g.hip); dp_path 9 keeps the dense-window kernels on them
-    else if ((g_path == 0 || g_path == 8) && strip1g_supported(L, TR))
-        rc = launch_dag_strip1g(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else if ((g_path == 0 || g_path == 9) && dense_mfma_supported(L, TR))
         rc = launch_dag_dense_mfma(match, links, out_len, tgt_len, alpha, beta, B, T, L, TR, st);
     else
@@ -223,7 +223,7 @@ extern "C" int dsp_dag_loss_bwd_ld(const float* grad_out, const float* alpha, co
     if (!grad_out || !alpha || !beta || !match || !links || !out_len || !tgt_len) { set_error("dag_loss_bwd: null pointer"); return DSP_EINVAL; }
     if ((rc = check_ld("dag_loss_bwd", L, ld_match, ld_ab))) return rc;
     if (grad_match && ld_grad_match < L) { set_error("dag_loss_bwd: ld_grad_match=%d smaller than L=%d", ld_grad_match, L); return DSP_EINVAL; }
-    if (ld_ab != L && TR > 32) { set_error("dag_loss_bwd: pitched alpha / beta are served for TR <= 32 only (TR=%d)", TR); return DSP_EINVAL; }
+    if (ld_ab != L && TR > 128) { set_error("dag_loss_bwd: pitched alpha / beta are served for TR <= 128 only (TR=%d)", TR); return DSP_EINVAL; }
     return launch_dag_bwd_generic(grad_out, alpha, beta, match, links, out_len, tgt_len, grad_match, grad_links, B, T, L, TR,
                                   ld_ab, ld_match, grad_match ? ld_grad_match : L, as_stream(stream));
 }
@@ -282,6 +282,8 @@ static int best_alignment_impl(const float* match, const float* links, const int
     if (ld_match != L || ld_am != L) {
         if ((g_path == 0 || g_path == 7) && maxstrip_supported(match, alpha_max, L, TR, ld_match, ld_am))
             return launch_dag_maxstrip(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, ld_match, ld_am, st);
+        if ((g_path == 0 || g_path == 7) && maxstripw_supported(L, TR))
+            return launch_dag_maxstripw(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, ld_match, ld_am, st);
         set_error("dag_best_alignment: pitched rows (ld_match=%d ld_alpha_max=%d, L=%d) are served by the TR <= 32 strip kernels only (L <= 8192, "
                   "16-byte aligned pointers, pitches that are multiples of 4)", ld_match, ld_am, L);
         return DSP_EINVAL;
@@ -289,7 +291,7 @@ static int best_alignment_impl(const float* match, const float* links, const int
     // windows 33 .. 128 (r06): values-only max-DP strips with 2 x 64 / 1 x 128 transitions per lane + the wide back-trace (dag_dp_maxstripw.hip):
     // no trace tensor.  dp_path 2 / 9 keep the log-space strips + trace walk / the blocked max-plus kernels on these windows.
     if ((g_path == 0 || g_path == 7) && maxstripw_supported(L, TR))
-        return launch_dag_maxstripw(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, st);
+        return launch_dag_maxstripw(match, links, out_len, tgt_len, alpha_max, path, B, T, L, TR, L, L, st);
     // windows 33 .. 64 with a trace buffer: the banded log-space strips + trace walk (C2 at TR = 64: 2.0 ms against 3.1 for the dense kernels)
     const bool mid = TR > 32 && TR <= 64 && trace && (g_path == 0 || g_path == 2) && (size_t)L * 4 <= 160 * 1024 && banded_supported(L, TR);
     // dense window: blocked max-plus DP + trace-free back-trace (the trace buffer, if given, is left untouched)
@@ -364,10 +366,13 @@ extern "C" int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* 
 }
 
 // May the caller hand this op PITCHED rows (dsp_dag_loss_fwd_ld / _bwd_ld: op 0, dsp_dag_best_alignment_ld: op 1) for a graph of L vertices?  Only
-// the TR <= 32 strip families take them, so the answer follows the calling thread's dp_path pin like the dispatch itself does.
+// the strip families (windows <= 128) take them, so the answer follows the calling thread's dp_path pin like the dispatch itself does.
 extern "C" int dsp_dag_pitch_supported(int op, int L, int TR)
 {
-    if (TR > 32 || L < 1) return 0;
+    if (L < 1) return 0;
+    if (TR > 32)           // windows 33 .. 128 (r06): the wide strips read match by 4-byte DMA and write their tables row by row — any pitch
+        return op == 0 ? (((g_path == 0 || g_path == 8) && (strip2g_supported(L, TR) || strip1g_supported(L, TR))) ? 1 : 0)
+                       : (((g_path == 0 || g_path == 7) && maxstripw_supported(L, TR)) ? 1 : 0);
     if (op == 0) return (g_path == 0 || g_path == 5) ? 1 : 0;
     return ((g_path == 0 || g_path == 7) && L <= 8192) ? 1 : 0;
 }

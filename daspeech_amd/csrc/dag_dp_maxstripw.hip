@@ -83,6 +83,7 @@ struct MWParams {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word
     u32 tag_base;
     int B, T, L, TR, NS;
+    int ldm, ldo;                             // row pitches (elements) of match / of the max-alpha table (>= L)
 };
 
 constexpr int MW_NT = 256;
@@ -112,9 +113,10 @@ __device__ __forceinline__ void maxstripw_body(const MWParams& p, char* smem_raw
     const int T = p.T, L = p.L, TR = p.TR;
     const int j0 = s * W;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
-    const float* M = p.match + (size_t)b * T * L;
+    const float* M = p.match + (size_t)b * T * p.ldm;
     const float* K = p.links + (size_t)b * L * TR;
-    float* O = p.alpha + (size_t)b * T * L;
+    float* O = p.alpha + (size_t)b * T * p.ldo;
+    const int LDO = p.ldo;
     const int nrows = Tb;
     const bool has_producer = so > 0;
     const bool has_consumer = s < p.NS - 1 && j0 + W < Lb;
@@ -218,18 +220,18 @@ __device__ __forceinline__ void maxstripw_body(const MWParams& p, char* smem_raw
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 Abuf[cur * RL + TRP + CPL * l + c] = a[c];
-                if (j + c < L) O[(size_t)t * L + j + c] = a[c];
+                if (j + c < L) O[(size_t)t * LDO + j + c] = a[c];
             }
             mw_barrier();
         }
         if (col_ok) for (int t = Tb; t < T; ++t) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) if (j + c < L) O[(size_t)t * L + j + c] = NEG_INF;
+            for (int c = 0; c < CPL; ++c) if (j + c < L) O[(size_t)t * LDO + j + c] = NEG_INF;
         }
     } else if (wave == NCW) {
         // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA, 4 bytes per lane)
         auto issue_row = [&](int itr) {
-            const float* rowp = M + (size_t)itr * L;
+            const float* rowp = M + (size_t)itr * p.ldm;
             float* slot = Mring + (size_t)(itr % MW_RING) * W;
 #pragma unroll
             for (int i = 0; i < W / 64; ++i) {
@@ -336,9 +338,9 @@ __global__ __launch_bounds__(MW_NT + 192) void dag_maxstripw_kernel(MWParams p)
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
     if (!valid || j0 >= Lb) {
-        float* O = p.alpha + (size_t)b * T * L;
+        float* O = p.alpha + (size_t)b * T * p.ldo;
         for (int jj = j0 + tid; jj < j0 + W && jj < L; jj += MW_NT + 192)
-            for (int t = 0; t < T; ++t) O[(size_t)t * L + jj] = NEG_INF;
+            for (int t = 0; t < T; ++t) O[(size_t)t * p.ldo + jj] = NEG_INF;
         return;
     }
     maxstripw_body<CPL>(p, smem_raw + 16, b, s, so);
@@ -347,14 +349,14 @@ __global__ __launch_bounds__(MW_NT + 192) void dag_maxstripw_kernel(MWParams p)
 // ---- back-trace over a window of up to 128 predecessors: one wave per sample -------------------------------------------------------------
 __global__ __launch_bounds__(64) void dag_backtrace_wide_kernel(
     const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len, const int64_t* __restrict__ tgt_len,
-    int64_t* __restrict__ path, int B, int T, int L, int TR)
+    int64_t* __restrict__ path, int B, int T, int L, int TR, int LDA)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t bw_lp[];       // [L] path image
     const int b = blockIdx.x, lane = threadIdx.x;
     for (int jj = lane; jj < L; jj += 64) bw_lp[jj] = -1;
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
-    const float* A = amax + (size_t)b * T * L;
+    const float* A = amax + (size_t)b * T * LDA;
     const float* K = links + (size_t)b * L * TR;
     __syncthreads();
     if (valid) {
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(64) void dag_backtrace_wide_kernel(
             // candidates: predecessor pos - 1 - d at distance d + 1, d = lane and lane + 64
             float x0 = NEG_INF, x1 = NEG_INF;
             const int i0 = pos - 1 - lane, i1 = pos - 65 - lane;
-            if (lane < TR && i0 >= 0) x0 = A[(size_t)(t - 1) * L + i0] + K[(size_t)i0 * TR + lane];
-            if (lane + 64 < TR && i1 >= 0) x1 = A[(size_t)(t - 1) * L + i1] + K[(size_t)i1 * TR + lane + 64];
+            if (lane < TR && i0 >= 0) x0 = A[(size_t)(t - 1) * LDA + i0] + K[(size_t)i0 * TR + lane];
+            if (lane + 64 < TR && i1 >= 0) x1 = A[(size_t)(t - 1) * LDA + i1] + K[(size_t)i1 * TR + lane + 64];
             float mx = fmaxf(x0, x1);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -410,16 +412,16 @@ static int launch_mw(MWParams& p, int B, int T, int L, hipStream_t st)
 
 // alpha_max by column strips (values only), then the wide back-trace: no trace tensor
 int launch_dag_maxstripw(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                         float* alpha_max, int64_t* path, int B, int T, int L, int TR, hipStream_t st)
+                         float* alpha_max, int64_t* path, int B, int T, int L, int TR, int ldm, int ldo, hipStream_t st)
 {
     MWParams p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha_max;
-    p.B = B; p.T = T; p.L = L; p.TR = TR;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.ldm = ldm; p.ldo = ldo;
     int rc = TR <= 64 ? launch_mw<2>(p, B, T, L, st) : launch_mw<1>(p, B, T, L, st);
     if (rc) return rc;
     const size_t lds = (size_t)L * 4;
     (void)hipFuncSetAttribute((const void*)dag_backtrace_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dag_backtrace_wide_kernel, dim3(B), dim3(64), lds, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR);
+    hipLaunchKernelGGL(dag_backtrace_wide_kernel, dim3(B), dim3(64), lds, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR, ldo);
     return check_launch("dag_best_alignment(wide back-trace)");
 }
 

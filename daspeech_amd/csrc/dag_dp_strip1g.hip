@@ -84,6 +84,7 @@ struct H1Params {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word, counters[2] = exact-path cells
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
+    int ldm, ldo;                             // row pitches (elements) of match and of alpha / beta (>= L; pad columns L .. round4(L)-1 of alpha / beta get -inf)
 };
 
 constexpr int H1_NT = 256;                    // compute lanes = columns per strip
@@ -129,9 +130,10 @@ __device__ __forceinline__ void strip1g_body(const H1Params& p, char* smem_raw, 
     const int T = p.T, L = p.L, TR = p.TR;
     const int j0 = s * W;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
-    const float* M = p.match + (size_t)b * T * L;
+    const float* M = p.match + (size_t)b * T * p.ldm;
     const float* K = p.links + (size_t)b * L * TR;
-    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * L;
+    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
+    const int LDO = p.ldo, LPAD = min(p.ldo, (L + 3) & ~3);
     const int nrows = Tb;
 
     const bool has_producer = so > 0 && (BETA ? (j0 + W < Lb) : true);
@@ -347,15 +349,21 @@ __device__ __forceinline__ void strip1g_body(const H1Params& p, char* smem_raw, 
             Vbuf[cur * RL + own_li0 + l] = vn;
             if (par == 0) Xbuf[cur * GL + (own_li0 >> 2) + (l >> 2)] = xn;
             Abuf[cur * RL + own_li0 + l] = a2;
-            if (col_ok) O[(size_t)t * L + j] = a2 * H1_LN2;
+            if (col_ok) {
+                O[(size_t)t * LDO + j] = a2 * H1_LN2;
+                if (j + 1 == L) for (int c = L; c < LPAD; ++c) O[(size_t)t * LDO + c] = NEG_INF;         // the owner of the last column fills the pitch padding
+            }
             h1_barrier();
         }
-        if (col_ok) for (int t = Tb; t < T; ++t) O[(size_t)t * L + j] = NEG_INF;       // rows the recurrence never reaches
+        if (col_ok) for (int t = Tb; t < T; ++t) {                                      // rows the recurrence never reaches
+            O[(size_t)t * LDO + j] = NEG_INF;
+            if (j + 1 == L) for (int c = L; c < LPAD; ++c) O[(size_t)t * LDO + c] = NEG_INF;
+        }
     } else if (wave == NCW) {
         // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA, 4 bytes per lane)
         auto issue_row = [&](int itr) {
             const int t = BETA ? (Tb - 1 - itr) : itr;
-            const float* rowp = M + (size_t)t * L;
+            const float* rowp = M + (size_t)t * p.ldm;
             float* slot = Mring + (size_t)(itr % H1_RING) * W;
 #pragma unroll
             for (int i = 0; i < W / 64; ++i) {
@@ -463,9 +471,10 @@ __global__ __launch_bounds__(H1_NT + 192) void dag_strip1g_kernel(H1Params p)
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
     if (!valid || j0 >= Lb) {                    // nothing reachable in this strip: -inf everywhere, no hand-off
-        float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * L;
-        for (int jj = j0 + tid; jj < j0 + H1_W && jj < L; jj += H1_NT + 192)
-            for (int t = 0; t < T; ++t) O[(size_t)t * L + jj] = NEG_INF;
+        float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
+        const int lpad = min(p.ldo, (L + 3) & ~3);
+        for (int jj = j0 + tid; jj < j0 + H1_W && jj < lpad; jj += H1_NT + 192)
+            for (int t = 0; t < T; ++t) O[(size_t)t * p.ldo + jj] = NEG_INF;
         return;
     }
     if (is_beta) strip1g_body<true>(p, smem_raw + 16, b, s, dirslot, so);
@@ -479,13 +488,13 @@ bool strip1g_supported(int L, int TR) { return TR > 64 && TR <= H1_TRP && L >= 1
 size_t strip1g_ws_bytes(int B, int T, int L, int ndir) { return 256 + (size_t)ndir * B * ((L + H1_W - 1) / H1_W) * T * H1_TRP * sizeof(u64); }
 
 int launch_dag_strip1g(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
+                       float* alpha, float* beta, int B, int T, int L, int TR, int ldm, int ldo, hipStream_t st)
 {
     const int ndir = (alpha && beta) ? 2 : 1;
     const int NS = (L + H1_W - 1) / H1_W;
     H1Params p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha; p.beta = beta;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.ldm = ldm; p.ldo = ldo;
     const size_t halo_bytes = (size_t)ndir * B * NS * T * H1_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;

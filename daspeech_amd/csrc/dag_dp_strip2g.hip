@@ -32,6 +32,7 @@ struct H2Params {
     u64* halo; u32* counters;                 // counters[0] = ticket, counters[1] = error word, counters[2] = exact-path cells
     u32 tag_base;
     int B, T, L, TR, NS, ndir;
+    int ldm, ldo;                             // row pitches (elements) of match and of alpha / beta (r06: >= L; the pad columns L .. round4(L)-1 of alpha / beta get -inf)
 };
 
 constexpr int H2_NT = 256;                    // compute lanes
@@ -74,9 +75,10 @@ __device__ __forceinline__ void strip2g_body(const H2Params& p, char* smem_raw, 
     const int T = p.T, L = p.L, TR = p.TR;
     const int j0 = s * W;
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
-    const float* M = p.match + (size_t)b * T * L;
+    const float* M = p.match + (size_t)b * T * p.ldm;
     const float* K = p.links + (size_t)b * L * TR;
-    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * L;
+    float* O = (BETA ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
+    const int LDO = p.ldo, LPAD = min(p.ldo, (L + 3) & ~3);
     const int nrows = Tb;
 
     const bool has_producer = so > 0 && (BETA ? (j0 + W < Lb) : true);
@@ -342,22 +344,24 @@ __device__ __forceinline__ void strip2g_body(const H2Params& p, char* smem_raw, 
             if (!par) Xbuf[cur * GL + (own_li0 >> 2) + (l >> 1)] = xn;
             *reinterpret_cast<float2*>(Abuf + cur * RL + own_li0 + 2 * l) = make_float2(a2[0], a2[1]);
             if (col_ok) {
-                if (j + 1 < L) { O[(size_t)t * L + j] = a2[0] * H2_LN2; O[(size_t)t * L + j + 1] = a2[1] * H2_LN2; }
-                else O[(size_t)t * L + j] = a2[0] * H2_LN2;
+                if (j + 1 < L) { O[(size_t)t * LDO + j] = a2[0] * H2_LN2; O[(size_t)t * LDO + j + 1] = a2[1] * H2_LN2; }
+                else O[(size_t)t * LDO + j] = a2[0] * H2_LN2;
+                if (j + 2 >= L) for (int c = L; c < LPAD; ++c) O[(size_t)t * LDO + c] = NEG_INF;       // the owner of the last column fills the pitch padding
             }
             h2_barrier();
         }
         // rows the recurrence never reaches
         if (col_ok) for (int t = Tb; t < T; ++t) {
-            O[(size_t)t * L + j] = NEG_INF;
-            if (j + 1 < L) O[(size_t)t * L + j + 1] = NEG_INF;
+            O[(size_t)t * LDO + j] = NEG_INF;
+            if (j + 1 < L) O[(size_t)t * LDO + j + 1] = NEG_INF;
+            if (j + 2 >= L) for (int c = L; c < LPAD; ++c) O[(size_t)t * LDO + c] = NEG_INF;
         }
     } else if (wave == NCW) {
         // =========================================================== loader wave: match rows -> LDS ring (LDS-DMA, 4 bytes per lane: rows
         // of a dense tensor are not 16-byte aligned in general)
         auto issue_row = [&](int itr) {
             const int t = BETA ? (Tb - 1 - itr) : itr;
-            const float* rowp = M + (size_t)t * L;
+            const float* rowp = M + (size_t)t * p.ldm;
             float* slot = Mring + (size_t)(itr % H2_RING) * W;
 #pragma unroll
             for (int i = 0; i < W / 64; ++i) {
@@ -474,9 +478,10 @@ __global__ __launch_bounds__(H2_NT + 192) void dag_strip2g_kernel(H2Params p)
     const int Lb = (int)p.out_len[b], Tb = (int)p.tgt_len[b];
     const bool valid = !(Tb <= 0 || Lb <= 0 || Tb > T || Lb > L);
     if (!valid || j0 >= Lb) {                    // nothing reachable in this strip: -inf everywhere, no hand-off
-        float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * L;
-        for (int jj = j0 + tid; jj < j0 + H2_W && jj < L; jj += H2_NT + 192)
-            for (int t = 0; t < T; ++t) O[(size_t)t * L + jj] = NEG_INF;
+        float* O = (is_beta ? p.beta : p.alpha) + (size_t)b * T * p.ldo;
+        const int lpad = min(p.ldo, (L + 3) & ~3);
+        for (int jj = j0 + tid; jj < j0 + H2_W && jj < lpad; jj += H2_NT + 192)
+            for (int t = 0; t < T; ++t) O[(size_t)t * p.ldo + jj] = NEG_INF;
         return;
     }
     __syncthreads();                             // everyone has read the ticket before the tile overlays it
@@ -490,13 +495,13 @@ int banded_acquire_ws(hipStream_t st, size_t halo_bytes, int T, u32** counters, 
 bool strip2g_supported(int L, int TR) { return TR > 32 && TR <= H2_TRP && L >= 1; }
 
 int launch_dag_strip2g(const float* match, const float* links, const int64_t* out_len, const int64_t* tgt_len,
-                       float* alpha, float* beta, int B, int T, int L, int TR, hipStream_t st)
+                       float* alpha, float* beta, int B, int T, int L, int TR, int ldm, int ldo, hipStream_t st)
 {
     const int ndir = (alpha && beta) ? 2 : 1;
     const int NS = (L + H2_W - 1) / H2_W;
     H2Params p;
     p.match = match; p.links = links; p.out_len = out_len; p.tgt_len = tgt_len; p.alpha = alpha; p.beta = beta;
-    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir;
+    p.B = B; p.T = T; p.L = L; p.TR = TR; p.NS = NS; p.ndir = ndir; p.ldm = ldm; p.ldo = ldo;
     const size_t halo_bytes = (size_t)ndir * B * NS * T * H2_TRP * sizeof(u64);
     int rc = banded_acquire_ws(st, halo_bytes, T, &p.counters, &p.halo, &p.tag_base);
     if (rc) return rc;

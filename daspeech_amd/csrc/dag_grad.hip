@@ -2,6 +2,7 @@
 // Replaces calculate_grad_match_all_kernel (dag_loss.cu:378-401) and calculate_grad_links_kernel (:432-485).
 #include "common.h"
 #include <atomic>
+#include <cmath>
 #include <stdlib.h>
 
 namespace dsp {
@@ -182,6 +183,11 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     float* __restrict__ g_links, const float* __restrict__ match, float* __restrict__ g_match, int B, int T, int L, int TR,
     int LDA, int LDM, int LDG, int remap)        // row pitches (elements) of alpha / beta, match, grad_match: multiples of 4, >= L rounded up to 4
 {
+    // r06: windows 33 .. 128 run the SAME kernel with gridDim.y = ceil(TR / 32): the workgroups of plane y own transitions S .. S+31, S = 32 y, and
+    // read beta S columns to the right (a 128-byte shift keeps every 16-byte granule aligned); TR stays the row stride of links / grad_links.
+    // grad_match is written by plane 0 only (fz).
+    const int S = 32 * (int)blockIdx.y;
+    const bool fz = FUSE && S == 0;
     extern __shared__ __attribute__((aligned(16))) char gx_smem[];
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int GX_WAVE_WORDS = gx_wave_words(GX_TC, FUSE && !MREG);
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     const int Lb = (int)out_len[b], Tb = (int)tgt_len[b];
     const float* A = alpha + (size_t)b * T * LDA;
     const float* Bp = beta + (size_t)b * T * LDA;
+    const float* Bs = Bp + S;                                    // window rows: column q of this launch is graph column q + S
     const float b00 = Bp[0];
     const bool dead = isinf(b00) || Tb > T || Lb > L || Tb < 1 || Lb < 1;
     const float b00_2 = b00 * LOG2E;
@@ -233,24 +240,24 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     float4 carry = zero4;                                        // beta[tb][own vertices]: the last beta row of the previous pass
 #pragma unroll
     for (int r = 0; r < GX_TC; ++r) rm[r] = zero4;
-    if (FUSE && tlo < thi && v0 < L) carry = *reinterpret_cast<const float4*>(Bp + (size_t)tlo * LDA + v0);
+    if (FUSE && fz && tlo < thi && v0 < L) carry = *reinterpret_cast<const float4*>(Bp + (size_t)tlo * LDA + v0);
     auto request = [&](int tb0) {
         const int nr = min(GX_TC, thi - tb0);
-        if (FUSE && MREG) {
+        if (FUSE && MREG && fz) {
 #pragma unroll
             for (int r = 0; r < GX_TC; ++r)
                 if (r < nr && v0 < L) rm[r] = *reinterpret_cast<const float4*>(Mp + (size_t)(tb0 + r) * LDM + v0);
         }
         for (int r = 0; r < nr; ++r) {
-            const float* brow = Bp + (size_t)(tb0 + r + 1) * LDA;
+            const float* brow = Bs + (size_t)(tb0 + r + 1) * LDA;
             const int c0 = i0 + 4 * lane, c1 = i0 + 256 + 4 * lane;
-            if (FUSE && !MREG)
+            if (FUSE && !MREG && fz)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Mp + (size_t)(tb0 + r) * LDM + (c0 < L ? c0 : 0)),
                                                  (__attribute__((address_space(3))) void*)(Mraw + r * 256), 16, 0, AUX);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c0 < L ? c0 : 0)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c0 + S < L ? c0 : 0)),
                                              (__attribute__((address_space(3))) void*)(Braw + r * GX_P), 16, 0, AUX);
             if (lane < 9)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c1 < L ? c1 : 0)),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow + (c1 + S < L ? c1 : 0)),
                                                  (__attribute__((address_space(3))) void*)(Braw + r * GX_P + 256), 16, 0, AUX);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)(tb0 + r) * LDA + (c0 < L ? c0 : 0)),
                                              (__attribute__((address_space(3))) void*)(Araw + r * 256), 16, 0, AUX);
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             if (FUSE && !MREG) rm[r] = *reinterpret_cast<const float4*>(Mraw + r * 256 + 4 * lane);
         }
         const float4 rbh = *reinterpret_cast<const float4*>(Braw + hr * GX_P + 4 * hg);
-        if (FUSE) {
+        if (FUSE && fz) {
             // grad_match rows tb .. tb+rows-1: alpha[t] = ra[r], beta[t] = the previous row's rb0 (row tb: carried from the last pass)
 #pragma unroll
             for (int r = 0; r < GX_TC; ++r) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
                 Xq[r * GX_G + g] = (gd | !live) ? GX_NEG : (int)cf;
             }
         };
-        const bool live_own = i0 + 4 * lane < L, live_halo = i0 + 4 * hg < L;
+        const bool live_own = i0 + 4 * lane + S < L, live_halo = i0 + 4 * hg + S < L;
         const float pen_own = live_own ? 0.f : __builtin_huge_valf(), pen_halo = live_halo ? 0.f : __builtin_huge_valf();
 #pragma unroll
         for (int r = 0; r < GX_TC; ++r) {
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             else acc[c][d] = d == 0 ? accP[c][15].x : (d == 31 ? accP[c][15].y : ((d & 1) ? accP[c][(d - 1) >> 1].x : accP[c][(d - 1) >> 1].y));
         }
     }
-    if (FUSE && v0 < L) {
+    if (FUSE && fz && v0 < L) {
         // rows T_b-1 .. T-1 (and every row of a dead sample): no transition term, K4 alone — streamed, four rows in flight per wave
         for (int t = nt + wave; t < T; t += 16) {
             float4 a4[4], b4[4], m4[4];
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
         float e2[32]; bool okd[32]; bool weak = false;
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
-            okd[d] = !dead && d < TR && vi < Lb && vi + d + 1 < Lb;                                  // dag_loss.cu:461-466
-            e2[d] = okd[d] ? links[((size_t)b * L + vi) * TR + d] * LOG2E : NEG_INF;
+            okd[d] = !dead && S + d < TR && vi < Lb && vi + S + d + 1 < Lb;                          // dag_loss.cu:461-466
+            e2[d] = okd[d] ? links[((size_t)b * L + vi) * TR + S + d] * LOG2E : NEG_INF;
             weak |= okd[d] & (e2[d] != NEG_INF) & (e2[d] < -100.f);
         }
         float s[32];
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
                 const float a = A[(size_t)t * LDA + vi] * LOG2E - b00_2;
 #pragma unroll
                 for (int d = 0; d < 32; ++d)
-                    if (okd[d]) s[d] += __builtin_amdgcn_exp2f(a + Bp[(size_t)(t + 1) * LDA + vi + d + 1] * LOG2E + e2[d]);
+                    if (okd[d]) s[d] += __builtin_amdgcn_exp2f(a + Bs[(size_t)(t + 1) * LDA + vi + d + 1] * LOG2E + e2[d]);
             }
 #pragma unroll
             for (int d = 0; d < 32; ++d) s[d] = okd[d] ? s[d] * go : 0.f;
@@ -499,13 +506,13 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
                 s[d] += red[(0 * 64 + lane) * 33 + d] + red[(1 * 64 + lane) * 33 + d] + red[(2 * 64 + lane) * 33 + d];
             }
             if (vi < L) {
-                float* out = g_links + ((size_t)b * L + vi) * TR;
-                if (TR == 32) {
+                float* out = g_links + ((size_t)b * L + vi) * TR + S;
+                if (TR - S >= 32 && (TR & 3) == 0) {
 #pragma unroll
                     for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(out + d) = make_float4(s[d], s[d + 1], s[d + 2], s[d + 3]);
                 } else {
 #pragma unroll
-                    for (int d = 0; d < 32; ++d) if (d < TR) out[d] = s[d];
+                    for (int d = 0; d < 32; ++d) if (S + d < TR) out[d] = s[d];
                 }
             }
         }
@@ -543,7 +550,7 @@ static int launch_gx(const float* g_out, const float* alpha, const float* beta, 
     auto kern = dag_grad_links_exp_kernel<TC, FUSE, MREG, AUX>;
     static const char* const e_rm = getenv("DSP_GX_REMAP");
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(((L + 255) / 256) * B), dim3(256), lds, st,
+    hipLaunchKernelGGL(kern, dim3(((L + 255) / 256) * B, (TR + 31) / 32), dim3(256), lds, st,
                        g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR, lda, ldm, ldg, e_rm ? 1 : 0);
     return check_launch(FUSE ? "dag_loss_bwd(grad_match + grad_links, exp space, one launch)" : "dag_loss_bwd(grad_links, exp space)");
 }
@@ -556,9 +563,39 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
     // are multiples of 4 and cover L rounded up to 4 — the columns past L hold -inf in alpha / beta, as the strip kernels leave them); every
     // other family takes dense tensors only.
     const int L4 = (L + 3) & ~3;
-    const bool expk = TR <= 32 && (lda & 3) == 0 && lda >= L4 && ((((uintptr_t)alpha) | ((uintptr_t)beta) | ((uintptr_t)g_links)) & 15) == 0;
+    const bool rows16 = (lda & 3) == 0 && lda >= L4 && ((((uintptr_t)alpha) | ((uintptr_t)beta) | ((uintptr_t)g_links)) & 15) == 0;
+    const bool expk = TR <= 32 && rows16;
     const bool pitched_m = (ldm & 3) == 0 && ldm >= L4 && (ldg & 3) == 0 && ldg >= L4;
     const int fuse = g_k5_fuse.load();
+    // windows 33 .. 128 (r06): the TR <= 32 kernel with one plane of workgroups per block of 32 transitions (gridDim.y) — plane k reads beta 32 k
+    // columns to the right and owns slots 32 k .. 32 k + 31 of links / grad_links, plane 0 writes grad_match too.  ONE launch (k5_last 6).
+    // C2 at TR = 64 / 96 / 128: 0.92 / 1.23 / 1.52 ms (grad_match pass + tiled log-space kernel) -> 0.46 / 0.70 / 0.89 ms.  Its cost is a latency
+    // chain per wave (~55 us + 0.2-0.3 us per target row, per round of 512 resident workgroups), the tiled kernel's is proportional to the terms
+    // (~5e12 / s): auto takes the cheaper estimate; k5_path 3 pins the planes, 1 / 2 the tiled kernel / the dense block products.
+    if (g_links && TR > 32 && TR <= 128 && rows16 && (g_k5_path == 0 || g_k5_path == 3)) {
+        const double planes = (TR + 31) / 32, nwg = (double)((L + 255) / 256) * B * planes;
+        const double est_planes = std::ceil(nwg / 512.0) * (55.0 + (nwg <= 256 ? 0.20 : 0.30) * T);      // fitted on ten shapes, profiles/r06_bwd_windows_33_128.txt
+        const double est_tiled = 45.0 + (double)B * T * L * TR / 5.2e6;
+        if (g_k5_path == 3 || est_planes < est_tiled) {
+            const bool fa = g_match && pitched_m && fuse != 3 && ((((uintptr_t)match) | ((uintptr_t)g_match)) & 15) == 0;
+            int rc;
+            if (fa) {
+                rc = launch_gx<3, true, false, 2>(g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR, lda, ldm, ldg, st);
+            } else {
+                if (g_match) {
+                    const size_t TL = (size_t)T * L;
+                    int gx = (int)((TL / 4 + 255) / 256); if (gx < 1) gx = 1; if (gx > 1024) gx = 1024;
+                    hipLaunchKernelGGL(dag_grad_match_kernel, dim3(gx, B), dim3(256), 0, st, g_out, alpha, beta, match, g_match, B, T, L, lda, ldm, ldg);
+                    rc = check_launch("dag_loss_bwd(grad_match)");
+                    if (rc) return rc;
+                }
+                rc = launch_gx<4, false, false>(g_out, alpha, beta, links, out_len, tgt_len, g_links, nullptr, nullptr, B, T, L, TR, lda, lda, lda, st);
+            }
+            if (rc) return rc;
+            g_k5_last = 6u;
+            return DSP_OK;
+        }
+    }
     // both gradients of a banded graph: ONE launch reads alpha / beta / match once (k5_last 4 / 5)
     if (g_match && g_links && expk && pitched_m && g_k5_path != 1 && fuse != 3 && ((((uintptr_t)match) | ((uintptr_t)g_match)) & 15) == 0) {
         // measured at C2 (r06, us per launch): default cache policy + XCD-contiguous tiles 285, nt 276, round-robin tiles 269, round-robin + nt 257
@@ -591,7 +628,8 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
         int rc = check_launch("dag_loss_bwd(grad_links)");
         if (rc) return rc;
         g_k5_last = 1u;
-    } else if (g_links && g_k5_path != 1 && grad_dense_supported(L, TR)) {
+    } else if (g_links && g_k5_path != 1 && (TR > 128 || g_k5_path == 2) && grad_dense_supported(L, TR)) {
+        // (auto keeps the tiled kernel up to TR = 128: 1.23 vs 1.86 ms at C2 / TR = 96, 1.52 vs 1.58 at 128, 0.23 vs 0.31 at T = 64 — r06)
         // dense window: block products over the target axis on the f32 matrix cores (dag_grad_dense.hip).  Half of the compact
         // [L][TR] layout addresses vertices past the graph (i + d + 1 >= L): zeros, as the reference's at::zeros leaves them.
         hipError_t e = hipMemsetAsync(g_links, 0, (size_t)B * L * TR * sizeof(float), st);

@@ -84,7 +84,7 @@ def _workspace(dev: torch.device, nbytes: int) -> Tensor:
     return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
 
 
-# The banded fast paths (TR <= 32: exp-space strips, values-only max-DP, fused gradients) read rows with 16-byte loads.  A graph length is
+# The banded fast paths (exp-space strips, values-only max-DP, fused gradients; windows <= 128) read rows with 16-byte loads.  A graph length is
 # floor(src_upsample * frames) — any integer; three graphs in four are not a multiple of 4.  r05 padded such inputs to the next multiple with
 # F.pad copies of match / links and cut alpha / beta / the gradients back (~4 extra passes over [B,T,L]).  r06: the C ABI takes a ROW PITCH
 # (dsp_dag_loss_fwd_ld & co.), dag_logsoftmax_gather_inplace writes `match` with a pitch rounded up to 4, alpha / beta / grad_match are
@@ -134,7 +134,7 @@ def _as_pitched(match_all: Tensor):
 
 
 def _dag_forward(match_all, links, output_length, target_length, need_beta: bool):
-    """-> (m, k, ol, tl, alpha, beta, loss, (ld_match, ld_ab)); alpha / beta are [B,T,L] (views of pitched buffers when TR <= 32)."""
+    """-> (m, k, ol, tl, alpha, beta, loss, (ld_match, ld_ab)); alpha / beta are [B,T,L] (views of pitched buffers on the strip kernels: windows <= 128)."""
     dev = _require_gpu("dag_loss", match_all, links, output_length, target_length)
     B, T, L, TR = _check_dp_args("dag_loss", match_all, links, output_length, target_length)
     if match_all.dtype == torch.float64 or links.dtype == torch.float64:
@@ -173,7 +173,7 @@ def _dag_backward(grad_output, alpha, beta, m, k, ol, tl, need_match: bool, need
         go = grad_output.detach().to(torch.float32).contiguous()
         gm, ldg = None, L
         if need_match:
-            if lda != L or (TR <= 32 and lda % 4 == 0):          # (TR <= 32: the fused gradient kernel wants 16-byte rows for grad_match too)
+            if lda != L or lda % 4 == 0:                         # (the fused gradient kernel wants 16-byte rows for grad_match too)
                 gm, ldg = _pitched_empty(B, T, L, dev), _round4(L)
             else:
                 gm = torch.empty((B, T, L), dtype=torch.float32, device=dev)

@@ -195,7 +195,9 @@ int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace
  *   strips / the dense-window kernels),
  *   9 = dense-window blocked products on the f32 matrix cores (the auto choice for TR > 64); used by tests to
  *   cross-check the families.  "k5_path": 0 = auto, 1 = tiled log-space grad_links kernel, 2 = exp-space (TR <= 32) / block products
- *   (TR > 64).  "k5_fuse" 0|1|2|3 (r06): dsp_dag_loss_bwd on a banded graph (TR <= 32) asked for BOTH gradients — 0 = auto (2), 1 / 2 = ONE
+ *   (TR > 64).  Windows 33 .. 128 with 16-byte aligned rows (r06): the TR <= 32 kernel with one plane of workgroups per block of 32 transitions, beta
+ *   read 32 k columns to the right (family 6) — 3 pins it, auto takes it where its estimated cost is under the tiled kernel's (long target axes);
+ *   the block products are the auto choice above 128 only.  "k5_fuse" 0|1|2|3 (r06): dsp_dag_loss_bwd on a banded graph (TR <= 32) asked for BOTH gradients — 0 = auto (2), 1 / 2 = ONE
  *   launch writes grad_match and grad_links (alpha, beta, match read once; match rows prefetched into registers with 4-row passes / by
  *   LDS-DMA with 3-row passes), 3 = the two launches of r01-r05 (K4, then K5); the three are bit-identical.  "dm_mt" 1|2: rows per chunk of the dense kernel in MFMA row tiles (default 2 = 32 rows), "dm_depth" 1|2: its register
  *   stages in flight with dm_mt 1 (9 with dm_mt 2: the one-workgroup-per-CU build), "force_generic", "dm_*" affect speed only.
@@ -218,7 +220,7 @@ int dsp_dag_backtrace_blocks(const float* alpha_max, const uint16_t* block_trace
 int dsp_dag_alignment_trace_optional(int L, int TR);
 /* diagnostics of the grad_links kernels since the last call: out4 = {lanes redone exactly, unsafe factor, weak link (exp-space kernel),
  * family of the last grad_links launch: 1 tiled log space, 2 exp space, 3 dense block products, 4 / 5 exp space fused with grad_match
- * (k5_fuse 1 / 2), 0 none} */
+ * (k5_fuse 1 / 2), 6 exp space, a plane of workgroups per 32 transitions (windows 33 .. 128), 0 none} */
 int dsp_dag_debug_k5(unsigned int* out4);
 int dsp_dag_set_option(const char* name, int value);
 int dsp_dag_last_launch_status(dsp_stream_t stream, unsigned int* host_word);

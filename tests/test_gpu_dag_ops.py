@@ -572,7 +572,7 @@ def test_dense_grad_links_block_products_match_oracle(shape, weak):
         links = np.where(np.isfinite(links), links + (rng.integers(0, 6, links.shape) == 0) * -90.0, links).astype(np.float32)
     res = {}
     try:
-        for k5 in (0, 1):
+        for k5 in (0, 1, 2):
             _lib.set_option("k5_path", k5)
             m, k, o, t = to_dev(match, links, ol, tl)
             m.requires_grad_(); k.requires_grad_()
@@ -581,7 +581,9 @@ def test_dense_grad_links_block_products_match_oracle(shape, weak):
             gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
             assert _lib.last_launch_status() == 0
             diag = (ctypes.c_uint * 4)(); _lib.load().dsp_dag_debug_k5(diag)
-            assert diag[3] == (1 if k5 == 1 else 3), (k5, diag[3])          # 1 = the tiled log-space kernel really ran when pinned
+            # 1 = the tiled log-space kernel really ran when pinned
+            want = (1,) if k5 == 1 else ((3,) if (k5 == 2 or TR > 128) else (1, 6))      # auto up to 128: tiled or the planes, by estimated cost
+            assert diag[3] in want, (k5, diag[3])
             res[k5] = (gm.cpu().numpy(), gl.cpu().numpy())
     finally:
         _lib.set_option("k5_path", 0)
@@ -592,6 +594,53 @@ def test_dense_grad_links_block_products_match_oracle(shape, weak):
     outside = (i + d + 1) >= ol[:, None, None]
     for k5, (gm_, gl_) in res.items():
         assert np.isfinite(gl_).all(), k5
+        assert (gl_[outside] == 0).all(), k5
+        np.testing.assert_allclose(gl_, gl64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
+        np.testing.assert_allclose(gm_, gm64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
+
+
+@pytest.mark.parametrize("weak", [False, True])
+@pytest.mark.parametrize("shape", [(3, 30, 300, 33), (2, 25, 520, 64), (2, 40, 392, 48), (2, 20, 500, 100), (2, 33, 1028, 128), (3, 17, 260, 97),
+                                   (2, 12, 264, 65), (2, 9, 128, 127), (2, 21, 390, 48), (2, 14, 301, 100)])
+def test_windows_33_to_128_backward_in_blocks_of_32_transitions(shape, weak):
+    """r06: dag_loss backward on windows 33 .. 128 = the TR <= 32 exp-space kernel with one plane of workgroups per block of 32 transitions
+    (gridDim.y), beta read 32 k columns to the right, plane 0 fused with grad_match (family 6, pinned with k5_path 3; rows sit on 16-byte
+    boundaries: graph lengths off the grid run with a row pitch, as on the narrow windows).  Against the fp64 oracle and the tiled log-space kernel: ragged
+    lengths, -inf emissions, transitions ~2^-130 (weak: the exact redo inside every block), entries past the graph exactly zero
+    (dag_loss.cu:461-466, 493)."""
+    from daspeech_amd import _lib
+    import ctypes
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(23 + L + TR, B, T, L, TR)
+    rng = np.random.default_rng(L + TR)
+    match[rng.random(match.shape) < 0.08] = -np.inf
+    if weak:
+        links = np.where(np.isfinite(links), links + (rng.integers(0, 6, links.shape) == 0) * -90.0, links).astype(np.float32)
+    res = {}
+    try:
+        for k5 in (3, 1, 0):
+            _lib.set_option("k5_path", k5)
+            m, k, o, t = to_dev(match, links, ol, tl)
+            m.requires_grad_(); k.requires_grad_()
+            loss = ops().dag_loss(m, k, o, t)
+            fin = torch.isfinite(loss)
+            gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
+            assert _lib.last_launch_status() == 0
+            diag = (ctypes.c_uint * 4)(); _lib.load().dsp_dag_debug_k5(diag)
+            want = (1,) if k5 == 1 else ((6,) if k5 == 3 else (1, 6))                  # auto: the cheaper estimate of the two
+            assert diag[3] in want, (k5, diag[3])
+            if k5 == 3 and weak:
+                assert diag[2] > 0                           # the weak-transition redo really ran
+            res[k5] = (gm.cpu().numpy(), gl.cpu().numpy())
+    finally:
+        _lib.set_option("k5_path", 0)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
+    b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+    i = np.arange(L)[None, :, None]; d = np.arange(TR)[None, None, :]
+    outside = (i + d + 1) >= ol[:, None, None]
+    for k5, (gm_, gl_) in res.items():
+        assert np.isfinite(gl_).all() and np.isfinite(gm_).all(), k5
         assert (gl_[outside] == 0).all(), k5
         np.testing.assert_allclose(gl_, gl64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
         np.testing.assert_allclose(gm_, gm64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
@@ -1049,10 +1098,11 @@ def test_fused_backward_equals_the_two_launches(shape):
         assert not fin[2] and got[0][0][2].abs().max() == 0 and got[0][1][2].abs().max() == 0
 
 
-@pytest.mark.parametrize("shape", [(3, 24, 1023, 32), (2, 30, 518, 32), (2, 17, 261, 9), (3, 12, 97, 32), (1, 2, 5, 3), (2, 40, 1030, 20)])
+@pytest.mark.parametrize("shape", [(3, 24, 1023, 32), (2, 30, 518, 32), (2, 17, 261, 9), (3, 12, 97, 32), (1, 2, 5, 3), (2, 40, 1030, 20),
+                                   (2, 30, 517, 48), (2, 20, 1031, 100), (3, 12, 261, 64), (2, 9, 133, 128), (2, 16, 774, 33)])     # (windows 33 .. 128: r06)
 @pytest.mark.parametrize("source", ["gather", "dense"])
 def test_graph_lengths_off_the_16_byte_grid_run_pitched(shape, source):
-    """r06: graph lengths that are not multiples of 4 (three real graphs in four) reach the TR <= 32 strip kernels through ROW PITCHES
+    """r06: graph lengths that are not multiples of 4 (three real graphs in four) reach the strip kernels (windows <= 128) through ROW PITCHES
     (dsp_dag_loss_fwd_ld / _bwd_ld / dsp_dag_best_alignment_ld), not through F.pad copies: `match` straight from
     dag_logsoftmax_gather_inplace (written with the pitch) or a dense caller tensor (one copy into a pitched buffer).  Loss, alpha, beta, both
     gradients against the fp64 oracle; the Viterbi path bit-exact; the fast kernel families are the ones that ran."""
@@ -1084,7 +1134,7 @@ def test_graph_lengths_off_the_16_byte_grid_run_pitched(shape, source):
     gm, gl = torch.autograd.grad((loss.nan_to_num(neginf=0.0) * w).sum(), [m, k])
     torch.cuda.synchronize()
     _lib.load().dsp_dag_debug_k5(diag)
-    assert diag[3] == 5, "the fused exp-space gradient kernel ran (pitched rows), not the log-space fallback"
+    assert diag[3] == 5 or (TR > 32 and diag[3] in (1, 6)), "the fused exp-space gradient kernel ran (pitched rows), not the log-space fallback"
     assert gm.shape == (B, T, L) and gl.shape == (B, L, TR)
     a64 = orc.dag_alpha(match, links, ol, tl, np.float64)
     b64 = orc.dag_beta(match, links, ol, tl, np.float64)
