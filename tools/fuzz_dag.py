@@ -15,6 +15,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
 bad = 0
+if os.environ.get("DSP_FUZZ_K5"):                                  # pin the grad_links family (3 = the planes of windows 33 .. 128, which auto picks on long target axes only)
+    _lib.set_option("k5_path", int(os.environ["DSP_FUZZ_K5"]))
 for case in range(n):
     dense = len(sys.argv) > 3 and sys.argv[3] == "dense"          # dense windows (TR > 64: the matrix-core kernels and their stand-by path)
     if dense:
