@@ -3,6 +3,7 @@
 #include "common.h"
 #include <atomic>
 #include <cmath>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace dsp {
@@ -453,8 +454,10 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
     }
     // ---- transition weights; lanes with an unsafe factor or a transition under 2^-100 redo their sums term by term ----
     const float go = dead ? 0.f : g_out[b];
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
+    // (r06: both loops over the lane's four vertices are unrolled with a STATIC vertex index — as `#pragma unroll 1` loops every access to
+    //  acc[c][*] was a 4-way select chain, ~1 000 v_cndmask per vertex; the compiler barrier between the vertices keeps their live ranges apart)
+    auto scale_vertex = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
         const int vi = v0 + c;
         float e2[32]; bool okd[32]; bool weak = false;
 #pragma unroll
@@ -463,12 +466,10 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             e2[d] = okd[d] ? links[((size_t)b * L + vi) * TR + S + d] * LOG2E : NEG_INF;
             weak |= okd[d] & (e2[d] != NEG_INF) & (e2[d] < -100.f);
         }
-        float s[32];
-#pragma unroll
-        for (int d = 0; d < 32; ++d) s[d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
         if (__builtin_expect(bad | weak, 0)) {
             if (c == 0) { atomicAdd(&g_gx_diag[0], 1u); if (bad) atomicAdd(&g_gx_diag[1], 1u); if (weak) atomicAdd(&g_gx_diag[2], 1u); }
             // exact form of dag_loss.cu:471-475 over this wave's rows (the scaled sum is discarded)
+            float s[32];
 #pragma unroll
             for (int d = 0; d < 32; ++d) s[d] = 0.f;
             for (int t = tlo; t < thi; ++t) {
@@ -478,33 +479,31 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
                     if (okd[d]) s[d] += __builtin_amdgcn_exp2f(a + Bs[(size_t)(t + 1) * LDA + vi + d + 1] * LOG2E + e2[d]);
             }
 #pragma unroll
-            for (int d = 0; d < 32; ++d) s[d] = okd[d] ? s[d] * go : 0.f;
+            for (int d = 0; d < 32; ++d) acc[c][d] = okd[d] ? s[d] * go : 0.f;
         } else {
 #pragma unroll
-            for (int d = 0; d < 32; ++d) s[d] = okd[d] ? s[d] * __builtin_amdgcn_exp2f(e2[d]) * go : 0.f;
+            for (int d = 0; d < 32; ++d) acc[c][d] = okd[d] ? acc[c][d] * __builtin_amdgcn_exp2f(e2[d]) * go : 0.f;
         }
-#pragma unroll
-        for (int d = 0; d < 32; ++d) { if (c == 0) acc[0][d] = s[d]; else if (c == 1) acc[1][d] = s[d]; else if (c == 2) acc[2][d] = s[d]; else acc[3][d] = s[d]; }
-    }
+        asm volatile("" ::: "memory");
+    };
+    scale_vertex(std::integral_constant<int, 0>{}); scale_vertex(std::integral_constant<int, 1>{});
+    scale_vertex(std::integral_constant<int, 2>{}); scale_vertex(std::integral_constant<int, 3>{});
     // ---- the four waves' partial sums meet in LDS (one vertex column at a time), wave 0 stores ----
     __syncthreads();
     float* red = reinterpret_cast<float*>(gx_smem);               // [3 waves][64 lanes][33]
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
+    auto reduce_vertex = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
         if (wave > 0) {
 #pragma unroll
-            for (int d = 0; d < 32; ++d)
-                red[((wave - 1) * 64 + lane) * 33 + d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
+            for (int d = 0; d < 32; ++d) red[((wave - 1) * 64 + lane) * 33 + d] = acc[c][d];
         }
         __syncthreads();
         if (wave == 0) {
             const int vi = v0 + c;
             float s[32];
 #pragma unroll
-            for (int d = 0; d < 32; ++d) {
-                s[d] = (c == 0) ? acc[0][d] : (c == 1) ? acc[1][d] : (c == 2) ? acc[2][d] : acc[3][d];
-                s[d] += red[(0 * 64 + lane) * 33 + d] + red[(1 * 64 + lane) * 33 + d] + red[(2 * 64 + lane) * 33 + d];
-            }
+            for (int d = 0; d < 32; ++d)
+                s[d] = acc[c][d] + red[(0 * 64 + lane) * 33 + d] + red[(1 * 64 + lane) * 33 + d] + red[(2 * 64 + lane) * 33 + d];
             if (vi < L) {
                 float* out = g_links + ((size_t)b * L + vi) * TR + S;
                 if (TR - S >= 32 && (TR & 3) == 0) {
@@ -517,7 +516,9 @@ __global__ __launch_bounds__(256, 2) void dag_grad_links_exp_kernel(
             }
         }
         __syncthreads();
-    }
+    };
+    reduce_vertex(std::integral_constant<int, 0>{}); reduce_vertex(std::integral_constant<int, 1>{});
+    reduce_vertex(std::integral_constant<int, 2>{}); reduce_vertex(std::integral_constant<int, 3>{});
 }
 
 // PROCESS-wide: dsp_dag_loss_bwd is called from PyTorch's autograd worker thread, not from the thread that pins the kernel (a
@@ -569,13 +570,13 @@ int launch_dag_bwd_generic(const float* g_out, const float* alpha, const float* 
     const int fuse = g_k5_fuse.load();
     // windows 33 .. 128 (r06): the TR <= 32 kernel with one plane of workgroups per block of 32 transitions (gridDim.y) — plane k reads beta 32 k
     // columns to the right and owns slots 32 k .. 32 k + 31 of links / grad_links, plane 0 writes grad_match too.  ONE launch (k5_last 6).
-    // C2 at TR = 64 / 96 / 128: 0.92 / 1.23 / 1.52 ms (grad_match pass + tiled log-space kernel) -> 0.46 / 0.70 / 0.89 ms.  Its cost is a latency
-    // chain per wave (~55 us + 0.2-0.3 us per target row, per round of 512 resident workgroups), the tiled kernel's is proportional to the terms
-    // (~5e12 / s): auto takes the cheaper estimate; k5_path 3 pins the planes, 1 / 2 the tiled kernel / the dense block products.
+    // C2 at TR = 64 / 96 / 128: 0.92 / 1.23 / 1.52 ms (grad_match pass + tiled log-space kernel) -> 0.40 / 0.56 / 0.73 ms.  Its cost is a latency
+    // chain per wave (~37 us + 0.2-0.3 us per target row, per round of 512 resident workgroups), the tiled kernel's is proportional to the terms
+    // (~6e12 / s): auto takes the cheaper estimate; k5_path 3 pins the planes, 1 / 2 the tiled kernel / the dense block products.
     if (g_links && TR > 32 && TR <= 128 && rows16 && (g_k5_path == 0 || g_k5_path == 3)) {
         const double planes = (TR + 31) / 32, nwg = (double)((L + 255) / 256) * B * planes;
-        const double est_planes = std::ceil(nwg / 512.0) * (55.0 + (nwg <= 256 ? 0.20 : 0.30) * T);      // fitted on ten shapes, profiles/r06_bwd_windows_33_128.txt
-        const double est_tiled = 45.0 + (double)B * T * L * TR / 5.2e6;
+        const double est_planes = std::ceil(nwg / 512.0) * (37.0 + (nwg <= 256 ? 0.20 : 0.30) * T);      // fitted on ten shapes, profiles/r06_bwd_windows_33_128.txt
+        const double est_tiled = 40.0 + (double)B * T * L * TR / 6.0e6;
         if (g_k5_path == 3 || est_planes < est_tiled) {
             const bool fa = g_match && pitched_m && fuse != 3 && ((((uintptr_t)match) | ((uintptr_t)g_match)) & 15) == 0;
             int rc;
