@@ -778,12 +778,12 @@ def main():
                     tr_full["extract_links"] = {"error": repr(e)[:200]}
             except Exception as e:      # noqa: a leg of its own, the headline does not depend on it
                 tr_full = {"error": repr(e)[:200]}
-        # 32 < TR <= 64: exp-space strips with two vertices per lane (forward), values-only max-DP strips (alignment), tiled log-space K5 (backward)
+        # 32 < TR <= 64: exp-space strips with two vertices per lane (forward), values-only max-DP strips (alignment), the TR <= 32 gradient kernel in two planes of 32 transitions (backward)
         tr64 = None
         try:
             p64, _, i64 = run_dag_ops(ctx, args.dag_batch, args.graph_len, args.tgt_len, args.vocab, 64, 3, 1, 55 + rank)
             b64 = 2.0 * (2 * args.dag_batch * args.tgt_len * args.graph_len * 4.0 + args.dag_batch * args.graph_len * 64 * 4.0)
-            tr64 = {"workload": "C2 with TR=64 (windows 33..64: dag_dp_strip2g forward, dag_dp_maxstripw alignment, K4 + tiled log-space K5 backward)", "phases_ms": p64,
+            tr64 = {"workload": "C2 with TR=64 (windows 33..64: dag_dp_strip2g forward, dag_dp_maxstripw alignment, backward = the exp-space gradient kernel in two planes of 32 transitions, one launch)", "phases_ms": p64,
                     "dag_loss_fwd_bwd_ms": p64["dag_fwd"] + p64["dag_bwd"], "dag_fwd_frac_of_hbm_peak": b64 / (p64["dag_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, **i64}
         except Exception as e:      # noqa
             tr64 = {"error": repr(e)[:200]}
