@@ -66,6 +66,7 @@ SIGNATURES = {
     "dsp_extract_links_bwd_ws": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           ctypes.c_float, _c_p, _c_sz, _c_p]),
     "dsp_extract_links_debug_ran": (ctypes.c_uint, []),
+    "dsp_extract_links_debug_range": (ctypes.c_uint, []),
     "dsp_posterior": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "dsp_posterior_features": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "dsp_posterior_features_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),

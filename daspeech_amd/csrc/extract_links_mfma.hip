@@ -58,9 +58,21 @@ struct XmParams {
     int B, L, TR, NT; float scale;
 };
 
+// RANGE (r05 ADVICE): the hi piece is an fp16 — an operand beyond +-65504 (k itself, or q * scale * log2(e)) has no split.  Such a value is
+// CLAMPED to +-65 000 (the result stays finite, and is wrong for that element) and the launch raises g_xl_range, which
+// dsp_extract_links_debug_range() returns and clears; the fp32-FMA kernels (xl_mfma 0) have no such limit.  Link-predictor inputs are
+// projections of layer-normed features (|x| ~ 1-10): four orders of magnitude of head-room.
+__device__ unsigned int g_xl_range;
 __device__ __forceinline__ void xm_split8(const float* x, xm_h8& hi, xm_h8& lo) {
+    bool over = false;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)x[e]; lo[e] = (_Float16)((x[e] - (float)hi[e]) * 2048.f); }
+    for (int e = 0; e < 8; ++e) {
+        const bool big = fabsf(x[e]) > 65000.f;                                    // (false for NaN: a NaN operand stays a NaN)
+        const float xc = big ? copysignf(65000.f, x[e]) : x[e];
+        over |= big;
+        hi[e] = (_Float16)xc; lo[e] = (_Float16)((xc - (float)hi[e]) * 2048.f);
+    }
+    if (__builtin_expect(over, 0)) atomicOr(&g_xl_range, 1u);
 }
 
 // pre-pass: x [B,L,8,64] fp32 -> A fragments [B][8 heads][NT tiles of 32 rows][4 steps][hi, lo][64 lanes][8 halves]; rows past L are zeros
@@ -586,6 +598,14 @@ static bool xm_bf16_contraction(int L) { const int c = g_xl_contract.load(); ret
 static size_t xm_bwd_bytes(int B, int L) { return 2 * xm_split_bytes(B, L) + 2 * xm_split_t_bytes(B, L); }
 
 }  // namespace dsp
+
+extern "C" unsigned int dsp_extract_links_debug_range(void)
+{
+    unsigned int v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(dsp::g_xl_range), sizeof(v)) != hipSuccess) return 0xffffffffu;       // (synchronises the device: tests only)
+    if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(dsp::g_xl_range), &z, sizeof(z));
+    return v;
+}
 
 extern "C" int dsp_extract_links_workspace(int B, int L, int H, int CK, int TR, int training, size_t* bytes)
 {

@@ -96,6 +96,11 @@ int dsp_extract_links_bwd_ws(const float* q, const float* k, const float* log_ga
  *   6 matrix-core backward with bf16-triple contractions.  The "xl_tile" / "xl_mfma" / "xl_contract" options are PROCESS-wide (PyTorch runs an
  *   autograd backward on its own worker thread); tests assert through this word that the family they pinned is the one that ran. */
 unsigned int dsp_extract_links_debug_ran(void);
+/* RANGE of the matrix-core kernels (dsp_extract_links_ws / _bwd_ws): operands are split into fp16 hi / lo pieces, so |k| and |q| * scale * log2(e)
+ *   must stay under 65 000 (link-predictor inputs are projections of layer-normed features: |x| ~ 1-10).  A larger operand is clamped — the call
+ *   returns finite, wrong values for it — and raises a device flag; this call returns the flag (1 = some operand was clamped since the last call)
+ *   and clears it.  It synchronises the device: for tests and debugging.  The fp32-FMA kernels (dsp_extract_links, "xl_mfma" 0) have no limit. */
+unsigned int dsp_extract_links_debug_range(void);
 
 /* F1   posterior of the forward-backward pass                                  (s2s_dag_fastspeech2_loss.py:259-261)
  *   score[b,t,:] = exp(alpha+beta - logsumexp_j(alpha+beta)), NaN -> 0 (rows without any finite entry). fp32 [B,T,L]. */

@@ -534,6 +534,38 @@ def test_matrix_core_extract_links_equal_the_fp32_kernels(B, L, TR, lens, use_bi
 
 
 @pytest.mark.gpu
+def test_matrix_core_extract_links_flags_operands_beyond_the_fp16_split():
+    """r05 ADVICE: the matrix-core kernels split their operands into fp16 pieces; a k (or q * scale * log2 e) beyond +-65504 has no split.  Such
+    an operand is clamped (finite output, no inf / NaN poisoning of the soft-max row) and dsp_extract_links_debug_range() reports it; in-range
+    inputs leave the flag clear, a NaN operand stays a NaN and is not reported as a range overflow."""
+    from daspeech_amd import _lib, decode_ops
+    lib = _lib.load()
+    B, L, TR = 2, 96, 95
+    olen, q0, k0, g0, w, bias = _links_case(B, L, 64, TR, [96, 70], 3)
+    try:
+        _lib.set_option("xl_mfma", 1)
+        lib.dsp_extract_links_debug_range()
+        with torch.no_grad():
+            ok = decode_ops.extract_links(q0, k0, g0, olen, TR, bias)
+        torch.cuda.synchronize()
+        assert lib.dsp_extract_links_debug_ran() & 0b100, "the matrix-core forward ran"
+        assert lib.dsp_extract_links_debug_range() == 0
+        k1 = k0.clone(); k1[0, 40, 3, 7] = 1.0e5
+        with torch.no_grad():
+            big = decode_ops.extract_links(q0, k1, g0, olen, TR, bias)
+        torch.cuda.synchronize()
+        assert lib.dsp_extract_links_debug_range() == 1 and lib.dsp_extract_links_debug_range() == 0       # reported once, then cleared
+        assert not torch.isnan(big).any() and torch.equal(torch.isneginf(big), torch.isneginf(ok))
+        k2 = k0.clone(); k2[1, 5, 0, 0] = float("nan")
+        with torch.no_grad():
+            decode_ops.extract_links(q0, k2, g0, olen, TR, bias)
+        torch.cuda.synchronize()
+        assert lib.dsp_extract_links_debug_range() == 0
+    finally:
+        _lib.set_option("xl_mfma", -1)
+
+
+@pytest.mark.gpu
 def test_matrix_core_extract_links_at_baseline_graph_size():
     """BASELINE's graph (L = 4096) with the README's dense window (TR = L-1), B = 8 ragged samples: the dispatch must pick the matrix-core kernels
     by itself; size-independent properties (every row with a successor is a distribution over its valid transitions; the -inf pattern is the
