@@ -346,7 +346,7 @@ static int at_launch(const AtParams& p, hipStream_t st)
     using L = AtLds<DK>;
     const size_t lds = 2 * (size_t)L::STAGE + (REL ? (size_t)L::PRING * L::PBLK + (size_t)AT_WAVES * L::SCR : 0);
     auto k = attention_split_kernel<DK, REL>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(p.ntq * p.H * p.B)), dim3(256), lds, st, p);
     return check_launch("attention_split");
 }

@@ -16,6 +16,7 @@ namespace dsp {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void set_max_dynamic_lds(const void* fn, int bytes);      // hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per (kernel, device) instead of per launch
 
 static inline hipStream_t as_stream(dsp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

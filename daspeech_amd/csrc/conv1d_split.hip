@@ -317,7 +317,7 @@ static int cs_launch(const CsParams& p, hipStream_t st)
     const size_t lds = (size_t)2 * (NT + p.ntaps - 1) * CI * 2;
     if (lds > 160 * 1024) { set_error("conv1d_split: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = conv1d_split_kernel<CI, MT, NT, WM, WN>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, ((p.M + MT - 1) / MT) * (p.kparts > 1 ? p.kparts : 1), p.B), dim3(WM * WN * 64), lds, st, p);
     return check_launch("conv1d_split");
 }

@@ -483,7 +483,7 @@ int launch_dag_dense_max(const float* match, const float* links, const int64_t* 
     const int TM = 16 * mt;
     const size_t lds = (size_t)(2 * TM * 64 + 2 * 64 * DX_WP + 2 * TM + TM * 64 + 64 + TM * 64 + 4 + TM * 64) * 4 + 64;
     auto k = mt == 2 ? (big ? dag_dense_max_kernel_occ2<2> : dag_dense_max_kernel<2>) : (big ? dag_dense_max_kernel_occ2<1> : dag_dense_max_kernel<1>);
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(B * NJ)), dim3(256), lds, st, p);
     rc = check_launch("dag_best_alignment(dense max-plus)");
     if (rc || !path) return rc;
@@ -498,7 +498,7 @@ static int launch_dense_backtrace(const float* alpha_max, const unsigned short* 
     while (ring > 1 && (size_t)L * 4 + (size_t)ring * L * 6 > 150 * 1024) --ring;
     if (ring < 3 || L > 48 * 192) ring = 0;
     const size_t lds2 = (size_t)L * 4 + (size_t)ring * L * 6;
-    (void)hipFuncSetAttribute((const void*)dag_dense_backtrace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    set_max_dynamic_lds((const void*)dag_dense_backtrace_blk_kernel, (int)lds2);
     hipLaunchKernelGGL(dag_dense_backtrace_blk_kernel, dim3((unsigned)B), dim3(256), lds2, st, alpha_max, btrace, links, out_len, tgt_len, path, B, T, L, TR, ring);
     return check_launch("dag_best_alignment(dense back-trace)");
 }

@@ -924,7 +924,7 @@ static int launch_dm(const DMParams& p, int nwg, hipStream_t st)
     constexpr int TM = DM_TM * MT;
     const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
     auto k = dag_dense_mfma_kernel<D, MT>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
     return check_launch("dag_loss_fwd(dense mfma)");
 }
@@ -978,7 +978,7 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
         const int TM = DM_TM * mt;
         const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
         auto k = mt == 3 ? dag_dense_mfma_kernel_occ2<1, 3> : dag_dense_mfma_kernel_occ2<1, 4>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_dynamic_lds((const void*)k, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
         return then_standby(check_launch("dag_loss_fwd(dense mfma)"));
     }
@@ -986,7 +986,7 @@ int launch_dag_dense_mfma(const float* match, const float* links, const int64_t*
         constexpr int TM = DM_TM * 2;
         const size_t lds = (size_t)(2 * TM * DM_AP + 2 * DM_ET + 6 * TM + 4 + 2 * TM + 68 + 64) * 4 + 64;
         auto k = dag_dense_mfma_kernel_occ2<1, 2>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_dynamic_lds((const void*)k, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, st, p);
         return then_standby(check_launch("dag_loss_fwd(dense mfma)"));
     }

@@ -196,7 +196,7 @@ extern "C" int dsp_dag_loss_fwd_f64(const double* match, const double* links, co
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || (!alpha && !beta)) { set_error("dag_loss_fwd_f64: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag64_logsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag64_logsum_kernel, (int)lds);
     hipLaunchKernelGGL(dag64_logsum_kernel, dim3(B, (alpha && beta) ? 2 : 1), dim3(D64_THREADS), lds, st, match, links, out_len, tgt_len, alpha, beta, B, T, L, TR);
     if ((rc = check_launch("dag_loss_fwd_f64"))) return rc;
     if (loss) {
@@ -237,7 +237,7 @@ extern "C" int dsp_dag_best_alignment_f64(const double* match, const double* lin
     if (B == 0) return DSP_OK;
     if (!match || !links || !out_len || !tgt_len || !alpha_max || !trace || !path) { set_error("dag_best_alignment_f64: null pointer"); return DSP_EINVAL; }
     hipStream_t st = as_stream(stream);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag64_maxalpha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag64_maxalpha_kernel, (int)lds);
     hipLaunchKernelGGL(dag64_maxalpha_kernel, dim3(B), dim3(D64_THREADS), lds, st, match, links, out_len, tgt_len, alpha_max, trace, B, T, L, TR);
     if ((rc = check_launch("dag_best_alignment_f64"))) return rc;
     return launch_backtrace(trace, out_len, tgt_len, path, B, T, L, st);

@@ -453,7 +453,7 @@ int launch_backtrace(const int32_t* trace, const int64_t* out_len, const int64_t
 {
     const size_t lds2 = (size_t)L * sizeof(int32_t);
     if (lds2 > 160 * 1024) { set_error("dag_best_alignment: graph size L=%d too large for the back-trace row image", L); return DSP_EINVAL; }
-    if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_backtrace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (lds2 > 48 * 1024) set_max_dynamic_lds((const void*)dag_backtrace_kernel, (int)lds2);
     hipLaunchKernelGGL(dag_backtrace_kernel, dim3(B), dim3(256), lds2, st, trace, out_len, tgt_len, path, B, T, L);
     return check_launch("dag_best_alignment(back-trace)");
 }
@@ -487,12 +487,12 @@ int launch_dag_fwd_generic(const float* match, const float* links, const int64_t
 {
     const size_t lds = 2 * (size_t)L * sizeof(float);
     if (lds > 160 * 1024) { set_error("dag_loss: graph size L=%d exceeds the generic kernel's LDS rows (max 20480)", L); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_logsum_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag_logsum_generic_kernel, (int)lds);
     const int ndir = (alpha && beta) ? 2 : 1;
     if (TR > 64) {                                       // dense window: wave-per-column kernel
         const float* in = alpha ? incoming_links(links, B, L, TR, st) : links;
         if (in) {
-            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag_dense_kernel<0>, (int)lds);
             const int NS = dense_slices(dag_dense_kernel<0>, lds, B * ndir, L);
             unsigned int* cnt = nullptr; unsigned long long* gran = nullptr; unsigned int tag_base = 0;
             int rcw = banded_acquire_ws(st, (size_t)B * ndir * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);
@@ -522,7 +522,7 @@ int launch_dag_dense_rows_gated(const float* match, const float* links, const in
     const int ndir = (alpha && beta) ? 2 : 1;
     const float* in = alpha ? incoming_links(links, B, L, TR, st, gate) : links;
     if (!in) { set_error("dag_loss_fwd: no memory for the stand-by log-space path (B*L*TR*4 bytes)"); return DSP_ENOSPC; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag_dense_kernel<0>, (int)lds);
     const int NS = dense_slices(dag_dense_kernel<0>, lds, B * ndir, L);
     hipLaunchKernelGGL(dag_dense_kernel<0>, dim3(B, ndir, NS), dim3(DP_THREADS), lds, st, match, links, in, out_len, tgt_len,
                        alpha, beta, (int32_t*)nullptr, B, T, L, TR, cnt, gran, tag_base, gate);
@@ -546,12 +546,12 @@ int launch_max_alpha_generic(const float* match, const float* links, const int64
 {
     const size_t lds = 2 * (size_t)L * sizeof(float);
     if (lds > 160 * 1024) { set_error("dag_best_alignment: graph size L=%d too large (max 20480)", L); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_maxalpha_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)dag_maxalpha_generic_kernel, (int)lds);
     if (TR > 64) {
         const float* in = incoming_links(links, B, L, TR, st);
         const size_t lds3 = 3 * (size_t)L * sizeof(float);
         if (in && lds3 <= 160 * 1024) {
-            if (lds3 > 48 * 1024) (void)hipFuncSetAttribute((const void*)dag_dense_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (lds3 > 48 * 1024) set_max_dynamic_lds((const void*)dag_dense_kernel<1>, (int)lds3);
             const int NS = dense_slices(dag_dense_kernel<1>, lds3, B, L);
             unsigned int* cnt = nullptr; unsigned long long* gran = nullptr; unsigned int tag_base = 0;
             int rcw = banded_acquire_ws(st, (size_t)B * 2 * L * sizeof(unsigned long long), T, &cnt, &gran, &tag_base);

@@ -664,7 +664,7 @@ static int launch_one_mx(const MStripParams& p, int nwg, hipStream_t st)
     const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     auto k = dag_maxstrip_kernel<NT, CPL>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(NT + 192), lds, st, p);
     return check_launch("dag_best_alignment(maxstrip)");
 }
@@ -699,12 +699,12 @@ int launch_dag_maxstrip(const float* match, const float* links, const int64_t* o
     if (rc) return rc;
     if (TR == 32 && g_bt_ring && (((uintptr_t)links) & 15) == 0) {
         const size_t lds3 = ((size_t)BR_RW * 32 + 2 * BR_H * BR_SEG + (size_t)L) * 4;
-        (void)hipFuncSetAttribute((const void*)dag_backtrace_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        set_max_dynamic_lds((const void*)dag_backtrace_ring_kernel, (int)lds3);
         hipLaunchKernelGGL(dag_backtrace_ring_kernel, dim3(B), dim3(256), lds3, st, alpha_max, links, out_len, tgt_len, path, B, T, L, ldo);
         return check_launch("dag_best_alignment(ring back-trace)");
     }
     const size_t lds2 = ((size_t)BT_LW * TR + BT_HOPS * BT_SEG + (size_t)L) * 4;
-    (void)hipFuncSetAttribute((const void*)dag_backtrace_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    set_max_dynamic_lds((const void*)dag_backtrace_lazy_kernel, (int)lds2);
     hipLaunchKernelGGL(dag_backtrace_lazy_kernel, dim3(B), dim3(256), lds2, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR, ldo);
     return check_launch("dag_best_alignment(lazy back-trace)");
 }

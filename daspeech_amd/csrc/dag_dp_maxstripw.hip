@@ -405,7 +405,7 @@ static int launch_mw(MWParams& p, int B, int T, int L, hipStream_t st)
     const size_t lds_tile = (size_t)(W + TRP) * 65 * 4 + 16;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     auto k = dag_maxstripw_kernel<CPL>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(B * p.NS)), dim3(MW_NT + 192), lds, st, p);
     return check_launch("dag_best_alignment(maxstripw)");
 }
@@ -420,7 +420,7 @@ int launch_dag_maxstripw(const float* match, const float* links, const int64_t* 
     int rc = TR <= 64 ? launch_mw<2>(p, B, T, L, st) : launch_mw<1>(p, B, T, L, st);
     if (rc) return rc;
     const size_t lds = (size_t)L * 4;
-    (void)hipFuncSetAttribute((const void*)dag_backtrace_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)dag_backtrace_wide_kernel, (int)lds);
     hipLaunchKernelGGL(dag_backtrace_wide_kernel, dim3(B), dim3(64), lds, st, alpha_max, links, out_len, tgt_len, path, B, T, L, TR, ldo);
     return check_launch("dag_best_alignment(wide back-trace)");
 }

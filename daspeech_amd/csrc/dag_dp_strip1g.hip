@@ -501,7 +501,7 @@ int launch_dag_strip1g(const float* match, const float* links, const int64_t* ou
     const size_t lds_main = (size_t)(4 * H1_RL + 2 * H1_GL + H1_RING * H1_W) * 4 + 16;
     const size_t lds_tile = (size_t)(H1_W + H1_TRP) * 65 * 4 + 16;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
-    (void)hipFuncSetAttribute((const void*)dag_strip1g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)dag_strip1g_kernel, (int)lds);
     hipLaunchKernelGGL(dag_strip1g_kernel, dim3((unsigned)(ndir * B * NS)), dim3(H1_NT + 192), lds, st, p);
     return check_launch("dag_loss_fwd(strip1g)");
 }

@@ -503,7 +503,7 @@ static int launch_strip2(const StripParams& p, int nwg, hipStream_t st)
     size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     { static const char* const e = getenv("DSP_S2_LDS"); if (e) lds = (size_t)atoi(e); }
     auto k = dag_strip2_kernel<NT, MODE>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     static const char* const e_dbg = getenv("DSP_DEBUG");
     if (e_dbg) {
         int nb = -1;

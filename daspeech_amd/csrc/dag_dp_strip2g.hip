@@ -508,7 +508,7 @@ int launch_dag_strip2g(const float* match, const float* links, const int64_t* ou
     const size_t lds_main = (size_t)(4 * H2_RL + 2 * H2_GL + H2_RING * H2_W) * 4 + 16;
     const size_t lds_tile = (size_t)(H2_W + H2_TRP) * 65 * 4 + 16;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
-    (void)hipFuncSetAttribute((const void*)dag_strip2g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)dag_strip2g_kernel, (int)lds);
     hipLaunchKernelGGL(dag_strip2g_kernel, dim3((unsigned)(ndir * B * NS)), dim3(H2_NT + 192), lds, st, p);
     return check_launch("dag_loss_fwd(strip2g)");
 }

@@ -629,7 +629,7 @@ static int launch_one_g(const GStripParams& p, int nwg, hipStream_t st)
     const size_t lds_tile = (size_t)(W + 32) * 33 * 4;
     const size_t lds = (lds_main > lds_tile ? lds_main : lds_tile) + 32;
     auto k = dag_strip4g_kernel<NT, 0, PROF>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(NT + 192), lds, st, p);
     return check_launch("dag_loss_fwd(strip4g)");
 }

@@ -550,7 +550,7 @@ static int launch_gx(const float* g_out, const float* alpha, const float* beta, 
     const size_t lds = (size_t)4 * gx_wave_words(TC, FUSE && !MREG) * 4;
     auto kern = dag_grad_links_exp_kernel<TC, FUSE, MREG, AUX>;
     static const char* const e_rm = getenv("DSP_GX_REMAP");
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)kern, (int)lds);
     hipLaunchKernelGGL(kern, dim3(((L + 255) / 256) * B, (TR + 31) / 32), dim3(256), lds, st,
                        g_out, alpha, beta, links, out_len, tgt_len, g_links, match, g_match, B, T, L, TR, lda, ldm, ldg, e_rm ? 1 : 0);
     return check_launch(FUSE ? "dag_loss_bwd(grad_match + grad_links, exp space, one launch)" : "dag_loss_bwd(grad_links, exp space)");

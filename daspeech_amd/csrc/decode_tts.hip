@@ -465,7 +465,7 @@ extern "C" int dsp_viterbi_collect(const int64_t* path, const int64_t* pred_leng
     if (!path || !pred_length || !unreachable || !tok || !out_tokens || !keep_idx || !n_keep) { set_error("viterbi_collect: null pointer"); return DSP_EINVAL; }
     const size_t lds = (size_t)L * sizeof(int32_t);
     if (lds > 150 * 1024) { set_error("viterbi_collect: L=%d too large for the LDS token image", L); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)viterbi_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)viterbi_collect_kernel, (int)lds);
     hipLaunchKernelGGL(viterbi_collect_kernel, dim3(B), dim3(256), lds, as_stream(stream), path, pred_length, unreachable, tok, pad, out_tokens, keep_idx, n_keep, L, cap);
     return check_launch("viterbi_collect");
 }
@@ -478,7 +478,7 @@ extern "C" int dsp_follow_path(const int32_t* next, const int32_t* tok, const in
     if (!next || !tok || !out_len || !out_tokens || !keep_idx || !n_feat) { set_error("follow_path: null pointer"); return DSP_EINVAL; }
     const size_t lds = (size_t)(2 * L + 2 * cap) * sizeof(int32_t);
     if (lds > 160 * 1024) { set_error("follow_path: L=%d / cap=%d too large for the LDS walk", L, cap); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)follow_path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)follow_path_kernel, (int)lds);
     hipLaunchKernelGGL(follow_path_kernel, dim3(B), dim3(256), lds, as_stream(stream), next, tok, out_len, pad, out_tokens, keep_idx, n_feat, L, cap);
     return check_launch("follow_path");
 }
@@ -503,7 +503,7 @@ extern "C" int dsp_posterior_features(const float* alpha, const float* beta, con
     if (!alpha || !beta || !features || !out) { set_error("posterior_features: null pointer"); return DSP_EINVAL; }
     const size_t lds = (size_t)PF_TT * L * sizeof(float);
     if (lds > 150 * 1024) { set_error("posterior_features: L=%d too large for the posterior rows in LDS", L); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)posterior_features_kernel, (int)lds);
     hipLaunchKernelGGL(posterior_features_kernel, dim3((T + PF_TT - 1) / PF_TT, B), dim3(256), lds, as_stream(stream), alpha, beta, features, out, lse, T, L, D);
     return check_launch("posterior_features");
 }
@@ -516,7 +516,7 @@ extern "C" int dsp_posterior_features_bwd(const float* alpha, const float* beta,
     if (!alpha || !beta || !lse || !grad_out || !grad_features) { set_error("posterior_features_bwd: null pointer"); return DSP_EINVAL; }
     const size_t lds = (size_t)PF_TT * T * sizeof(float);
     if (lds > 150 * 1024) { set_error("posterior_features_bwd: T=%d too large for the posterior columns in LDS", T); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_features_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)posterior_features_bwd_kernel, (int)lds);
     hipLaunchKernelGGL(posterior_features_bwd_kernel, dim3((L + PF_TT - 1) / PF_TT, B), dim3(256), lds, as_stream(stream), alpha, beta, lse, grad_out, grad_features, T, L, D);
     return check_launch("posterior_features_bwd");
 }
@@ -571,7 +571,7 @@ extern "C" int dsp_length_regulator_expand(const void* x, int dtype, const int64
     if (!out || (N && (!x || !cum))) { set_error("length_regulator_expand: null pointer"); return DSP_EINVAL; }
     const size_t lds = (size_t)(N > 0 ? N : 1) * sizeof(long);
     if (lds > 160 * 1024) { set_error("length_regulator_expand: N=%d too large", N); return DSP_EINVAL; }
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)lr_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)lr_expand_kernel, (int)lds);
     int gx = (maxlen + 3) / 4; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(lr_expand_kernel, dim3(gx, B), dim3(256), lds, as_stream(stream), (const char*)x, cum, (char*)out, N,
                        (long)C * es, maxlen);

@@ -582,13 +582,13 @@ extern "C" int dsp_extract_links_train(const float* q, const float* k, const flo
     if (const int TW = xl_tile_width(lds)) {
         const size_t l2 = xl_tiled_lds(CK, TW);
         auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
-        if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        if (l2 > 48 * 1024) set_max_dynamic_lds((const void*)kt, (int)l2);
         hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale, TW);
         g_xl_ran |= 2u;
         return check_launch("extract_links_train(tiled)");
     }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)kern, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
                        q, k, log_gates, out_len, dist_bias, links, stats, B, L, TR, scale);
     g_xl_ran |= 1u;
@@ -603,8 +603,8 @@ static int xl_bwd_launch(const float* q, const float* k, const float* g, const i
     auto ka = extract_links_bwd_kernel<CK4, false>;
     auto kb = extract_links_bwd_kernel<CK4, true>;
     if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_dynamic_lds((const void*)ka, (int)lds);
+        set_max_dynamic_lds((const void*)kb, (int)lds);
     }
     const dim3 grid((L + XL_IT - 1) / XL_IT, B);
     hipLaunchKernelGGL(ka, grid, dim3(256), lds, st, q, k, g, ol, bias, links, G, stats, dg, dq, B, L, TR, scale);
@@ -633,8 +633,8 @@ extern "C" int dsp_extract_links_bwd(const float* q, const float* k, const float
         const dim3 grid((L + XL_IT - 1) / XL_IT, B);
         auto go = [&](auto ka, auto kb) -> int {
             if (l2 > 48 * 1024) {
-                (void)hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-                (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                set_max_dynamic_lds((const void*)ka, (int)l2);
+                set_max_dynamic_lds((const void*)kb, (int)l2);
             }
             hipLaunchKernelGGL(ka, grid, dim3(256), l2, st, q, k, log_gates, out_len, dist_bias, links, grad_links, stats, grad_log_gates, grad_q, B, L, TR, scale, TW);
             int r = check_launch("extract_links_bwd(tiled: dq, dgate)");
@@ -667,13 +667,13 @@ extern "C" int dsp_extract_links(const float* q, const float* k, const float* lo
     if (const int TW = xl_tile_width(lds)) {
         const size_t l2 = xl_tiled_lds(CK, TW);
         auto kt = CK == 64 ? extract_links_tiled_kernel<16> : (CK == 32 ? extract_links_tiled_kernel<8> : extract_links_tiled_kernel<32>);
-        if (l2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        if (l2 > 48 * 1024) set_max_dynamic_lds((const void*)kt, (int)l2);
         hipLaunchKernelGGL(kt, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), l2, as_stream(stream), q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale, TW);
         g_xl_ran |= 2u;
         return check_launch("extract_links(tiled)");
     }
     auto kern = CK == 64 ? extract_links_kernel<16> : (CK == 32 ? extract_links_kernel<8> : extract_links_kernel<32>);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)kern, (int)lds);
     hipLaunchKernelGGL(kern, dim3((L + XL_IT - 1) / XL_IT, B), dim3(256), lds, as_stream(stream),
                        q, k, log_gates, out_len, dist_bias, links, (float*)nullptr, B, L, TR, scale);
     g_xl_ran |= 1u;

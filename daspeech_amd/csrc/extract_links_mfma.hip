@@ -567,7 +567,7 @@ static int xm_launch(const XmParams& p, hipStream_t st, const char* what)
     if (MODE == XM_EMIT) lds = (size_t)(QG == 1 ? 4 : 2) * XM_H * OT * XM_PITCH * sizeof(float);
     else if (MODE >= XM_SA) lds = (size_t)4 * 2 * OT * XM_PITCH * sizeof(float) + (MODE == XM_DK ? 4 * 256 * sizeof(float4) : 0);
     auto k = xl_mfma_kernel<MODE, QG, CT>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.L + OT - 1) / OT) * p.B)), dim3(512), lds, st, p);
     return check_launch(what);
 }

@@ -316,7 +316,7 @@ extern "C" int dsp_ffn_split(const float* x, long ldx, const float* ln_w, const 
     hipStream_t st = as_stream(stream);
     const size_t lds = (size_t)4 * 64 * 256 * 2;
     auto k = ffn_split_kernel<256, 64>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((T + 63) / 64, p.G, B), dim3(512), lds, st, p);
     int rc = check_launch("ffn_split");
     if (rc != DSP_OK) return rc;

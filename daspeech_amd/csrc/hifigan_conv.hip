@@ -238,7 +238,7 @@ static int hg_launch(const HgParams& p, hipStream_t st)
     if (lds_out > lds) lds = lds_out;
     if (lds > 160 * 1024) { set_error("hifigan_conv: input tile %zu bytes exceeds LDS", lds); return DSP_EINVAL; }
     auto k = hifigan_conv_kernel<CI, MT, NT, WM, WN>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     // columns: conv -> T outputs; upsample -> q = 0..T (the last column feeds the tail of the transposed conv)
     const int ncol = (p.out_mode == DSP_HG_OUT_UPSAMPLE) ? p.T + 1 : p.T;
     dim3 grid((ncol + NT - 1) / NT, (p.M + MT - 1) / MT, p.B);
@@ -425,7 +425,7 @@ static int hg_unit_launch(const HgUnitParams& p, hipStream_t st)
     const size_t lds = hg_unit_lds(C, NT, h1);
     if (lds > 160 * 1024) { set_error("hifigan_resunit: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = hifigan_resunit_kernel<C, NT, WM, WN>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, 1, p.B), dim3(512), lds, st, p);
     return check_launch("hifigan_resunit");
 }

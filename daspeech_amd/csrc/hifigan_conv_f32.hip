@@ -235,7 +235,7 @@ static int hgs_launch(const HgsParams& p, hipStream_t st)
     if (lds_out > lds) lds = lds_out;
     if (lds > 160 * 1024) { set_error("hifigan_conv_f32: tiles of %zu bytes exceed LDS (CI=%d, halo %d)", lds, CI, p.max_shift - p.min_shift); return DSP_EINVAL; }
     auto k = hifigan_conv_f32_kernel<CI, MT, NT, WM, WN>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     const int ncol = (p.out_mode == DSP_HG_OUT_UPSAMPLE) ? p.T + 1 : p.T;
     dim3 grid((ncol + NT - 1) / NT, (p.M + MT - 1) / MT, p.B);
     hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
@@ -420,7 +420,7 @@ static int hgs_unit_launch(const HgsUnitParams& p, hipStream_t st)
     const size_t lds = hgs_unit_lds(C, NT, h1);
     if (lds > 160 * 1024) { set_error("hifigan_resunit_f32: tiles need %zu bytes of LDS", lds); return DSP_EINVAL; }
     auto k = hifigan_resunit_f32_kernel<C, NT, WM, WN>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3((p.T + NT - 1) / NT, 1, p.B), dim3(512), lds, st, p);
     return check_launch("hifigan_resunit_f32");
 }

@@ -653,7 +653,7 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
                                                                                                                        : lsg_fwd_regl_kernel<T, 16, false>;
             const long nt = (long)B * ((L + RTg - 1) / RTg);
             const int gridg = (int)(nt < 4096 ? nt : 4096);
-            (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+            set_max_dynamic_lds((const void*)kg, (int)ldsg);
             hipLaunchKernelGGL(kg, dim3(gridg), dim3(256), ldsg, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss, B, L, V, S, RTg, ws, stats);
             return check_launch("logsoftmax_gather(reg, LDS gather, wide rows)");
         }
@@ -673,7 +673,7 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
                 int gridg = (int)(nt < 4096 ? nt : 4096);
                 static const char* const e_grid = getenv("DSP_K1_GRID");        // (tuning switches: read once per process)
                 if (e_grid) gridg = atoi(e_grid);
-                if (ldsg > 48 * 1024) (void)hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+                if (ldsg > 48 * 1024) set_max_dynamic_lds((const void*)kg, (int)ldsg);
                 hipLaunchKernelGGL(kg, dim3(gridg), dim3(256), ldsg, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
                                    B, L, V, S, RTg, ws, stats);
                 return check_launch("logsoftmax_gather(reg, LDS gather)");
@@ -686,13 +686,13 @@ static int launch_fwd(void* logits, const int64_t* idx, int64_t isb, int64_t isj
         static const char* const e_rt = getenv("DSP_K1_RT"); static const char* const e_grid2 = getenv("DSP_K1_GRID");
         if (e_rt) { RTr = atoi(e_rt); const long nt = (long)B * ((L + RTr - 1) / RTr); gridr = (int)(nt < 65535 * 4 ? nt : 65535 * 4); if (e_grid2) gridr = atoi(e_grid2); }
         const size_t ldsr = (32 + (size_t)S * RTr) * sizeof(float);
-        if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+        if (ldsr > 48 * 1024) set_max_dynamic_lds((const void*)kr, (int)ldsr);
         hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
                            B, L, V, S, RTr, ws, stats);
         return check_launch("logsoftmax_gather(reg)");
     }
     auto k = vec ? lsg_fwd_kernel<T, true> : lsg_fwd_kernel<T, false>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)logits, idx, isb, isj, iss, match, osb, osj, oss,
                        B, L, V, S, RT, ws, stats);
     return check_launch("logsoftmax_gather");
@@ -719,7 +719,7 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
                     : nvec <= 14 ? lsg_bwd_reg_kernel<T, 14, LAZY, 3, false> : lsg_bwd_reg_kernel<T, 16, LAZY, 3, false>;
             const long nt = (long)B * ((L + RT - 1) / RT);
             const int gridr = (int)(nt < 4096 ? nt : 4096);
-            (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+            set_max_dynamic_lds((const void*)kr, (int)ldsr);
             hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT, stats);
             return check_launch("logsoftmax_gather_bwd(reg, wide rows)");
         }
@@ -733,14 +733,14 @@ static int launch_bwd(void* sm, const int64_t* idx, int64_t isb, int64_t isj, in
             const long nt = (long)B * ((L + RT - 1) / RT);
             int gridr = (int)(nt < 4096 ? nt : 4096);
             { static const char* const e = getenv("DSP_K1B_GRID"); if (e) gridr = atoi(e); }
-            if (ldsr > 48 * 1024) (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+            if (ldsr > 48 * 1024) set_max_dynamic_lds((const void*)kr, (int)ldsr);
             hipLaunchKernelGGL(kr, dim3(gridr), dim3(256), ldsr, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, RT, stats);
             return check_launch("logsoftmax_gather_bwd(reg)");
         }
     }
     const int grid = (int)(nrows < 2048 ? nrows : 2048);
     auto k = vec ? lsg_bwd_kernel<T, true, LAZY> : lsg_bwd_kernel<T, false, LAZY>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) set_max_dynamic_lds((const void*)k, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (T*)sm, idx, isb, isj, iss, g, gsb, gsj, gss, B, L, V, S, stats);
     return check_launch("logsoftmax_gather_bwd");
 }
