@@ -238,19 +238,25 @@ def _c2_inputs(TR, B=32, T=512, L=4096, seed=0):
     return match, links, out_len.to(d), tgt_len.to(d)
 
 
-@pytest.mark.parametrize("TR", [32])
+@pytest.mark.parametrize("TR", [32, 64])
 def test_full_size_properties(TR):
     """BASELINE.json config 2 (B=32, L=4096, T=512): forward/backward consistency, posterior normalisation,
-    transition-count identity, Viterbi path validity by re-scoring (the reference's own check, dag_loss.py:497-512)."""
+    transition-count identity, Viterbi path validity by re-scoring (the reference's own check, dag_loss.py:497-512).
+    TR = 64 (r06): the same at the bench's `dag_tr64` leg — strip2g forward, the gradient kernel in two planes of 32 transitions, maxstripw."""
+    import ctypes
+    from daspeech_amd import _lib
     match, links, ol, tl = _c2_inputs(TR)
     B, T, L = match.shape
     m = match.clone().requires_grad_(); k = links.clone().requires_grad_()
+    diag = (ctypes.c_uint * 4)(); _lib.load().dsp_dag_debug_k5(diag)
     loss, (alpha, beta) = ops().dag_loss_with_alpha_beta(m, k, ol, tl)
     ar = torch.arange(B, device=dev())
     a_end = alpha[ar, tl - 1, ol - 1]
     assert torch.isfinite(loss).all()
     torch.testing.assert_close(a_end, loss.detach(), rtol=2e-5, atol=0.0)     # beta[0,0] == alpha[end]
     gm, gl = torch.autograd.grad(loss.sum(), [m, k])
+    torch.cuda.synchronize(); _lib.load().dsp_dag_debug_k5(diag)
+    assert diag[3] == (5 if TR == 32 else 6), diag[3]                          # one fused launch / one launch of two planes: the kernels the bench line times
     rows = gm.sum(-1)                                                          # sum_j posterior(t, j) = 1 for t < T_b
     tmask = torch.arange(T, device=dev()).view(1, T) < tl.view(B, 1)
     assert (rows[tmask] - 1).abs().max() < 0.05, (rows[tmask] - 1).abs().max()
