@@ -1,7 +1,5 @@
-mkdir -p gpurun_out/fz
-for args in "600 11 mid" "600 12 mid weak" "600 13 mid2" "600 14 mid2 weak"; do
-  echo "== DSP_FUZZ_K5=3 fuzz_dag.py $args" >> gpurun_out/fz/fuzz.txt
-  DSP_FUZZ_K5=3 timeout 900 python tools/fuzz_dag.py $args 2>&1 | tail -4 >> gpurun_out/fz/fuzz.txt
+mkdir -p gpurun_out/fz; rm -f gpurun_out/fz/replay.txt
+for k5 in 0 1; do
+  echo "== k5_path $k5" >> gpurun_out/fz/replay.txt
+  DSP_FUZZ_ONLY=216 DSP_FUZZ_K5=$k5 timeout 900 python tools/fuzz_dag.py 500 22 narrow weak 2>&1 | grep -v amdgpu | cut -c1-600 >> gpurun_out/fz/replay.txt
 done
-echo "== fuzz_dag.py 400 15 (narrow windows, auto)" >> gpurun_out/fz/fuzz.txt
-timeout 900 python tools/fuzz_dag.py 400 15 2>&1 | tail -3 >> gpurun_out/fz/fuzz.txt

@@ -50,6 +50,8 @@ for case in range(n):
     m = torch.from_numpy(match).to(dev).requires_grad_(); k = torch.from_numpy(links).to(dev).requires_grad_()
     o = torch.from_numpy(ol).to(dev); t = torch.from_numpy(tl).to(dev)
     tag = f"case {case}: B={B} T={T} L={L} TR={TR}"
+    if os.environ.get("DSP_FUZZ_ONLY") and case != int(os.environ["DSP_FUZZ_ONLY"]):      # replay ONE case of a sweep (the draws above keep the stream aligned)
+        continue
     try:
         loss, (alpha, beta) = ops.dag_loss_with_alpha_beta(m, k, o, t)
         st_ = _lib.last_launch_status()
@@ -64,7 +66,16 @@ for case in range(n):
         if fin.any():
             gm, gl = torch.autograd.grad(loss[fin].sum(), [m, k])
             gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
-            gt = max(3e-3, 2e-5 * T)           # exp() of sums carrying fp32 rounding of T rows
+            if os.environ.get("DSP_FUZZ_ONLY"):
+                g_ = gm.cpu().numpy(); big = np.abs(gm64) > 1e-3
+                print(tag, "max |alpha|", float(np.abs(a64[np.isfinite(a64)]).max()), "fp32 spacing there", float(np.spacing(np.float32(np.abs(a64[np.isfinite(a64)]).max()))),
+                      "max rel err of grad_match on cells > 1e-3:", float((np.abs(g_ - gm64)[big] / np.abs(gm64)[big]).max()),
+                      "alpha max abs err", float(np.abs(a - a64)[fa].max()), "beta", float(np.abs(b - b64)[fb].max()))
+            # exp() of sums carrying fp32 rounding of T rows; with peaked transitions |alpha| reaches 1e4-1e5 and an fp32 ulp THERE is the floor of
+            # alpha + beta - match - Z (case 216 of sweep "500 22 narrow weak": |alpha| = 20 749, ulp 0.002, alpha off by 0.03 after 729 rows ->
+            # posteriors 2 % off under every gradient kernel family alike)
+            amax = float(np.abs(a64[np.isfinite(a64)]).max()) if np.isfinite(a64).any() else 0.0
+            gt = max(3e-3, 2e-5 * T) + 16 * float(np.spacing(np.float32(amax)))
             np.testing.assert_allclose(gm.cpu().numpy(), gm64, rtol=gt, atol=2e-7)
             np.testing.assert_allclose(gl.cpu().numpy(), gl64, rtol=gt, atol=2e-7)
         path = ops.dag_best_alignment(m.detach(), k.detach(), o, t).cpu().numpy()
