@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_lazy_kernel(
 //     predecessors i >= 0 of a row t - 1 >= 0, inside the segment's range by the 1..32-vertices-per-row bound).
 constexpr int BR_H = 7;                        // hops per iteration
 constexpr int BR_RW = 512;                     // ring rows (>= 64 H + 8 + 32 spare: see above)
-constexpr int BR_SEG = 448;                    // segment pitch: >= 62 H + 1 = 435, a multiple of 64 (one request = 64 columns)
+constexpr int BR_SEG = 512;                    // segment pitch: >= 62 H + 1 + 3 = 438 (the base is aligned down to 4 columns), a multiple of 256 (one request = 64 lanes x 16 bytes)
 
 __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
     const float* __restrict__ amax, const float* __restrict__ links, const int64_t* __restrict__ out_len,
@@ -557,21 +557,24 @@ __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
     bool done = !valid;
 
     // alpha_max segments for the iteration AFTER the one that starts at frame (tF, pF): slot k - 1 = row tF - H - k, columns pF - 32 (H + k) ...
+    // (r06: 16 bytes per lane — a request moves 256 columns, two per segment instead of five to eight 64-column ones: the helpers' round trip
+    //  paced the iteration (1.7 us per 7 hops against 1.1 us of hops), and a third of it was the issue of ~18 requests per wave.  The segment's
+    //  base column is aligned DOWN to 4; rows are 16-byte aligned by the launcher's pitch condition.)
     auto request_segments = [&](int tF, int pF, int buf, int w, int nw) {   // wave w of nw takes every nw-th request
         int r = 0;
 #pragma unroll
         for (int k = 1; k <= BR_H; ++k) {
-            const int row = tF - BR_H - k, col0 = pF - 32 * (BR_H + k), nreq = (31 * (BR_H + k) + 64) >> 6;
+            const int row = tF - BR_H - k, col0 = (pF - 32 * (BR_H + k)) & ~3, nreq = (31 * (BR_H + k) + 4 + 255) >> 8;
             const float* rowp = A + (size_t)(row < 0 ? 0 : row) * LDA;          // wave-uniform
             float* dst = seg + ((size_t)buf * BR_H + (k - 1)) * BR_SEG;
 #pragma unroll
-            for (int j = 0; j < (31 * (2 * BR_H) + 64) / 64; ++j) {
+            for (int j = 0; j < (31 * (2 * BR_H) + 4 + 255) / 256; ++j) {
                 if (j < nreq) {
                     if (r % nw == w) {
-                        int col = col0 + 64 * j + lane;
-                        col = col < 0 ? 0 : (col >= L ? L - 1 : col);
+                        int col = col0 + 256 * j + 4 * lane;                   // a multiple of 4: the lane's four columns lie inside the row's pitch or are clamped away together
+                        col = col < 0 ? 0 : (col > LDA - 4 ? LDA - 4 : col);
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + col),
-                                                         (__attribute__((address_space(3))) void*)(dst + 64 * j), 4, 0, 0);
+                                                         (__attribute__((address_space(3))) void*)(dst + 256 * j), 16, 0, 0);
                     }
                     ++r;
                 }
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void dag_backtrace_ring_kernel(
                 if (t == 0 || pos < t) { done = true; break; }               // row 0 / under the diagonal: trace = -1
                 const int i = pos - 1 - lane;
                 const int ic = i < 0 ? 0 : i;
-                const float av = sg[(h - 1) * BR_SEG + (ic - (pF - 32 * (BR_H + h)))];
+                const float av = sg[(h - 1) * BR_SEG + (ic - ((pF - 32 * (BR_H + h)) & ~3))];
                 const float kv = ring[((ic & (BR_RW - 1)) << 5) + (lane & 31)];
                 const float x = (lane < TR && i >= 0) ? av + kv : NEG_INF;
                 const float mx = bt_max_lanes32(x);                           // lanes >= 32 hold -inf
