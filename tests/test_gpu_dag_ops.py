@@ -652,6 +652,35 @@ def test_windows_33_to_128_backward_in_blocks_of_32_transitions(shape, weak):
         np.testing.assert_allclose(gm_, gm64, rtol=2e-3, atol=1e-7, err_msg=f"k5_path {k5}")
 
 
+@pytest.mark.parametrize("which", ["match", "links"])
+@pytest.mark.parametrize("shape,k5", [((3, 40, 520, 32), 0), ((2, 30, 517, 20), 0), ((2, 40, 392, 48), 3), ((2, 33, 1030, 128), 3), ((2, 20, 500, 100), 1),
+                                      ((2, 24, 300, 299), 0)])
+def test_backward_with_one_gradient_wanted(shape, k5, which):
+    """Only `match_all` or only `links` requires a gradient (the DAG frozen / a detached emission): the launchers then run K4 alone, or K5 alone —
+    on the narrow windows the un-fused exp-space kernel, on 33 .. 128 the planes without their grad_match part — and return None for the other
+    input.  Against the fp64 oracle; the gradient that IS computed equals the one of the both-gradients call bit for bit."""
+    from daspeech_amd import _lib
+    B, T, L, TR = shape
+    match, links, ol, tl = make_dag_inputs(77 + L + TR, B, T, L, TR)
+    try:
+        _lib.set_option("k5_path", k5)
+        m, k, o, t = to_dev(match, links, ol, tl)
+        mb, kb = m.clone().requires_grad_(), k.clone().requires_grad_()
+        lb = ops().dag_loss(mb, kb, o, t)
+        fin = torch.isfinite(lb)
+        gmb, gkb = torch.autograd.grad(lb[fin].sum(), [mb, kb])
+        x = (m if which == "match" else k).clone().requires_grad_()
+        loss = ops().dag_loss(x, k, o, t) if which == "match" else ops().dag_loss(m, x, o, t)
+        (g,) = torch.autograd.grad(loss[fin].sum(), [x])
+        assert _lib.last_launch_status() == 0
+    finally:
+        _lib.set_option("k5_path", 0)
+    assert torch.equal(g, gmb if which == "match" else gkb)
+    a64 = orc.dag_alpha(match, links, ol, tl, np.float64); b64 = orc.dag_beta(match, links, ol, tl, np.float64)
+    gm64, gl64 = orc.dag_grad(fin.cpu().numpy().astype(np.float64), a64, b64, match, links, ol, tl, np.float64)
+    np.testing.assert_allclose(g.cpu().numpy(), gm64 if which == "match" else gl64, rtol=2e-3, atol=1e-7)
+
+
 @pytest.mark.parametrize("shape", [(4, 256, 2048, 2047), (32, 100, 400, 399)])
 def test_dense_window_full_size_c1_and_readme_shape(shape):
     """BASELINE configs[0] (C1: B=4, T=256, L=2048, dense window) and the README's training shape (B=32, T=100, L=400,
